@@ -1,0 +1,421 @@
+// Flash-style scaled-dot-product attention for gfx950, head_dim 64, forward + backward.
+//
+// Replaces the attention core the reference reaches through `sdpa_attention_forward` / `eager_attention_forward`
+// (TF:modeling_whisper.py:215-238, 337-351) for its three shape classes: encoder self (1500x1500, no mask), decoder
+// self (447x447, causal) and cross (447x1500, no mask); no padding mask ever reaches attention in training.
+//
+// CDNA4 design: everything is computed "transposed" so that the softmax row statistics are lane-local:
+//   S^T[key][q] = K . Q^T     (A = K fragment from LDS, B = Q fragment held in registers)
+//   O^T[d][q]   = V^T . P^T   (A = V^T fragment via ds_read_b64_tr_b16, B = P^T straight from the S^T registers)
+// In the 32x32 accumulator layout the column (= query) is lane&31, so max / sum / rescale never cross lanes except
+// for one lane^32 exchange, and P never goes through LDS: the MFMA k-slot order of the P^T operand is simply
+// *defined* as the order in which the S^T accumulator registers hold the keys (key = 16s + 8(e>>2) + 4hi + (e&3)),
+// and the V^T operand is fetched with the same key permutation by choosing the tr-read row addresses.
+// The two backward kernels reuse the same skeleton with the roles of the stationary (register) and streamed (LDS)
+// operands swapped; dK/dV and dQ are produced by separate passes so no atomics are needed (deterministic).
+#include "common.h"
+#include "../../include/dwamd.h"
+
+#define NEG_BIG (-1.0e30f)
+
+struct AttnP {
+    const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse;
+    const bf16* d_o; float* delta; bf16* dq; bf16* dk; bf16* dv;
+    long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int B, H, Lq, Lk;
+    float scale;
+};
+
+// registers r = 8*s2 .. 8*s2+7 of a 32x32 accumulator -> bf16x8 MFMA operand
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = f2bf(x[s2 * 8 + e]);
+    return r;
+}
+
+// 16-byte global load of 8 bf16 of the stationary operand: row `row`, elements col..col+7
+__device__ __forceinline__ bf16x8 ldg8(const bf16* base, long row, long ld, int col) {
+    return *(const bf16x8*)(base + row * ld + col);
+}
+
+// store a transposed 32x32 accumulator block: lane (row = lane&31, hi), regs r -> column cb*32 + (r&3)+8*(r>>2)+4*hi
+__device__ __forceinline__ void store_t(bf16* base, long ld, long row, bool ok, int cb, int hi, const f32x16& a,
+                                        float mul) {
+    if (!ok) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = f2bf(a[g * 4 + e] * mul);
+        *(bf16x4*)(base + row * ld + cb * 32 + g * 8 + hi * 4) = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: block = 4 waves x 32 queries; key/value tiles of 64 rows double-buffered in LDS
+// ---------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];  // [buf][K tile 8K | V tile 8K]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qb0 = blockIdx.x * 128;
+    const int q = qb0 + wave * 32 + ln;          // this lane's query (column of S^T)
+    const bool q_ok = q < p.Lq;
+    const int qc = q_ok ? q : p.Lq - 1;
+    const bf16* Q = p.q + (long)b * p.Lq * p.ldq + h * 64;
+    const bf16* K = p.k + (long)b * p.Lk * p.ldk + h * 64;
+    const bf16* V = p.v + (long)b * p.Lk * p.ldv + h * 64;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = ldg8(Q, qc, p.ldq, kk * 16 + hi * 8);
+
+    int nkt = (p.Lk + 63) >> 6;
+    if (CAUSAL) {
+        const int lim = (min(qb0 + 127, p.Lq - 1) >> 6) + 1;
+        nkt = min(nkt, lim);
+    }
+    const float c = p.scale * 1.4426950408889634f;
+    float m_run = NEG_BIG, l_run = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+
+    stage_tile64<4>(K, p.ldk, 0, p.Lk, smem, wave, lane);
+    stage_tile64<4>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        wait_vm0();
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            stage_tile64<4>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
+            stage_tile64<4>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
+        }
+        const char* tK = smem + buf * 16384;
+        const char* tV = tK + 8192;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, kb, kk, lane), qf[kk], s[kb], 0, 0, 0);
+        }
+        // mask (key tail, causal) and running max
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool ok = key < p.Lk && (!CAUSAL || key <= q);
+                s[kb][r] = ok ? s[kb][r] : NEG_BIG;
+                mx = fmaxf(mx, s[kb][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * c);
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = exp2f((s[kb][r] - m_new) * c);
+                s[kb][r] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(s[kb], s2);
+                const int rb = kb * 32 + s2 * 16 + hi * 4;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tV, db, rb, rb + 8, lane), pf, o[db], 0, 0, 0);
+            }
+    }
+    const float inv = 1.0f / l_run;
+    bf16* O = p.o + (long)b * p.Lq * p.ldo + h * 64;
+    store_t(O, p.ldo, q, q_ok, 0, hi, o[0], inv);
+    store_t(O, p.ldo, q, q_ok, 1, hi, o[1], inv);
+    if (q_ok && hi == 0) p.lse[((long)b * p.H + h) * p.Lq + q] = m_run * p.scale + __logf(l_run);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward pre-pass: delta[b][h][q] = sum_d dO[q][d] * O[q][d]      (one wave handles 8 rows x 8 lanes)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = gid >> 3;  // (b, h, q) flattened
+    const int part = gid & 7;
+    const long total = (long)p.B * p.H * p.Lq;
+    float acc = 0.f;
+    long idx = row < total ? row : total - 1;
+    const int qi = idx % p.Lq;
+    const long bh = idx / p.Lq;
+    const int h = bh % p.H;
+    const long b = bh / p.H;
+    const bf16x8 a = *(const bf16x8*)(p.o + (b * p.Lq + qi) * p.ldo + h * 64 + part * 8);
+    const bf16x8 g = *(const bf16x8*)(p.d_o + (b * p.Lq + qi) * p.lddo + h * 64 + part * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += bf2f(a[e]) * bf2f(g[e]);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (part == 0 && row < total) p.delta[row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward dQ: stationary = 32 queries per wave (Q, dO fragments + lse, delta in registers); stream K, V tiles
+//   S^T = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T[d][q] += K^T . dS^T
+// ---------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int qb0 = blockIdx.x * 128;
+    const int q = qb0 + wave * 32 + ln;
+    const bool q_ok = q < p.Lq;
+    const int qc = q_ok ? q : p.Lq - 1;
+    const bf16* Q = p.q + (long)b * p.Lq * p.ldq + h * 64;
+    const bf16* DO = p.d_o + (long)b * p.Lq * p.lddo + h * 64;
+    const bf16* K = p.k + (long)b * p.Lk * p.ldk + h * 64;
+    const bf16* V = p.v + (long)b * p.Lk * p.ldv + h * 64;
+
+    bf16x8 qf[4], gf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = ldg8(Q, qc, p.ldq, kk * 16 + hi * 8);
+        gf[kk] = ldg8(DO, qc, p.lddo, kk * 16 + hi * 8);
+    }
+    const long sidx = ((long)b * p.H + h) * p.Lq + qc;
+    const float c = p.scale * 1.4426950408889634f;
+    const float lse2 = p.lse[sidx] * 1.4426950408889634f;
+    const float dl = p.delta[sidx];
+
+    int nkt = (p.Lk + 63) >> 6;
+    if (CAUSAL) nkt = min(nkt, (min(qb0 + 127, p.Lq - 1) >> 6) + 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+
+    stage_tile64<4>(K, p.ldk, 0, p.Lk, smem, wave, lane);
+    stage_tile64<4>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        wait_vm0();
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            stage_tile64<4>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
+            stage_tile64<4>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
+        }
+        const char* tK = smem + buf * 16384;
+        const char* tV = tK + 8192;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, kb, kk, lane), qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tV, kb, kk, lane), gf[kk], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool ok = key < p.Lk && (!CAUSAL || key <= q);
+                const float pv = ok ? exp2f(s[r] * c - lse2) : 0.f;
+                s[r] = pv * (dp[r] - dl);  // dS^T
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 df = pack8(s, s2);
+                const int rb = kb * 32 + s2 * 16 + hi * 4;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, db, rb, rb + 8, lane), df, acc[db], 0, 0, 0);
+            }
+        }
+    }
+    bf16* DQ = p.dq + (long)b * p.Lq * p.lddq + h * 64;
+    store_t(DQ, p.lddq, q, q_ok, 0, hi, acc[0], p.scale);
+    store_t(DQ, p.lddq, q, q_ok, 1, hi, acc[1], p.scale);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward dK/dV: stationary = 32 keys per wave (K, V fragments in registers); stream Q, dO tiles (+ lse, delta)
+//   S = Q.K^T, dP = dO.V^T  (rows = queries in registers, column = key = lane&31)
+//   dV^T[d][key] += dO^T . P,   dK^T[d][key] += Q^T . dS
+// ---------------------------------------------------------------------------------------------------------------
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
+    // [buf][Q tile 8K | dO tile 8K | lse 64 f32 | delta 64 f32]
+    constexpr int STG = 16384 + 512;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 17408];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int kb0 = blockIdx.x * 128;
+    const int key = kb0 + wave * 32 + ln;
+    const bool k_ok = key < p.Lk;
+    const int kc = k_ok ? key : p.Lk - 1;
+    const bf16* Q = p.q + (long)b * p.Lq * p.ldq + h * 64;
+    const bf16* DO = p.d_o + (long)b * p.Lq * p.lddo + h * 64;
+    const bf16* K = p.k + (long)b * p.Lk * p.ldk + h * 64;
+    const bf16* V = p.v + (long)b * p.Lk * p.ldv + h * 64;
+    const float* LSE = p.lse + ((long)b * p.H + h) * p.Lq;
+    const float* DEL = p.delta + ((long)b * p.H + h) * p.Lq;
+
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = ldg8(K, kc, p.ldk, kk * 16 + hi * 8);
+        vf[kk] = ldg8(V, kc, p.ldv, kk * 16 + hi * 8);
+    }
+    const float c = p.scale * 1.4426950408889634f;
+    const int nqt = (p.Lq + 63) >> 6;
+    int qt0 = 0;
+    if (CAUSAL) qt0 = kb0 >> 6;  // queries before the first key of this block see none of its keys
+    f32x16 av[2], ak[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { av[0][r] = 0.f; av[1][r] = 0.f; ak[0][r] = 0.f; ak[1][r] = 0.f; }
+
+    auto stage = [&](int qt, int buf) {
+        char* base = smem + buf * 17408;
+        stage_tile64<4>(Q, p.ldq, qt * 64, p.Lq, base, wave, lane);
+        stage_tile64<4>(DO, p.lddo, qt * 64, p.Lq, base + 8192, wave, lane);
+        if (threadIdx.x < 128) {  // waves 0,1: 64 lse + 64 delta values through the same async path (4 B per lane)
+            const int i = threadIdx.x & 63;
+            int qi = qt * 64 + i;
+            qi = qi < p.Lq ? qi : p.Lq - 1;
+            const float* src = (threadIdx.x < 64 ? LSE : DEL) + qi;
+            __builtin_amdgcn_global_load_lds((const glb_void_t*)src,
+                                             (lds_void_t*)(base + 16384 + (threadIdx.x < 64 ? 0 : 256)), 4, 0, 0);
+        }
+    };
+
+    if (qt0 < nqt) stage(qt0, 0);
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const int buf = (qt - qt0) & 1;
+        wait_vm0();
+        __syncthreads();
+        if (qt + 1 < nqt) stage(qt + 1, buf ^ 1);
+        const char* tQ = smem + buf * 17408;
+        const char* tG = tQ + 8192;
+        const float* tL = (const float*)(tQ + 16384);
+        const float* tD = tL + 64;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tQ, qb, kk, lane), kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tG, qb, kk, lane), vf[kk], dp, 0, 0, 0);
+            }
+            f32x16 pr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql = qb * 32 + g * 8 + hi * 4;  // 4 consecutive local queries
+                const f32x4 l4 = *(const f32x4*)(tL + ql);
+                const f32x4 d4 = *(const f32x4*)(tD + ql);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = g * 4 + e;
+                    const int qi = qt * 64 + ql + e;
+                    const bool ok = qi < p.Lq && k_ok && (!CAUSAL || key <= qi);
+                    const float pv = ok ? exp2f(s[r] * c - l4[e] * 1.4426950408889634f) : 0.f;
+                    pr[r] = pv;
+                    s[r] = pv * (dp[r] - d4[e]);  // dS
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(pr, s2);
+                const bf16x8 df = pack8(s, s2);
+                const int rb = qb * 32 + s2 * 16 + hi * 4;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    av[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tG, db, rb, rb + 8, lane), pf, av[db], 0, 0, 0);
+                    ak[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tQ, db, rb, rb + 8, lane), df, ak[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    bf16* DK = p.dk + (long)b * p.Lk * p.lddk + h * 64;
+    bf16* DV = p.dv + (long)b * p.Lk * p.lddv + h * 64;
+    store_t(DK, p.lddk, key, k_ok, 0, hi, ak[0], p.scale);
+    store_t(DK, p.lddk, key, k_ok, 1, hi, ak[1], p.scale);
+    store_t(DV, p.lddv, key, k_ok, 0, hi, av[0], 1.0f);
+    store_t(DV, p.lddv, key, k_ok, 1, hi, av[1], 1.0f);
+}
+
+static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
+
+extern "C" int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
+                           int Lk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int causal, float scale,
+                           void* stream) {
+    if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
+    if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || (ldo & 3)) return DW_EINVAL;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7)) return DW_EINVAL;
+    AttnP p = {};
+    p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
+    dim3 grid((Lq + 127) / 128, H, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, p);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
+extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                           const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk,
+                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                           int64_t lddk, int64_t lddv, int causal, float scale, void* stream) {
+    if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return DW_EINVAL;
+    if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
+    if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || check_ld(ldo) || check_ld(lddo)) return DW_EINVAL;
+    if ((lddq & 3) || (lddk & 3) || (lddv & 3)) return DW_EINVAL;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 15) ||
+        ((uintptr_t)d_o & 15) || ((uintptr_t)dq & 7) || ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7))
+        return DW_EINVAL;
+    AttnP p = {};
+    p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = (float*)lse;
+    p.d_o = (const bf16*)d_o; p.delta = delta; p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)B * H * Lq;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((rows * 8 + 255) / 256), dim3(256), 0, s, p);
+    DW_CHECK_LAUNCH();
+    dim3 gq((Lq + 127) / 128, H, B), gk((Lk + 127) / 128, H, B), block(256);
+    if (causal) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, block, 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, block, 0, s, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, block, 0, s, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, block, 0, s, p);
+    }
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}

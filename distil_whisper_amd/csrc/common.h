@@ -1,0 +1,138 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the Whisper-distillation hot path.
+// Wavefront = 64 lanes everywhere; MFMA tiles are v_mfma_f32_32x32x16_bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void glb_void_t;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+
+#define DW_WAVE 64
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+__device__ __forceinline__ float round_bf16(float x) { return (float)((bf16)x); }
+__device__ __forceinline__ float bits2f(unsigned short u) {
+    return __uint_as_float(((unsigned)u) << 16);
+}
+
+// ---- exact (erf) GELU, as transformers' GELUActivation / F.gelu(approximate='none') ------------------------
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- LDS tile swizzle for [rows][64 bf16] (=128-byte rows) tiles ------------------------------------------------
+// 16-byte slot s (0..7) of row r is stored at physical slot s ^ swz7(r).  The permutation of row bits
+// (bit1->bit2, bit3->bit1, bit2->bit0) makes BOTH access patterns conflict free on gfx950:
+//   * ds_read_b128 of a 32x32x16 MFMA operand fragment (lane -> row lane&31, k-slot 2*kk+(lane>>5)), and
+//   * ds_read_b64_tr_b16 of 4 consecutive rows x 64 bytes per 32-lane half (transposed operand fragments).
+__device__ __forceinline__ int swz7(int row) {
+    return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
+}
+
+// Direct global->LDS 16-byte-per-lane load (global_load_lds_dwordx4): the LDS destination is
+// (wave-uniform base) + lane*16; the global source address is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Fragment of a row-major [rows][64] swizzled tile for v_mfma_f32_32x32x16_bf16:
+// lane holds X[rb*32 + (lane&31)][kk*16 + 8*(lane>>5) + 0..7].
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int rb, int kk, int lane) {
+    const int row = rb * 32 + (lane & 31);
+    const int ps = ((kk << 1) | (lane >> 5)) ^ swz7(row);
+    return *(const bf16x8*)(tile + row * 128 + ps * 16);
+}
+
+// Transposed fragment of the same tile via ds_read_b64_tr_b16: lane (g = lane>>4, i = lane&15) receives
+// X[rowbase(rd) + j][cb*32 + 16*(g&1) + i] for j = 0..3 in elements 4*rd + j, where
+// rowbase(rd) = row0 + 8*rd_stride_sel ... (callers pass the two 4-row bases explicitly).
+// Hardware semantics used: within each 16-lane group, lane p supplies the address of 4 contiguous bf16;
+// output lane i, element j  =  element (i&3) of the 8 bytes supplied by lane 4*j + (i>>2).
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int cb, int rowbase0, int rowbase1, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int col = cb * 32 + ((g & 1) << 4) + ((p & 3) << 2);
+    const int r0 = rowbase0 + (p >> 2);
+    const int r1 = rowbase1 + (p >> 2);
+    const int ls = col >> 3;
+    const int inb = (p & 1) << 3;
+    const char* a0 = tile + r0 * 128 + ((ls ^ swz7(r0)) << 4) + inb;
+    const char* a1 = tile + r1 * 128 + ((ls ^ swz7(r1)) << 4) + inb;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)a1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// Stage a [64 rows][64 bf16] tile (8 KiB) with NW waves: 8 chunks of 1 KiB (= 8 rows each).
+// Rows past nrows are clamped to the last valid row (callers mask the results).
+template <int NW>
+__device__ __forceinline__ void stage_tile64(const bf16* base, long row_stride, int row0, int nrows, char* lds,
+                                             int wave, int lane) {
+#pragma unroll
+    for (int c = wave; c < 8; c += NW) {
+        const int row = c * 8 + (lane >> 3);
+        const int ls = (lane & 7) ^ swz7(row);
+        int grow = row0 + row;
+        grow = grow < nrows ? grow : nrows - 1;
+        glds16(base + (long)grow * row_stride + ls * 8, lds + c * 1024);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Block-wide sum for blocks of NT threads (NT multiple of 64, <= 1024). `red` is >= NT/64 floats of LDS.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+template <int NT>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+#define DW_CHECK_LAUNCH()                                  \
+    do {                                                   \
+        hipError_t e__ = hipGetLastError();                \
+        if (e__ != hipSuccess) return (int)e__;            \
+    } while (0)

@@ -1,0 +1,194 @@
+// LayerNorm forward / backward for gfx950 (HBM-bound; one 64-lane wave per row, 16-byte loads, fp32 statistics).
+// Replaces nn.LayerNorm(eps=1e-5) of the reference model (TF:modeling_whisper.py:371,377,434,443,446,573,682).
+// Under the reference's bf16 autocast LayerNorm runs in fp32 on the (fp32 student / bf16 teacher) residual stream and
+// its output is cast to bf16 by the next Linear; here the bf16 cast is fused into the store.
+#include "common.h"
+#include "../../include/dwamd.h"
+
+#define LN_MAXV 8  // up to 8 float4 per lane -> cols <= 2048
+
+template <bool XBF>
+__device__ __forceinline__ f32x4 ld4(const void* x, long off) {
+    if (XBF) {
+        const bf16x4 t = *(const bf16x4*)((const bf16*)x + off);
+        f32x4 r; r[0] = bf2f(t[0]); r[1] = bf2f(t[1]); r[2] = bf2f(t[2]); r[3] = bf2f(t[3]);
+        return r;
+    } else {
+        return *(const f32x4*)((const float*)x + off);
+    }
+}
+
+template <bool XBF, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float* gamma, const float* beta, bf16* y,
+                                                     float* mean, float* rstd, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = cols >> 2;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < nvec) {
+            v[j] = ld4<XBF>(x, (long)row * cols + idx * 4);
+            s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        }
+    }
+    s = wave_sum(s);
+    const float mu = s / cols;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < nvec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q += d * d; }
+        }
+    }
+    q = wave_sum(q);
+    const float rs = rsqrtf(q / cols + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < nvec) {
+            const f32x4 g = *(const f32x4*)(gamma + idx * 4);
+            const f32x4 bt = *(const f32x4*)(beta + idx * 4);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf((v[j][e] - mu) * rs * g[e] + bt[e]);
+            *(bf16x4*)(y + (long)row * cols + idx * 4) = o;
+        }
+    }
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <bool XBF, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void* x, const float* mean,
+                                                     const float* rstd, const float* gamma, float* dres,
+                                                     int accumulate, float* dgamma, float* dbeta, int rows, int cols) {
+    __shared__ float red[2 * 4 * 512];  // [dgamma|dbeta][wave][512-column window]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nvec = cols >> 2;
+    f32x4 gm[NV], ag[NV], ab[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = lane + 64 * j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 0.f; }
+        if (idx < nvec) gm[j] = *(const f32x4*)(gamma + idx * 4);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], g[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+                const f32x4 xv = ld4<XBF>(x, (long)row * cols + idx * 4);
+                const f32x4 dv = ld4<true>(dy, (long)row * cols + idx * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[j][e] = (xv[e] - mu) * rs;
+                    g[j][e] = dv[e] * gm[j][e];
+                    c1 += g[j][e];
+                    c2 += g[j][e] * xh[j][e];
+                    ag[j][e] += dv[e] * xh[j][e];
+                    ab[j][e] += dv[e];
+                }
+            }
+        }
+        c1 = wave_sum(c1) / cols;
+        c2 = wave_sum(c2) / cols;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+                float* dst = dres + (long)row * cols + idx * 4;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
+                if (accumulate) {
+                    const f32x4 old = *(const f32x4*)dst;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += old[e];
+                }
+                *(f32x4*)dst = o;
+            }
+        }
+    }
+    // block reduction of the per-wave dgamma / dbeta partials, then one atomic per column per block
+    float* r0 = red;
+    float* r1 = red + 2048;
+    // windows of 512 columns: red[k][wave][col - base]
+    for (int base = 0; base < cols; base += 512) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            const int col = idx * 4;
+            if (idx < nvec && col >= base && col < base + 512) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r0[wave * 512 + (col - base) + e] = ag[j][e];
+                    r1[wave * 512 + (col - base) + e] = ab[j][e];
+                }
+            }
+        }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < 512 && base + cidx < cols; cidx += 256) {
+            const float sg = r0[cidx] + r0[512 + cidx] + r0[1024 + cidx] + r0[1536 + cidx];
+            const float sb = r1[cidx] + r1[512 + cidx] + r1[1024 + cidx] + r1[1536 + cidx];
+            atomicAdd(dgamma + base + cidx, sg);
+            atomicAdd(dbeta + base + cidx, sb);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                                float* mean, float* rstd, int rows, int cols, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
+    if ((mean == nullptr) != (rstd == nullptr)) return DW_EINVAL;
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = ((cols >> 2) + 63) / 64;
+#define LN_FWD(NVV)                                                                                                   \
+    do {                                                                                                              \
+        if (x_dtype == DW_BF16)                                                                                       \
+            hipLaunchKernelGGL((ln_fwd_kernel<true, NVV>), grid, block, 0, s, x, gamma, beta, (bf16*)y, mean, rstd,   \
+                               rows, cols, eps);                                                                      \
+        else                                                                                                          \
+            hipLaunchKernelGGL((ln_fwd_kernel<false, NVV>), grid, block, 0, s, x, gamma, beta, (bf16*)y, mean, rstd,  \
+                               rows, cols, eps);                                                                      \
+    } while (0)
+    if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 5) LN_FWD(5); else LN_FWD(8);
+#undef LN_FWD
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
+extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
+                                const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, int rows,
+                                int cols, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dres || !dgamma || !dbeta) return DW_EINVAL;
+    if (rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
+    int nb = (rows + 3) / 4;
+    if (nb > 1024) nb = 1024;
+    hipStream_t s = (hipStream_t)stream;
+    const int nv = ((cols >> 2) + 63) / 64;
+#define LN_BWD(NVV)                                                                                                   \
+    do {                                                                                                              \
+        if (x_dtype == DW_BF16)                                                                                       \
+            hipLaunchKernelGGL((ln_bwd_kernel<true, NVV>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, x, mean, rstd, \
+                               gamma, dres, accumulate, dgamma, dbeta, rows, cols);                                   \
+        else                                                                                                          \
+            hipLaunchKernelGGL((ln_bwd_kernel<false, NVV>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, x, mean,      \
+                               rstd, gamma, dres, accumulate, dgamma, dbeta, rows, cols);                             \
+    } while (0)
+    if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 5) LN_BWD(5); else LN_BWD(8);
+#undef LN_BWD
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}

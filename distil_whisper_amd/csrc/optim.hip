@@ -1,0 +1,97 @@
+// Global-norm gradient clipping + AdamW over flat fp32 parameter / gradient / moment buffers (HBM-bound: 16 B read +
+// 14 B written per parameter), refreshing the bf16 shadow weights the MFMA GEMMs consume in the same pass.
+// Replaces accelerator.clip_grad_norm_ + torch.optim.AdamW.step (run_distillation.py:1377-1407, 1611-1614).
+#include "common.h"
+#include "../../include/dwamd.h"
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const f32x4 v = *(const f32x4*)(g + i);
+            acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        } else {
+            for (long j = i; j < n; ++j) acc += g[j] * g[j];
+        }
+    }
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, long n,
+                                                    const float* sumsq, float max_norm, float grad_mul, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt) {
+    float clip = grad_mul;
+    if (max_norm > 0.f && sumsq) {
+        const float norm = sqrtf(sumsq[0]) * fabsf(grad_mul);
+        const float coef = max_norm / (norm + 1e-6f);
+        clip *= coef < 1.f ? coef : 1.f;
+    }
+    const float step_size = lr / bc1;
+    const float decay = 1.f - lr * wd;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 pv = *(f32x4*)(p + i);
+            const f32x4 gv = *(const f32x4*)(g + i);
+            f32x4 mv = *(f32x4*)(m + i);
+            f32x4 vv = *(f32x4*)(v + i);
+            bf16x4 sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = gv[e] * clip;
+                pv[e] *= decay;
+                mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
+                vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+                const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+                pv[e] -= step_size * (mv[e] / denom);
+                sh[e] = f2bf(pv[e]);
+            }
+            *(f32x4*)(p + i) = pv;
+            *(f32x4*)(m + i) = mv;
+            *(f32x4*)(v + i) = vv;
+            if (shadow) *(bf16x4*)(shadow + i) = sh;
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gg = g[j] * clip;
+                float pj = p[j] * decay;
+                const float mj = beta1 * m[j] + (1.f - beta1) * gg;
+                const float vj = beta2 * v[j] + (1.f - beta2) * gg * gg;
+                pj -= step_size * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+                p[j] = pj; m[j] = mj; v[j] = vj;
+                if (shadow) shadow[j] = f2bf(pj);
+            }
+        }
+    }
+}
+
+extern "C" int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
+    if (!g || !out || n <= 0 || ((uintptr_t)g & 15)) return DW_EINVAL;
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
+extern "C" int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, const float* sumsq,
+                        float max_norm, float grad_mul, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return DW_EINVAL;
+    if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) ||
+        ((uintptr_t)shadow & 7))
+        return DW_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow, (long)n,
+                       sumsq, max_norm, grad_mul, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}

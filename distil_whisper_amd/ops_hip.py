@@ -1,0 +1,334 @@
+"""ctypes binding of libdwamd.so (C ABI in include/dwamd.h) over torch device tensors.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every compute call goes to a hand-written gfx950
+kernel.  There is NO fallback: constructing `HipOps` without the shared library or without a GPU raises.
+The method set is the "ops" interface the host engine (engine.py) is written against; tests inject a torch
+restatement with the same interface (oracle/ref_ops.py) to check the host logic on CPU.
+"""
+import ctypes as C
+import math
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdwamd.so")
+
+DW_F32, DW_BF16 = 0, 1
+
+
+class DwGemm(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("bias", C.c_void_p), ("z_out", C.c_void_p),
+        ("zgrad_in", C.c_void_p), ("r", C.c_void_p),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldz", C.c_int64), ("ldzg", C.c_int64),
+        ("ldr", C.c_int64),
+        ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+        ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("act", C.c_int32), ("c_dtype", C.c_int32),
+        ("r_dtype", C.c_int32), ("r_row_mod", C.c_int32), ("round_res", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+_SIGS = {
+    "dw_version": ([], C.c_int),
+    "dw_logmel": ([C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p], C.c_int),
+    "dw_gemm_bf16": ([C.POINTER(DwGemm), C.c_void_p], C.c_int),
+    "dw_layernorm_fwd": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                          C.c_int, C.c_float, C.c_void_p], C.c_int),
+    "dw_layernorm_bwd": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_attn_fwd": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
+    "dw_attn_bwd": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
+    "dw_distill_loss": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float,
+                         C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                         C.c_void_p], C.c_int),
+    "dw_embed_fwd": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                      C.c_void_p], C.c_int),
+    "dw_embed_bwd": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_im2col_mel": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_im2col_s2": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_col2im_s2_gelu_bwd": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_pack_conv_weight": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_unpack_conv_grad": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_cast_f32_bf16": ([C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p], C.c_int),
+    "dw_cast_bf16_f32": ([C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p], C.c_int),
+    "dw_colsum_bf16": ([C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
+    "dw_add": ([C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p], C.c_int),
+    "dw_sumsq_f32": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p], C.c_int),
+    "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 8 + [C.c_int, C.c_void_p], C.c_int),
+    "dw_selftest_tr16": ([C.c_void_p, C.c_void_p], C.c_int),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libdwamd.so and attach the prototypes.  Raises if the library is missing (no fallback path)."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -m distil_whisper_amd.build` (hipcc --offload-arch=gfx950). "
+            "The MI355X path has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    return lib
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return DW_F32
+    if t.dtype == torch.bfloat16:
+        return DW_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class HipOps:
+    """MI355X kernels behind the ops interface.  All tensors must live on the same cuda (HIP) device."""
+
+    name = "hip"
+
+    def __init__(self, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipOps needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path.")
+        self.lib = load_library()
+        self.device = torch.device(device)
+        i = torch.arange(400, dtype=torch.float64)
+        ang = 2.0 * math.pi * i / 400.0
+        self._twiddle = torch.stack([torch.cos(ang), torch.sin(ang)], 1).to(torch.float32).contiguous().to(self.device)
+        self._window = torch.hann_window(400, periodic=True, dtype=torch.float64).to(torch.float32).to(self.device)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _chk(rc, what):
+        if rc != 0:
+            raise RuntimeError(f"libdwamd: {what} failed with code {rc}")
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def selftest_tr16(self):
+        out = self.empty((64, 4), torch.int32)
+        self._chk(self.lib.dw_selftest_tr16(_p(out), self._stream()), "selftest_tr16")
+        return out
+
+    def logmel(self, audio, filters):
+        assert audio.dtype == torch.float32 and audio.dim() == 2 and audio.is_contiguous()
+        assert filters.dtype == torch.float32 and filters.shape[0] == 201 and filters.is_contiguous()
+        B, N = audio.shape
+        M = filters.shape[1]
+        out = self.empty((B, M, N // 160), torch.float32)
+        clip = self.empty((B,), torch.float32)
+        self._chk(self.lib.dw_logmel(_p(audio), B, N, _p(filters), M, _p(self._twiddle), _p(self._window), _p(out),
+                                     _p(clip), self._stream()), "logmel")
+        return out
+
+    def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
+             r_row_mod=0, round_res=True, out_dtype=torch.bfloat16, out=None, tile=0):
+        """C = op(a) @ op(b) with the fused epilogue of dw_gemm_bf16.  a: [M,K] (or [K,M] if trans_a);
+        b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1."""
+        assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+        assert a.stride(1) == 1 and b.stride(1) == 1
+        if trans_a:
+            K, M = a.shape
+        else:
+            M, K = a.shape
+        if trans_b:
+            Kb, N = b.shape
+        else:
+            N, Kb = b.shape
+        assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+        if out is None:
+            out = self.empty((M, N), out_dtype)
+        assert out.shape == (M, N) and out.stride(1) == 1
+        g = DwGemm()
+        g.a, g.b, g.c = a.data_ptr(), b.data_ptr(), out.data_ptr()
+        g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
+        g.m, g.n, g.k = M, N, K
+        g.trans_a, g.trans_b = int(trans_a), int(trans_b)
+        g.act = int(act)
+        g.c_dtype = _dt(out)
+        g.tile = int(tile)
+        z = None
+        if bias is not None:
+            assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+            g.bias = bias.data_ptr()
+        if want_z:
+            z = self.empty((M, N), torch.bfloat16)
+            g.z_out, g.ldz = z.data_ptr(), z.stride(0)
+        if zgrad is not None:
+            assert zgrad.dtype == torch.bfloat16 and zgrad.shape == (M, N) and zgrad.stride(1) == 1
+            g.zgrad_in, g.ldzg = zgrad.data_ptr(), zgrad.stride(0)
+        if residual is not None:
+            assert residual.stride(1) == 1 and residual.shape[1] == N
+            g.r, g.ldr, g.r_dtype = residual.data_ptr(), residual.stride(0), _dt(residual)
+            g.r_row_mod = int(r_row_mod)
+            g.round_res = int(bool(round_res))
+        self._chk(self.lib.dw_gemm_bf16(C.byref(g), self._stream()), f"gemm m={M} n={N} k={K} ta={trans_a} tb={trans_b}")
+        return (out, z) if want_z else out
+
+    def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True):
+        rows, cols = x.shape
+        assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+        y = self.empty((rows, cols), torch.bfloat16)
+        mean = self.empty((rows,), torch.float32) if save_stats else None
+        rstd = self.empty((rows,), torch.float32) if save_stats else None
+        self._chk(self.lib.dw_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols,
+                                            float(eps), self._stream()), "layernorm_fwd")
+        return y, mean, rstd
+
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
+        """dres (f32 [rows,cols]) += LN'(dy) if dres is given, else a new tensor is returned.  dgamma/dbeta += ..."""
+        rows, cols = x.shape
+        assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
+        acc = dres is not None
+        if dres is None:
+            dres = self.empty((rows, cols), torch.float32)
+        assert dres.dtype == torch.float32 and dres.is_contiguous()
+        self._chk(self.lib.dw_layernorm_bwd(_p(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(dres), int(acc),
+                                            _p(dgamma), _p(dbeta), rows, cols, self._stream()), "layernorm_bwd")
+        return dres
+
+    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale):
+        for t in (q, k, v):
+            assert t.dtype == torch.bfloat16 and t.stride(1) == 1
+        o = self.empty((B * Lq, H * 64), torch.bfloat16)
+        lse = self.empty((B, H, Lq), torch.float32)
+        self._chk(self.lib.dw_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Lq, Lk, q.stride(0), k.stride(0),
+                                       v.stride(0), o.stride(0), int(causal), float(scale), self._stream()), "attn_fwd")
+        return o, lse
+
+    def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None):
+        if dq is None:
+            dq = self.empty((B * Lq, H * 64), torch.bfloat16)
+        if dk is None:
+            dk = self.empty((B * Lk, H * 64), torch.bfloat16)
+        if dv is None:
+            dv = self.empty((B * Lk, H * 64), torch.bfloat16)
+        delta = self.empty((B, H, Lq), torch.float32)
+        for t in (q, k, v, o, do, dq, dk, dv):
+            assert t.dtype == torch.bfloat16 and t.stride(1) == 1
+        self._chk(self.lib.dw_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv),
+                                       B, H, Lq, Lk, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
+                                       dq.stride(0), dk.stride(0), dv.stride(0), int(causal), float(scale),
+                                       self._stream()), "attn_bwd")
+        return dq, dk, dv
+
+    def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad):
+        """Returns losses f32[4] = (ce, kl, total, n_valid).  With want_grad the gradient w.r.t. the student logits
+        overwrites s_logits in place (bf16)."""
+        rows, ld = s_logits.shape
+        assert s_logits.dtype == torch.bfloat16 and t_logits.dtype == torch.bfloat16
+        assert s_logits.is_contiguous() and t_logits.is_contiguous() and t_logits.shape == s_logits.shape
+        assert labels.dtype == torch.int64 and labels.numel() == rows and labels.is_contiguous()
+        losses = self.empty((4,), torch.float32)
+        row_ce = self.empty((rows,), torch.float32)
+        row_kl = self.empty((rows,), torch.float32)
+        counts = self.empty((2,), torch.int32)
+        self._chk(self.lib.dw_distill_loss(_p(s_logits), _p(t_logits), _p(labels), rows, V, ld, float(temperature),
+                                           float(ce_weight), float(kl_weight), float(grad_scale), _p(losses),
+                                           _p(s_logits) if want_grad else None, _p(row_ce), _p(row_kl), _p(counts),
+                                           self._stream()), "distill_loss")
+        return losses
+
+    def embed_fwd(self, ids, tok, pos, out_dtype):
+        B, T = ids.shape
+        D = tok.shape[1]
+        assert ids.dtype == torch.int64 and ids.is_contiguous() and tok.is_contiguous() and pos.is_contiguous()
+        assert tok.dtype == pos.dtype
+        out = self.empty((B * T, D), out_dtype)
+        self._chk(self.lib.dw_embed_fwd(_p(ids), _p(tok), _p(pos), _dt(tok), _p(out), _dt(out), B, T, D,
+                                        self._stream()), "embed_fwd")
+        return out
+
+    def embed_bwd(self, dx, ids, dtok, dpos):
+        B, T = ids.shape
+        D = dx.shape[1]
+        assert dx.dtype == torch.float32 and dx.is_contiguous() and dtok.dtype == torch.float32
+        self._chk(self.lib.dw_embed_bwd(_p(dx), _p(ids), _p(dtok), _p(dpos), B, T, D, self._stream()), "embed_bwd")
+
+    def im2col_mel(self, mel, kpad):
+        B, Cc, T = mel.shape
+        assert mel.dtype == torch.float32 and mel.is_contiguous()
+        out = self.empty((B * T, kpad), torch.bfloat16)
+        self._chk(self.lib.dw_im2col_mel(_p(mel), _p(out), B, Cc, T, kpad, self._stream()), "im2col_mel")
+        return out
+
+    def im2col_s2(self, a, B, T):
+        Cc = a.shape[1]
+        assert a.dtype == torch.bfloat16 and a.is_contiguous() and a.shape[0] == B * T
+        out = self.empty((B * T // 2, 3 * Cc), torch.bfloat16)
+        self._chk(self.lib.dw_im2col_s2(_p(a), _p(out), B, T, Cc, self._stream()), "im2col_s2")
+        return out
+
+    def col2im_s2_gelu_bwd(self, dxcol, z, B, T):
+        Cc = z.shape[1]
+        assert dxcol.is_contiguous() and z.is_contiguous() and dxcol.dtype == torch.bfloat16
+        dz = self.empty((B * T, Cc), torch.bfloat16)
+        self._chk(self.lib.dw_col2im_s2_gelu_bwd(_p(dxcol), _p(z), _p(dz), B, T, Cc, self._stream()), "col2im")
+        return dz
+
+    def pack_conv_weight(self, w, kpad, out=None):
+        D, Cc, _ = w.shape
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        if out is None:
+            out = self.empty((D, kpad), torch.bfloat16)
+        self._chk(self.lib.dw_pack_conv_weight(_p(w), _p(out), D, Cc, kpad, self._stream()), "pack_conv_weight")
+        return out
+
+    def unpack_conv_grad(self, gwp, gw, accumulate):
+        D, Cc, _ = gw.shape
+        assert gwp.dtype == torch.float32 and gwp.is_contiguous() and gw.is_contiguous()
+        self._chk(self.lib.dw_unpack_conv_grad(_p(gwp), _p(gw), D, Cc, gwp.shape[1], int(accumulate), self._stream()),
+                  "unpack_conv_grad")
+
+    def cast_bf16(self, x, out=None):
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        if out is None:
+            out = self.empty(x.shape, torch.bfloat16)
+        self._chk(self.lib.dw_cast_f32_bf16(_p(x), _p(out), x.numel(), self._stream()), "cast_f32_bf16")
+        return out
+
+    def cast_f32(self, x, out=None):
+        assert x.dtype == torch.bfloat16 and x.is_contiguous()
+        if out is None:
+            out = self.empty(x.shape, torch.float32)
+        self._chk(self.lib.dw_cast_bf16_f32(_p(x), _p(out), x.numel(), self._stream()), "cast_bf16_f32")
+        return out
+
+    def colsum(self, x, out, accumulate):
+        rows, cols = x.shape
+        assert x.dtype == torch.bfloat16 and x.stride(1) == 1 and out.dtype == torch.float32
+        self._chk(self.lib.dw_colsum_bf16(_p(x), x.stride(0), rows, cols, _p(out), int(accumulate), self._stream()),
+                  "colsum")
+        return out
+
+    def add(self, a, b, out_dtype):
+        assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+        y = self.empty(a.shape, out_dtype)
+        self._chk(self.lib.dw_add(_p(a), _dt(a), _p(b), _dt(b), _p(y), _dt(y), a.numel(), self._stream()), "add")
+        return y
+
+    def sumsq(self, g, out):
+        assert g.dtype == torch.float32 and g.is_contiguous()
+        self._chk(self.lib.dw_sumsq_f32(_p(g), g.numel(), _p(out), self._stream()), "sumsq")
+        return out
+
+    def adamw(self, p, g, m, v, shadow, sumsq, max_norm, grad_mul, lr, beta1, beta2, eps, weight_decay, step):
+        assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+        self._chk(self.lib.dw_adamw(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(sumsq), float(max_norm),
+                                    float(grad_mul), float(lr), float(beta1), float(beta2), float(eps),
+                                    float(weight_decay), int(step), self._stream()), "adamw")

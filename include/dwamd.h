@@ -1,0 +1,154 @@
+/*
+ * dwamd.h -- C ABI of libdwamd.so: the MI355X (gfx950 / CDNA4) kernels of the Whisper distillation hot path.
+ *
+ * The reference (huggingface/distil-whisper) has no FFI layer of its own: its hot path calls the Python surface
+ * of `transformers` (WhisperFeatureExtractor + WhisperForConditionalGeneration) which dispatches to ATen/rocBLAS/
+ * MIOpen kernels.  Each entry point below names the reference site it replaces (paths relative to the reference
+ * tree `training/`, `TF:` = transformers/models/whisper of the pinned transformers==5.15.0).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a hipError_t value (>0) if a launch failed, or a negative DW_E* code
+ *     for an invalid argument; nothing throws across this boundary;
+ *   - the caller owns every buffer (device pointers from its own allocator); kernels never allocate;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, no host sync inside;
+ *   - bf16 = 16-bit brain float (the upper half of an IEEE binary32), row-major everywhere, "ld" = leading
+ *     dimension in ELEMENTS;
+ *   - re-entrant: may be called from the Python main thread (forward) and the autograd engine thread (backward).
+ */
+#ifndef DWAMD_H
+#define DWAMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DW_OK 0
+#define DW_EINVAL (-1)  /* bad argument (alignment, K %% 64, null pointer ...) */
+#define DW_EUNSUP (-2)  /* unsupported shape (e.g. head_dim != 64)            */
+
+#define DW_F32 0
+#define DW_BF16 1
+
+int dw_version(void);
+
+/* ---- a1: log-mel front end --------------------------------------------------------------------------------------
+ * Replaces WhisperFeatureExtractor._torch_extract_fbank_features (TF:feature_extraction_whisper.py:135-168), called
+ * from run_distillation.py:1176,1234 and run_eval.py:628-642.
+ * audio [batch][n_samples] f32 (n_samples = 480000), hann window 400 (periodic), hop 160, reflect-pad centre STFT,
+ * power spectrum, mel_filters [201][n_mels] f32 (HF layout), log10(clamp 1e-10), max(x, clipmax-8), (x+4)/4.
+ * out [batch][n_mels][n_frames] f32 with n_frames = n_samples/160.  twiddle [400][2] f32 = (cos, sin)(2*pi*i/400),
+ * window [400] f32; clipmax [batch] f32 scratch (overwritten). */
+int dw_logmel(const float* audio, int batch, int n_samples, const float* mel_filters, int n_mels,
+              const float* twiddle, const float* window, float* out, float* clipmax, void* stream);
+
+/* ---- a3/a4/a5/a6: dense projections on the bf16 MFMA ------------------------------------------------------------
+ * Replaces nn.Linear / nn.Conv1d (after im2col) forward+backward GEMMs (TF:modeling_whisper.py:279-282, 375-376,
+ * 444-445, 566-567, 970).   C[M,N] = epilogue( op(A)[M,K] . op(B)[K,N] ), fp32 accumulation.
+ *   trans_a = 0: A stored [M][lda] (K contiguous)      trans_a = 1: A stored [K][lda] (M contiguous)
+ *   trans_b = 0: B stored [N][ldb] (K contiguous, i.e. the nn.Linear weight layout)
+ *   trans_b = 1: B stored [K][ldb] (N contiguous)
+ * Requirements: K %% 64 == 0 (pad with zeros), lda/ldb multiples of 8, base pointers 16-byte aligned.
+ * Epilogue, in this order (each step optional):
+ *   v = acc + bias[n]                      (bias f32 [N])
+ *   Z[m][n] = bf16(v)                      (z_out, ldz; the pre-activation kept for backward)
+ *   v = gelu(round_bf16(v))                (act == 1; exact erf GELU on the bf16-rounded value, as autocast does)
+ *   v = v * gelu'(Zin[m][n])               (zgrad_in bf16, ldzg: fused GELU backward)
+ *   v = (round_res ? round_bf16(v) : v) + R[m %% r_row_mod or m][n]     (residual R, f32 or bf16, ldr)
+ *   C[m][n] = v as f32 or bf16             (c_dtype, ldc)
+ * R may alias C (in-place accumulation: every element is read and written by the same lane). */
+typedef struct DwGemm {
+    const void* a;      /* bf16 */
+    const void* b;      /* bf16 */
+    void* c;            /* f32 or bf16 */
+    const float* bias;  /* f32 [N] or NULL */
+    void* z_out;        /* bf16 or NULL */
+    const void* zgrad_in; /* bf16 or NULL */
+    const void* r;      /* residual or NULL */
+    int64_t lda, ldb, ldc, ldz, ldzg, ldr;
+    int32_t m, n, k;
+    int32_t trans_a, trans_b;
+    int32_t act;        /* 0 none, 1 gelu */
+    int32_t c_dtype;    /* DW_F32 / DW_BF16 */
+    int32_t r_dtype;    /* DW_F32 / DW_BF16 */
+    int32_t r_row_mod;  /* 0: R row = m; >0: R row = m %% r_row_mod (positional table broadcast) */
+    int32_t round_res;  /* 1: round v to bf16 before adding R (autocast semantics) */
+    int32_t tile;       /* 0 auto, 128 or 256: force the block tile */
+} DwGemm;
+int dw_gemm_bf16(const DwGemm* g, void* stream);
+
+/* ---- LayerNorm (TF:modeling_whisper.py:371,377,434,443,446,573,682), eps 1e-5, statistics in f32 ---------------
+ * x [rows][cols] f32 or bf16 (x_dtype), y bf16 [rows][cols]; mean/rstd f32 [rows] (may be NULL for inference). */
+int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, float* mean,
+                     float* rstd, int rows, int cols, float eps, void* stream);
+/* dx = LN'(dy); if accumulate: dres[rows][cols] (f32) += dx else dres = dx.  dgamma/dbeta f32 [cols] are ADDED to
+ * (atomics; zero them first). */
+int dw_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const float* mean, const float* rstd,
+                     const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, int rows, int cols,
+                     void* stream);
+
+/* ---- attention core (TF:modeling_whisper.py:215-238 / integrations/sdpa_attention.py), head_dim 64 --------------
+ * q [B*Lq rows], k,v [B*Lk rows]: bf16, head h of a row at element offset h*64, row strides ldq/ldk/ldv/ldo
+ * (elements).  o bf16 same addressing with ldo; lse f32 [B][H][Lq] (natural-log logsumexp of scale*q.k).
+ * softmax(scale * q k^T [+ causal mask]) v; the reference pre-scales q by 0.125 and passes scaling=1.0, which is
+ * bit-identical to scale=0.125 here (power of two). */
+int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
+                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int causal, float scale, void* stream);
+/* delta f32 [B][H][Lq] scratch.  dq/dk/dv bf16 with row strides lddq/lddk/lddv. */
+int dw_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int64_t ldq, int64_t ldk,
+                int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int causal,
+                float scale, void* stream);
+
+/* ---- a7: fused CE + temperature-KL distillation loss (run_distillation.py:1453-1462, 1486-1493 and
+ * TF:modeling_whisper.py:1083-1087).  s/t logits bf16 [rows][ld] (V valid columns), labels int64 [rows] (-100 =
+ * ignore).  losses f32[4] = {ce, kl*T^2, 0.8-weighted total, n_valid}.  If dlogits != NULL the gradient of
+ * grad_scale * total w.r.t. the student logits is written there (bf16 [rows][ld], may alias s_logits; columns
+ * V..ld-1 are zeroed).  row_ce/row_kl f32 [rows] scratch; counts int32[2] scratch. */
+int dw_distill_loss(const void* s_logits, const void* t_logits, const int64_t* labels, int rows, int V, int64_t ld,
+                    float temperature, float ce_weight, float kl_weight, float grad_scale, float* losses,
+                    void* dlogits, float* row_ce, float* row_kl, int32_t* counts, void* stream);
+
+/* ---- embeddings (TF:modeling_whisper.py:675-676, 736-762) ------------------------------------------------------
+ * out[b*T+t][:] = tok[ids[b*T+t]][:] + pos[t][:]; tables f32 or bf16 (tab_dtype); out f32 or bf16. */
+int dw_embed_fwd(const int64_t* ids, const void* tok, const void* pos, int tab_dtype, void* out, int out_dtype,
+                 int B, int T, int D, void* stream);
+/* dtok[ids[r]] += dx[r] (atomic f32), dpos[t] += sum_b dx[b*T+t] (skipped if dpos NULL). */
+int dw_embed_bwd(const float* dx, const int64_t* ids, float* dtok, float* dpos, int B, int T, int D, void* stream);
+
+/* ---- conv front end helpers (TF:modeling_whisper.py:566-567, 618-625) ------------------------------------------
+ * conv1 (k3,p1,s1) and conv2 (k3,p1,s2) run as im2col + dw_gemm_bf16 with W' [D][3*C] (W'[d][k*C+c] = W[d][c][k]).
+ * im2col_mel: mel f32 [B][C][T] -> xcol bf16 [B*T][kpad], xcol[(b,t)][k*C+c] = mel[b][c][t+k-1], zero padded. */
+int dw_im2col_mel(const float* mel, void* xcol, int B, int C, int T, int kpad, void* stream);
+/* im2col_s2: a bf16 [B*T][C] -> xcol bf16 [B*T/2][3*C], xcol[(b,t)][k*C+c] = a[b][2t+k-1][c]. */
+int dw_im2col_s2(const void* a, void* xcol, int B, int T, int C, void* stream);
+/* col2im_s2 + GELU backward: dz[b][r][c] = gelu'(z[b][r][c]) * sum_{2t+k-1=r} dxcol[(b,t)][k*C+c]. */
+int dw_col2im_s2_gelu_bwd(const void* dxcol, const void* z, void* dz, int B, int T, int C, void* stream);
+/* conv weight <-> GEMM weight layouts: w [D][C][3] f32 <-> wp [D][kpad] (bf16 pack / f32 grad unpack-accumulate). */
+int dw_pack_conv_weight(const float* w, void* wp_bf16, int D, int C, int kpad, void* stream);
+int dw_unpack_conv_grad(const float* gwp, float* gw, int D, int C, int kpad, int accumulate, void* stream);
+
+/* ---- small streaming kernels -----------------------------------------------------------------------------------*/
+int dw_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+int dw_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream);
+/* out[n] (+)= sum_r x[r][n], x bf16 [rows][ld] (bias gradients). */
+int dw_colsum_bf16(const void* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* stream);
+/* y = a (bf16/f32) + b (bf16/f32) elementwise into f32 or bf16 */
+int dw_add(const void* a, int a_dtype, const void* b, int b_dtype, void* y, int y_dtype, int64_t n, void* stream);
+
+/* ---- a9: global-norm clip + AdamW (run_distillation.py:1377-1407, 1611-1614; torch.optim.AdamW semantics) -------
+ * sumsq: out[0] += sum(g^2) (zero it first).  adamw: clip = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) (max_norm <= 0
+ * disables), g' = g*clip*grad_mul; p *= 1-lr*wd; m,v update; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps); the bf16
+ * shadow copy used by the GEMMs is refreshed in the same pass (shadow may be NULL). */
+int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
+int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq,
+             float max_norm, float grad_mul, float lr, float beta1, float beta2, float eps, float weight_decay,
+             int step, void* stream);
+
+/* ---- self tests (diagnostics for bring-up; not on the hot path) --------------------------------------------------
+ * Runs ds_read_b64_tr_b16 on a known LDS image: out int32 [64][4] = element ids received by each lane. */
+int dw_selftest_tr16(int32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

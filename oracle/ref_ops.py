@@ -1,0 +1,267 @@
+"""TEST INFRASTRUCTURE -- not part of the product path.
+
+Plain-torch restatement of every entry point of libdwamd.so (include/dwamd.h), with the same Python interface as
+distil_whisper_amd.ops_hip.HipOps.  Two uses, both in tests only:
+  * `-m gpu` tests run each HIP kernel and this restatement on the same device tensors and compare;
+  * `-m "not gpu"` tests inject it into the host engine to check the hand-written forward/backward orchestration on
+    CPU against the `transformers` reference (tests/test_engine_cpu.py).
+The product (engine/trainer/bench) never imports this module; HipOps raises if the HIP library is missing.
+
+Each function cites the reference arithmetic it restates (TF: = transformers 5.15 models/whisper).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+class RefOps:
+    name = "ref"
+
+    def __init__(self, device="cpu"):
+        self.device = torch.device(device)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    # TF:feature_extraction_whisper.py:135-168 (_torch_extract_fbank_features), restated without torch.stft:
+    # explicit reflect padding, framing, periodic Hann, 400-point real DFT by matmul in float64 then cast.
+    def logmel(self, audio, filters):
+        B, N = audio.shape
+        x = audio.to(torch.float64)
+        xp = F.pad(x.unsqueeze(1), (200, 200), mode="reflect").squeeze(1)
+        frames = xp.unfold(1, 400, 160)[:, : N // 160]  # drop the last frame, as log_spec[..., :-1]
+        win = torch.hann_window(400, periodic=True, dtype=torch.float64, device=audio.device)
+        n = torch.arange(400, dtype=torch.float64, device=audio.device)
+        k = torch.arange(201, dtype=torch.float64, device=audio.device)
+        ang = 2.0 * math.pi * torch.outer(n, k) / 400.0
+        fw = frames * win
+        re = fw @ torch.cos(ang)
+        im = fw @ torch.sin(ang)
+        power = re * re + im * im                       # [B, T, 201]
+        mel = power @ filters.to(torch.float64)         # [B, T, M]
+        log_spec = torch.clamp(mel, min=1e-10).log10().transpose(1, 2)
+        mx = log_spec.amax(dim=(1, 2), keepdim=True)
+        log_spec = torch.maximum(log_spec, mx - 8.0)
+        return ((log_spec + 4.0) / 4.0).to(torch.float32).contiguous()
+
+    # nn.Linear under bf16 autocast: bf16 operands, fp32 accumulation (TF:modeling_whisper.py:279-282 etc.)
+    def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
+             r_row_mod=0, round_res=True, out_dtype=torch.bfloat16, out=None, tile=0):
+        A = a.float().t() if trans_a else a.float()
+        Bm = b.float() if trans_b else b.float().t()
+        v = A @ Bm
+        if bias is not None:
+            v = v + bias
+        z = _bf(v) if want_z else None
+        if act == 1:
+            v = F.gelu(_bf(v).float())
+        if zgrad is not None:
+            zz = zgrad.float()
+            cdf = 0.5 * (1.0 + torch.erf(zz * 0.7071067811865476))
+            pdf = 0.3989422804014327 * torch.exp(-0.5 * zz * zz)
+            v = v * (cdf + zz * pdf)
+        if residual is not None:
+            r = residual.float()
+            if r_row_mod > 0:
+                idx = torch.arange(v.shape[0], device=v.device) % r_row_mod
+                r = r[idx]
+            v = (_bf(v).float() if round_res else v) + r
+        v = v.to(out_dtype)
+        if out is not None:
+            out.copy_(v)
+            v = out
+        return (v, z) if want_z else v
+
+    # nn.LayerNorm in fp32 (autocast keeps layer_norm in fp32), output cast to bf16 by the consumer
+    def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True):
+        xf = x.float()
+        mu = xf.mean(-1)
+        var = ((xf - mu[:, None]) ** 2).mean(-1)
+        rstd = torch.rsqrt(var + eps)
+        y = (xf - mu[:, None]) * rstd[:, None] * gamma + beta
+        return _bf(y), (mu if save_stats else None), (rstd if save_stats else None)
+
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
+        xf, d = x.float(), dy.float()
+        xh = (xf - mean[:, None]) * rstd[:, None]
+        g = d * gamma
+        c1 = g.mean(-1, keepdim=True)
+        c2 = (g * xh).mean(-1, keepdim=True)
+        dx = rstd[:, None] * (g - c1 - xh * c2)
+        dgamma += (d * xh).sum(0)
+        dbeta += d.sum(0)
+        if dres is None:
+            return dx
+        dres += dx
+        return dres
+
+    # softmax(scale q k^T + mask) v  (TF:modeling_whisper.py:215-238), bf16 in/out, fp32 softmax
+    @staticmethod
+    def _heads(t, B, L, H):
+        return t.reshape(B, L, H, 64).permute(0, 2, 1, 3).float()
+
+    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale):
+        qh, kh, vh = self._heads(q, B, Lq, H), self._heads(k, B, Lk, H), self._heads(v, B, Lk, H)
+        s = (qh @ kh.transpose(-1, -2)) * scale
+        if causal:
+            mask = torch.ones(Lq, Lk, dtype=torch.bool, device=s.device).tril()
+            s = s.masked_fill(~mask, float("-inf"))
+        lse = torch.logsumexp(s, -1)
+        p = torch.exp(s - lse[..., None])
+        o = _bf(p).float() @ vh
+        o = _bf(o.permute(0, 2, 1, 3).reshape(B * Lq, H * 64))
+        return o, lse
+
+    def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None):
+        qh, kh, vh = self._heads(q, B, Lq, H), self._heads(k, B, Lk, H), self._heads(v, B, Lk, H)
+        oh, doh = self._heads(o, B, Lq, H), self._heads(do, B, Lq, H)
+        s = (qh @ kh.transpose(-1, -2)) * scale
+        if causal:
+            mask = torch.ones(Lq, Lk, dtype=torch.bool, device=s.device).tril()
+            s = s.masked_fill(~mask, float("-inf"))
+        p = torch.exp(s - lse[..., None])
+        delta = (oh * doh).sum(-1, keepdim=True)
+        dvh = _bf(p).float().transpose(-1, -2) @ doh
+        dp = doh @ vh.transpose(-1, -2)
+        ds = _bf(p * (dp - delta)).float()
+        dqh = (ds @ kh) * scale
+        dkh = (ds.transpose(-1, -2) @ qh) * scale
+
+        def back(t, L):
+            return _bf(t.permute(0, 2, 1, 3).reshape(B * L, H * 64))
+
+        rq, rk, rv = back(dqh, Lq), back(dkh, Lk), back(dvh, Lk)
+        if dq is not None:
+            dq.copy_(rq); rq = dq
+        if dk is not None:
+            dk.copy_(rk); rk = dk
+        if dv is not None:
+            dv.copy_(rv); rv = dv
+        return rq, rk, rv
+
+    # run_distillation.py:1453-1462, 1486-1493 + CrossEntropyLoss (TF:modeling_whisper.py:1083-1087), verbatim math
+    def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad):
+        zs = s_logits[:, :V].float().detach().requires_grad_(want_grad)
+        zt = t_logits[:, :V].float()
+        ce = F.cross_entropy(zs, labels, ignore_index=-100)
+        teacher = F.softmax(zt / temperature, dim=-1)
+        student = F.log_softmax(zs / temperature, dim=-1)
+        div = F.kl_div(student, teacher, reduction="none")
+        mask = (labels >= 0).unsqueeze(-1)
+        kl = (div * mask).sum() / mask.sum() * temperature ** 2
+        total = ce_weight * ce + kl_weight * kl
+        if want_grad:
+            (g,) = torch.autograd.grad(total * grad_scale, zs)
+            s_logits.zero_()
+            s_logits[:, :V] = g.to(torch.bfloat16)
+        n = (labels != -100).sum().float()
+        return torch.stack([ce.detach(), kl.detach(), total.detach(), n]).float()
+
+    def embed_fwd(self, ids, tok, pos, out_dtype):
+        B, T = ids.shape
+        x = tok.float()[ids.reshape(-1)] + pos.float()[:T].repeat(B, 1)
+        return x.to(out_dtype)
+
+    def embed_bwd(self, dx, ids, dtok, dpos):
+        B, T = ids.shape
+        dtok.index_add_(0, ids.reshape(-1), dx)
+        if dpos is not None:
+            dpos[:T] += dx.reshape(B, T, -1).sum(0)
+
+    # conv1d(k=3, pad=1) as im2col (TF:modeling_whisper.py:566-567)
+    def im2col_mel(self, mel, kpad):
+        B, Cc, T = mel.shape
+        xp = F.pad(mel, (1, 1))                                # [B, C, T+2]
+        cols = torch.stack([xp[:, :, k:k + T] for k in range(3)], 1)  # [B, 3, C, T]
+        cols = cols.permute(0, 3, 1, 2).reshape(B * T, 3 * Cc)
+        out = torch.zeros(B * T, kpad, dtype=torch.bfloat16, device=mel.device)
+        out[:, : 3 * Cc] = _bf(cols)
+        return out
+
+    def im2col_s2(self, a, B, T):
+        Cc = a.shape[1]
+        x = a.reshape(B, T, Cc)
+        xp = F.pad(x, (0, 0, 1, 1))                             # [B, T+2, C]
+        cols = torch.stack([xp[:, k:k + T:2] for k in range(3)], 2)   # [B, T/2, 3, C]
+        return cols.reshape(B * T // 2, 3 * Cc).contiguous()
+
+    def col2im_s2_gelu_bwd(self, dxcol, z, B, T):
+        Cc = z.shape[1]
+        d = dxcol.float().reshape(B, T // 2, 3, Cc)
+        acc = torch.zeros(B, T + 2, Cc, dtype=torch.float32, device=z.device)
+        for k in range(3):
+            acc[:, k:k + T:2] += d[:, :, k]
+        da = _bf(acc[:, 1:T + 1].reshape(B * T, Cc)).float()
+        zz = z.float()
+        cdf = 0.5 * (1.0 + torch.erf(zz * 0.7071067811865476))
+        pdf = 0.3989422804014327 * torch.exp(-0.5 * zz * zz)
+        return _bf(da * (cdf + zz * pdf))
+
+    def pack_conv_weight(self, w, kpad, out=None):
+        D, Cc, _ = w.shape
+        wp = torch.zeros(D, kpad, dtype=torch.bfloat16, device=w.device)
+        wp[:, : 3 * Cc] = _bf(w.permute(0, 2, 1).reshape(D, 3 * Cc))
+        if out is not None:
+            out.copy_(wp)
+            return out
+        return wp
+
+    def unpack_conv_grad(self, gwp, gw, accumulate):
+        D, Cc, _ = gw.shape
+        g = gwp[:, : 3 * Cc].reshape(D, 3, Cc).permute(0, 2, 1)
+        if accumulate:
+            gw += g
+        else:
+            gw.copy_(g)
+
+    def cast_bf16(self, x, out=None):
+        if out is not None:
+            out.copy_(x)
+            return out
+        return _bf(x)
+
+    def cast_f32(self, x, out=None):
+        if out is not None:
+            out.copy_(x)
+            return out
+        return x.float()
+
+    def colsum(self, x, out, accumulate):
+        s = x.float().sum(0)
+        if accumulate:
+            out += s
+        else:
+            out.copy_(s)
+        return out
+
+    def add(self, a, b, out_dtype):
+        return (a.float() + b.float()).to(out_dtype)
+
+    def sumsq(self, g, out):
+        out += (g.double() ** 2).sum().float()
+        return out
+
+    # torch.optim.AdamW (single-tensor path) + clip_grad_norm_ coefficient (run_distillation.py:1377-1407, 1611)
+    def adamw(self, p, g, m, v, shadow, sumsq, max_norm, grad_mul, lr, beta1, beta2, eps, weight_decay, step):
+        clip = grad_mul
+        if max_norm > 0 and sumsq is not None:
+            norm = torch.sqrt(sumsq[0]) * abs(grad_mul)
+            clip = grad_mul * torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        gg = g * clip
+        p.mul_(1.0 - lr * weight_decay)
+        m.mul_(beta1).add_(gg, alpha=1.0 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1.0 - beta2)
+        bc1 = 1.0 - beta1 ** step
+        bc2 = 1.0 - beta2 ** step
+        denom = v.sqrt() / math.sqrt(bc2) + eps
+        p.addcdiv_(m, denom, value=-lr / bc1)
+        if shadow is not None:
+            shadow.copy_(p)

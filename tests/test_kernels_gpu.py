@@ -1,0 +1,298 @@
+"""Parity of every HIP kernel (through the C ABI, via HipOps) against the torch restatement in oracle/ref_ops.py,
+on the same seeded device tensors.  bf16 kernels: the restatement rounds at the same points, so tolerances are a few
+bf16 ulps of the output scale; fp32 kernels (log-mel, loss, AdamW, LayerNorm stats) get tight tolerances."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from distil_whisper_amd.ops_hip import HipOps
+    return HipOps("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle.ref_ops import RefOps
+    return RefOps("cuda:0")
+
+
+def rnd(shape, scale=1.0, dtype=torch.bfloat16, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda", dtype=torch.float32) * scale).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def maxerr(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+def test_tr16_semantics(ops):
+    """ds_read_b64_tr_b16: output lane i (of a 16-lane group), element j = element (i&3) of the 8 bytes supplied by
+    lane 4*j + (i>>2) of the same group.  Every transposed-operand fragment in gemm/attention relies on this."""
+    out = ops.selftest_tr16().cpu()
+    for lane in range(64):
+        g, i = lane // 16, lane % 16
+        for j in range(4):
+            src_lane = g * 16 + 4 * j + (i >> 2)
+            assert out[lane, j].item() == src_lane * 4 + (i & 3), (lane, j, out[lane].tolist())
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_layouts(ops, ref, ta, tb, tile):
+    M, N, K = 520, 392, 320  # ragged M/N edges (multiples of 8), K multiple of 64
+    a = rnd((K, M) if ta else (M, K), seed=1)
+    b = rnd((K, N) if tb else (N, K), seed=2)
+    c = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, tile=tile)
+    r = ref.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32)
+    assert relerr(c, r) < 1e-5, relerr(c, r)
+
+
+def test_gemm_odd_m_rows(ops, ref):
+    a = rnd((447 * 3, 384), seed=3)          # M = 1341: not a multiple of anything
+    b = rnd((51866 // 16, 384), seed=4)      # N = 3241 (odd)
+    c = ops.gemm(a, b, out_dtype=torch.float32)
+    assert relerr(c, ref.gemm(a, b, out_dtype=torch.float32)) < 1e-5
+
+
+def test_gemm_strided_views(ops, ref):
+    """q/k/v are column slices of the fused QKV buffer: lda != K."""
+    buf = rnd((300, 3 * 128), seed=5)
+    w = rnd((256, 128), seed=6)
+    a = buf[:, 128:256]
+    c = ops.gemm(a, w, out_dtype=torch.float32)
+    assert relerr(c, ref.gemm(a, w, out_dtype=torch.float32)) < 1e-5
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_epilogues(ops, ref, tile):
+    M, N, K = 300, 512, 256
+    a, b = rnd((M, K), 0.5, seed=7), rnd((N, K), 0.1, seed=8)
+    bias = rnd((N,), 0.5, torch.float32, seed=9)
+    # bias + gelu with pre-activation kept
+    c, z = ops.gemm(a, b, bias=bias, act=1, want_z=True, tile=tile)
+    rc, rz = ref.gemm(a, b, bias=bias, act=1, want_z=True)
+    assert maxerr(z, rz) <= 0.04 and relerr(z, rz) < 3e-3
+    assert relerr(c, rc) < 6e-3
+    # fp32 residual stream, rounded projection output (student)
+    res = rnd((M, N), 1.0, torch.float32, seed=10)
+    c = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, tile=tile)
+    rc = ref.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    assert relerr(c, rc) < 2e-3
+    # in-place accumulation (R aliases C), no rounding
+    acc = res.clone()
+    ops.gemm(a, b, residual=acc, round_res=False, out_dtype=torch.float32, out=acc, tile=tile)
+    rc = ref.gemm(a, b, residual=res, round_res=False, out_dtype=torch.float32)
+    assert relerr(acc, rc) < 1e-5
+    # bf16 residual stream (teacher) + positional broadcast (row modulo)
+    pos = rnd((100, N), 1.0, torch.float32, seed=11)
+    c = ops.gemm(a, b, bias=bias, act=1, residual=pos, r_row_mod=100, out_dtype=torch.float32, tile=tile)
+    rc = ref.gemm(a, b, bias=bias, act=1, residual=pos, r_row_mod=100, out_dtype=torch.float32)
+    assert relerr(c, rc) < 3e-3
+    # fused GELU backward
+    zg = rnd((M, N), 1.0, seed=12)
+    c = ops.gemm(a, b, zgrad=zg, tile=tile)
+    rc = ref.gemm(a, b, zgrad=zg)
+    assert relerr(c, rc) < 6e-3
+
+
+def test_gemm_full_size_linearity(ops):
+    """BASELINE-size property check (no oracle needed): (A1+A2).W == A1.W + A2.W up to fp32 accumulation, and the
+    256-tile and 128-tile kernels agree, at the distil-large-v3 encoder FFN shape."""
+    M, N, K = 32 * 1500, 5120, 1280
+    a = rnd((M, K), 1.0, seed=13)
+    w = rnd((N, K), 0.03, seed=14)
+    c256 = ops.gemm(a, w, out_dtype=torch.float32, tile=256)
+    c128 = ops.gemm(a, w, out_dtype=torch.float32, tile=128)
+    assert relerr(c256, c128) < 1e-6
+    rows = torch.randint(0, M, (64,), device="cuda")
+    r = a[rows].float() @ w.float().t()
+    assert relerr(c256[rows], r) < 1e-5
+
+
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [384, 768, 1280])
+def test_layernorm(ops, ref, D, x_dtype):
+    rows = 517
+    x = rnd((rows, D), 2.0, x_dtype, seed=20) + 0.5
+    gamma = rnd((D,), 1.0, torch.float32, seed=21)
+    beta = rnd((D,), 1.0, torch.float32, seed=22)
+    y, mu, rs = ops.layernorm_fwd(x, gamma, beta)
+    ry, rmu, rrs = ref.layernorm_fwd(x, gamma, beta)
+    assert maxerr(mu, rmu) < 1e-5 and relerr(rs, rrs) < 1e-5
+    assert relerr(y, ry) < 3e-3
+    dy = rnd((rows, D), 1.0, seed=23)
+    dres = rnd((rows, D), 1.0, torch.float32, seed=24)
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    rdg, rdb = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    out = ops.layernorm_bwd(dy, x, mu, rs, gamma, dres.clone(), dg, db)
+    rout = ref.layernorm_bwd(dy, x, rmu, rrs, gamma, dres.clone(), rdg, rdb)
+    assert relerr(out, rout) < 1e-5
+    assert relerr(dg, rdg) < 1e-4 and relerr(db, rdb) < 1e-4
+    out2 = ops.layernorm_bwd(dy, x, mu, rs, gamma, None, dg, db)
+    assert relerr(out2, rout - dres) < 1e-4
+
+
+ATTN_CASES = [
+    (2, 3, 1500, 1500, False),   # encoder self
+    (2, 3, 447, 447, True),      # decoder self (causal)
+    (2, 3, 447, 1500, False),    # cross
+    (1, 2, 64, 64, True),
+    (1, 1, 5, 70, False),        # tiny ragged
+]
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", ATTN_CASES)
+def test_attention_fwd_bwd(ops, ref, B, H, Lq, Lk, causal):
+    D = H * 64
+    # q,k,v as column slices of fused projections, like the engine uses them
+    qkv = rnd((B * max(Lq, Lk), 3 * D), 1.0, seed=30)
+    q = qkv[: B * Lq, :D]
+    k = qkv[: B * Lk, D:2 * D]
+    v = qkv[: B * Lk, 2 * D:]
+    o, lse = ops.attn_fwd(q, k, v, B, H, Lq, Lk, causal, 0.125)
+    ro, rlse = ref.attn_fwd(q, k, v, B, H, Lq, Lk, causal, 0.125)
+    assert maxerr(lse, rlse) < 2e-3, maxerr(lse, rlse)
+    assert relerr(o, ro) < 1e-2, relerr(o, ro)
+    do = rnd((B * Lq, D), 1.0, seed=31)
+    dq, dk, dv = ops.attn_bwd(q, k, v, ro, do, rlse, B, H, Lq, Lk, causal, 0.125)
+    rdq, rdk, rdv = ref.attn_bwd(q, k, v, ro, do, rlse, B, H, Lq, Lk, causal, 0.125)
+    assert relerr(dv, rdv) < 1.5e-2, relerr(dv, rdv)
+    assert relerr(dq, rdq) < 1.5e-2, relerr(dq, rdq)
+    assert relerr(dk, rdk) < 1.5e-2, relerr(dk, rdk)
+
+
+def test_attention_spiked_row(ops, ref):
+    """Force the online-softmax rescale: one key per tile dominates a query's row."""
+    B, H, L = 1, 1, 320
+    q, k, v = rnd((L, 64), 1.0, seed=32), rnd((L, 64), 1.0, seed=33), rnd((L, 64), 1.0, seed=34)
+    for t in range(5):
+        k[t * 64 + 7] = q[3] * (2.0 + t)
+    o, lse = ops.attn_fwd(q, k, v, B, H, L, L, False, 0.125)
+    ro, rlse = ref.attn_fwd(q, k, v, B, H, L, L, False, 0.125)
+    assert maxerr(lse, rlse) < 2e-2 and relerr(o, ro) < 1e-2
+
+
+@pytest.mark.parametrize("V,ld", [(51866, 51968), (1000, 1000), (51864, 51864)])
+def test_distill_loss(ops, ref, V, ld):
+    rows = 97
+    s = rnd((rows, ld), 2.0, seed=40)
+    t = rnd((rows, ld), 2.0, seed=41)
+    labels = torch.randint(0, V, (rows,), device="cuda")
+    labels[::5] = -100
+    s_ref, s_hip = s.clone(), s.clone()
+    rl = ref.distill_loss(s_ref, t, labels, V, 2.0, 0.8, 1.0, 1.0, True)
+    hl = ops.distill_loss(s_hip, t, labels, V, 2.0, 0.8, 1.0, 1.0, True)
+    assert relerr(hl[:3], rl[:3]) < 2e-5, (hl.tolist(), rl.tolist())
+    assert hl[3].item() == rl[3].item()
+    assert relerr(s_hip[:, :V], s_ref[:, :V]) < 1e-2
+    assert s_hip[:, V:].abs().max().item() == 0 if ld > V else True
+    hl2 = ops.distill_loss(s.clone(), t, labels, V, 2.0, 0.8, 1.0, 1.0, False)
+    assert torch.equal(hl2, hl)
+
+
+def test_logmel(ops, ref):
+    from transformers.audio_utils import mel_filter_bank
+    g = torch.Generator().manual_seed(0)
+    audio = (0.1 * torch.randn(3, 480000, generator=g)).cuda()
+    audio[2, 200000:] = 0.0  # a padded clip: exercises the 1e-10 clamp and the max-8 clip
+    for M in (80, 128):
+        filt = torch.tensor(mel_filter_bank(201, M, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney"),
+                            dtype=torch.float32).cuda().contiguous()
+        out = ops.logmel(audio, filt)
+        r = ref.logmel(audio, filt)
+        assert out.shape == (3, M, 3000)
+        assert maxerr(out, r) < 1e-4, maxerr(out, r)
+
+
+def test_embedding(ops, ref):
+    B, T, D, V = 3, 447, 384, 1000
+    ids = torch.randint(0, V, (B, T), device="cuda")
+    tok, pos = rnd((V, D), 1.0, torch.float32, seed=50), rnd((448, D), 1.0, torch.float32, seed=51)
+    assert torch.equal(ops.embed_fwd(ids, tok, pos, torch.float32), ref.embed_fwd(ids, tok, pos, torch.float32))
+    tb, pb = tok.bfloat16(), pos.bfloat16()
+    assert maxerr(ops.embed_fwd(ids, tb, pb, torch.bfloat16), ref.embed_fwd(ids, tb, pb, torch.bfloat16)) == 0
+    dx = rnd((B * T, D), 1.0, torch.float32, seed=52)
+    dt, dp = torch.zeros(V, D, device="cuda"), torch.zeros(448, D, device="cuda")
+    rdt, rdp = torch.zeros(V, D, device="cuda"), torch.zeros(448, D, device="cuda")
+    ops.embed_bwd(dx, ids, dt, dp)
+    ref.embed_bwd(dx, ids, rdt, rdp)
+    assert relerr(dt, rdt) < 1e-5 and relerr(dp, rdp) < 1e-5
+
+
+def test_conv_helpers(ops, ref):
+    B, Cm, T, D = 2, 80, 3000, 384
+    mel = rnd((B, Cm, T), 1.0, torch.float32, seed=60)
+    assert torch.equal(ops.im2col_mel(mel, 256), ref.im2col_mel(mel, 256))
+    a = rnd((B * T, D), 1.0, seed=61)
+    assert torch.equal(ops.im2col_s2(a, B, T), ref.im2col_s2(a, B, T))
+    dxcol = rnd((B * T // 2, 3 * D), 1.0, seed=62)
+    z = rnd((B * T, D), 1.0, seed=63)
+    assert relerr(ops.col2im_s2_gelu_bwd(dxcol, z, B, T), ref.col2im_s2_gelu_bwd(dxcol, z, B, T)) < 3e-3
+    w = rnd((D, Cm, 3), 1.0, torch.float32, seed=64)
+    assert torch.equal(ops.pack_conv_weight(w, 256), ref.pack_conv_weight(w, 256))
+    gwp = rnd((D, 256), 1.0, torch.float32, seed=65)
+    g1, g2 = torch.ones(D, Cm, 3, device="cuda"), torch.ones(D, Cm, 3, device="cuda")
+    ops.unpack_conv_grad(gwp, g1, True)
+    ref.unpack_conv_grad(gwp, g2, True)
+    assert torch.equal(g1, g2)
+
+
+def test_conv_as_gemm_matches_conv1d(ops):
+    """im2col + GEMM reproduces F.conv1d(k=3,p=1) + GELU of the reference front end (stride 1 and 2)."""
+    import torch.nn.functional as F
+    B, Cm, T, D = 2, 80, 3000, 384
+    mel = rnd((B, Cm, T), 1.0, torch.float32, seed=66)
+    w1, b1 = rnd((D, Cm, 3), 0.05, torch.float32, seed=67), rnd((D,), 0.1, torch.float32, seed=68)
+    w2, b2 = rnd((D, D, 3), 0.03, torch.float32, seed=69), rnd((D,), 0.1, torch.float32, seed=70)
+    x1 = ops.im2col_mel(mel, 256)
+    a1 = ops.gemm(x1, ops.pack_conv_weight(w1, 256), bias=b1, act=1)
+    r1 = F.gelu(F.conv1d(mel.bfloat16().float(), w1.bfloat16().float(), b1, padding=1).bfloat16().float())
+    assert relerr(a1.reshape(B, T, D).transpose(1, 2), r1) < 6e-3
+    x2 = ops.im2col_s2(a1, B, T)
+    a2 = ops.gemm(x2, ops.pack_conv_weight(w2, 3 * D), bias=b2, act=1)
+    r2 = F.gelu(F.conv1d(a1.reshape(B, T, D).transpose(1, 2).float(), w2.bfloat16().float(), b2, stride=2,
+                         padding=1).bfloat16().float())
+    assert relerr(a2.reshape(B, T // 2, D).transpose(1, 2), r2) < 6e-3
+
+
+def test_small_streaming(ops, ref):
+    x = rnd((1000, 384), 1.0, torch.float32, seed=80)
+    assert torch.equal(ops.cast_bf16(x), x.bfloat16())
+    assert torch.equal(ops.cast_f32(x.bfloat16()), x.bfloat16().float())
+    xb = rnd((1003, 1280), 1.0, seed=81)
+    out = torch.ones(1280, device="cuda")
+    ops.colsum(xb, out, True)
+    assert relerr(out, 1.0 + xb.float().sum(0)) < 1e-5
+    ops.colsum(xb[:, 256:512], out[:256], False)
+    assert relerr(out[:256], xb[:, 256:512].float().sum(0)) < 1e-5
+    y = ops.add(x, x.bfloat16(), torch.bfloat16)
+    assert torch.equal(y, (x + x.bfloat16().float()).bfloat16())
+
+
+def test_adamw_and_clip(ops, ref):
+    n = 1_000_003
+    p = rnd((n,), 1.0, torch.float32, seed=90)
+    g = rnd((n,), 0.01, torch.float32, seed=91)
+    st = {}
+    for name, o in (("hip", ops), ("ref", ref)):
+        pp, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+        sh = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+        for step in (1, 2, 3):
+            ss = torch.zeros(1, device="cuda")
+            o.sumsq(g, ss)
+            o.adamw(pp, g, m, v, sh, ss, 1.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        st[name] = (pp, m, v, sh, ss)
+    assert relerr(st["hip"][4], st["ref"][4]) < 1e-5
+    for i in range(3):
+        assert relerr(st["hip"][i], st["ref"][i]) < 1e-5, i
+    assert relerr(st["hip"][3], st["ref"][3]) < 1e-3
