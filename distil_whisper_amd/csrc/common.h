@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -15,6 +16,15 @@ typedef __attribute__((address_space(1))) void glb_void_t;
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
 
 #define DW_WAVE 64
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E) -- guarantees static register indexing
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 // ---- bf16 <-> f32 (round-to-nearest-even, NaN preserved) -------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

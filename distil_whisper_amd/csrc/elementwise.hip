@@ -143,6 +143,26 @@ __global__ __launch_bounds__(256) void col2im_s2_gelu_bwd_kernel(const bf16* dxc
     *(bf16x8*)(dz + row * C + c) = o;
 }
 
+// dz = bf16(dy) * gelu'(z)   (dy f32 or bf16)
+template <bool YBF>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* dy, const bf16* z, bf16* dz, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 g;
+    if (YBF) {
+        const bf16x4 t = *(const bf16x4*)((const bf16*)dy + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = bf2f(t[e]);
+    } else {
+        g = *(const f32x4*)((const float*)dy + i);
+    }
+    const bf16x4 zz = *(const bf16x4*)(z + i);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = f2bf(round_bf16(g[e]) * gelu_grad_f(bf2f(zz[e])));
+    *(bf16x4*)(dz + i) = o;
+}
+
 // w f32 [D][C][3] -> wp bf16 [D][kpad], wp[d][k*C+c] = w[d][c][k]
 __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* w, bf16* wp, int D, int C, int kpad) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -306,6 +326,19 @@ extern "C" int dw_col2im_s2_gelu_bwd(const void* dxcol, const void* z, void* dz,
     const long nvec = (long)B * T * (C >> 3);
     hipLaunchKernelGGL(col2im_s2_gelu_bwd_kernel, dim3((nvec + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)dxcol, (const bf16*)z, (bf16*)dz, T, C, nvec);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
+extern "C" int dw_gelu_bwd(const void* dy, int dy_dtype, const void* z, void* dz, int64_t n, void* stream) {
+    if (!dy || !z || !dz || n <= 0 || (n & 3)) return DW_EINVAL;
+    dim3 grid((n / 4 + 255) / 256), block(256);
+    if (dy_dtype == DW_BF16)
+        hipLaunchKernelGGL(gelu_bwd_kernel<true>, grid, block, 0, (hipStream_t)stream, dy, (const bf16*)z, (bf16*)dz,
+                           (long)n);
+    else
+        hipLaunchKernelGGL(gelu_bwd_kernel<false>, grid, block, 0, (hipStream_t)stream, dy, (const bf16*)z, (bf16*)dz,
+                           (long)n);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

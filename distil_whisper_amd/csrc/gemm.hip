@@ -179,42 +179,50 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                 if (TB) bfr[j] = frag_kmajor<BN>(tB, wn0 + j * 32, kk, lane);
                 else bfr[j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane);
             }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
+            static_for<0, FM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, FN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                });
+            });
         }
     }
 
     // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // (compile-time indices only: a runtime-indexed accumulator array would be demoted to scratch memory)
     const int hi = lane >> 5, ln = lane & 31;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
+    const bool plain = !p.bias && !p.z_out && p.act == 0 && !p.zgrad && !p.r;
+    static_for<0, FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, FN>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             const int n = n0 + wn0 + j * 32 + ln;
-            if (n >= p.n) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            const bool n_ok = n < p.n;
+            const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
+            static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m >= p.m) continue;
-                float v = acc[i][j][r] + bv;
-                if (p.z_out) p.z_out[(long)m * p.ldz + n] = f2bf(v);
-                if (p.act == 1) v = gelu_f(round_bf16(v));
-                if (p.zgrad) v *= gelu_grad_f(bf2f(p.zgrad[(long)m * p.ldzg + n]));
-                if (p.r) {
-                    const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
-                    const float rv = p.r_dtype == DW_F32 ? ((const float*)p.r)[(long)rr * p.ldr + n]
-                                                         : bf2f(((const bf16*)p.r)[(long)rr * p.ldr + n]);
-                    v = (p.round_res ? round_bf16(v) : v) + rv;
+                if (n_ok && m < p.m) {
+                    float v = acc[i][j][r];
+                    if (!plain) {
+                        v += bv;
+                        if (p.z_out) p.z_out[(long)m * p.ldz + n] = f2bf(v);
+                        if (p.act == 1) v = gelu_f(round_bf16(v));
+                        if (p.zgrad) v *= gelu_grad_f(bf2f(p.zgrad[(long)m * p.ldzg + n]));
+                        if (p.r) {
+                            const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
+                            const float rv = p.r_dtype == DW_F32 ? ((const float*)p.r)[(long)rr * p.ldr + n]
+                                                                 : bf2f(((const bf16*)p.r)[(long)rr * p.ldr + n]);
+                            v = (p.round_res ? round_bf16(v) : v) + rv;
+                        }
+                    }
+                    if (p.c_dtype == DW_F32) ((float*)p.c)[(long)m * p.ldc + n] = v;
+                    else ((bf16*)p.c)[(long)m * p.ldc + n] = f2bf(v);
                 }
-                if (p.c_dtype == DW_F32) ((float*)p.c)[(long)m * p.ldc + n] = v;
-                else ((bf16*)p.c)[(long)m * p.ldc + n] = f2bf(v);
-            }
-        }
-    }
+            });
+        });
+    });
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -237,8 +245,10 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     if (g->m <= 0 || g->n <= 0 || g->k <= 0 || (g->k & 63)) return DW_EINVAL;
     if ((g->lda & 7) || (g->ldb & 7)) return DW_EINVAL;
     if (((uintptr_t)g->a & 15) || ((uintptr_t)g->b & 15)) return DW_EINVAL;
-    if (g->trans_a && (g->m & 7)) return DW_EINVAL;  // 16-byte column slots must be fully in or out of range
-    if (g->trans_b && (g->n & 7)) return DW_EINVAL;
+    // k-major operands are fetched in 16-byte column slots: a slot whose first column is valid is read whole, so the
+    // row must be readable up to the next multiple of 8 columns (true whenever ld covers the padded width)
+    if (g->trans_a && g->lda < ((g->m + 7) & ~7)) return DW_EINVAL;
+    if (g->trans_b && g->ldb < ((g->n + 7) & ~7)) return DW_EINVAL;
     GemmP p;
     p.a = (const bf16*)g->a; p.b = (const bf16*)g->b; p.c = g->c; p.bias = g->bias;
     p.z_out = (bf16*)g->z_out; p.zgrad = (const bf16*)g->zgrad_in; p.r = g->r;

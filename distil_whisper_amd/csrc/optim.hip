@@ -21,17 +21,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, floa
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, long n,
-                                                    const float* sumsq, float max_norm, float grad_mul, float lr,
-                                                    float beta1, float beta2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt) {
+                                                    const float* sumsq, float max_norm, float grad_mul,
+                                                    float step_size, float decay, float beta1, float omb1,
+                                                    float beta2, float omb2, float eps, float bc2_sqrt) {
     float clip = grad_mul;
     if (max_norm > 0.f && sumsq) {
         const float norm = sqrtf(sumsq[0]) * fabsf(grad_mul);
         const float coef = max_norm / (norm + 1e-6f);
         clip *= coef < 1.f ? coef : 1.f;
     }
-    const float step_size = lr / bc1;
-    const float decay = 1.f - lr * wd;
     const long stride = (long)gridDim.x * 256 * 4;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
@@ -44,8 +42,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
             for (int e = 0; e < 4; ++e) {
                 const float gg = gv[e] * clip;
                 pv[e] *= decay;
-                mv[e] = beta1 * mv[e] + (1.f - beta1) * gg;
-                vv[e] = beta2 * vv[e] + (1.f - beta2) * gg * gg;
+                mv[e] = beta1 * mv[e] + omb1 * gg;
+                vv[e] = beta2 * vv[e] + omb2 * (gg * gg);
                 const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
                 pv[e] -= step_size * (mv[e] / denom);
                 sh[e] = f2bf(pv[e]);
@@ -58,8 +56,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
             for (long j = i; j < n; ++j) {
                 const float gg = g[j] * clip;
                 float pj = p[j] * decay;
-                const float mj = beta1 * m[j] + (1.f - beta1) * gg;
-                const float vj = beta2 * v[j] + (1.f - beta2) * gg * gg;
+                const float mj = beta1 * m[j] + omb1 * gg;
+                const float vj = beta2 * v[j] + omb2 * (gg * gg);
                 pj -= step_size * (mj / (sqrtf(vj) / bc2_sqrt + eps));
                 p[j] = pj; m[j] = mj; v[j] = vj;
                 if (shadow) shadow[j] = f2bf(pj);
@@ -79,19 +77,21 @@ extern "C" int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream)
 }
 
 extern "C" int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, const float* sumsq,
-                        float max_norm, float grad_mul, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int step, void* stream) {
+                        float max_norm, float grad_mul, double lr, double beta1, double beta2, double eps,
+                        double weight_decay, int step, void* stream) {
     if (!p || !g || !m || !v || n <= 0 || step < 1) return DW_EINVAL;
     if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) ||
         ((uintptr_t)shadow & 7))
         return DW_EINVAL;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+    // scalar hyper-parameter arithmetic in double, exactly as torch.optim.AdamW does it on the host
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     long nb = (n / 4 + 255) / 256;
     if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow, (long)n,
-                       sumsq, max_norm, grad_mul, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+                       sumsq, max_norm, grad_mul, (float)(lr / bc1), (float)(1.0 - lr * weight_decay), (float)beta1,
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2));
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

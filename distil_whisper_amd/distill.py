@@ -1,0 +1,164 @@
+"""Distillation step on the MI355X engine: teacher forward + student forward/backward + gradient all-reduce + global
+norm clip + AdamW -- the hot loop of run_distillation.py:1465-1495 and 1606-1614, one process per GPU.
+
+Semantics kept from the reference (PyTorch path):
+  * loss = 0.8 * CE + kl_weight * KL * T^2, CE = token mean over labels != -100, KL = sum / count(labels >= 0)
+    (run_distillation.py:1453-1462, 1486-1493), each computed PER RANK; ranks are then averaged by the gradient
+    all-reduce exactly like DDP does -- not the Flax path's global-token normalisation;
+  * shared-encoder mode (`--freeze_encoder` with an identical teacher encoder, run_distillation.py:1046-1049,
+    1473-1478): one encoder forward, teacher decoder inputs rebuilt from the labels by shift_tokens_right;
+  * AdamW with two parameter groups (decay / no decay for biases and LayerNorm, 1386-1407), clip_grad_norm_(1.0).
+Data parallelism: the flat fp32 gradient buffer is all-reduced with RCCL (torch.distributed "nccl" backend on ROCm)
+in layer-ordered buckets on a side stream while the backward of earlier layers is still running.
+"""
+import torch
+
+from .engine import ParamStore, WhisperDims, WhisperEngine
+
+
+def shift_tokens_right(labels, pad_token_id, decoder_start_token_id):
+    """TF:modeling_whisper.py:68-81 (used by the shared-encoder teacher call, run_distillation.py:1478)."""
+    out = labels.new_zeros(labels.shape)
+    out[:, 1:] = labels[:, :-1]
+    out[:, 0] = decoder_start_token_id
+    return out.masked_fill(out == -100, pad_token_id)
+
+
+class GradReducer:
+    """Bucketed all-reduce (sum) of ranges of the flat gradient buffer, issued on a communication stream as soon as a
+    range is final.  With world_size 1 (or no process group) it is a no-op."""
+
+    def __init__(self, flat, group=None, bucket_bytes=256 << 20):
+        import torch.distributed as dist
+        self.flat, self.group, self.dist = flat, group, dist
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.bucket_elems = bucket_bytes // 4
+        self.pending_lo = self.pending_hi = None
+        self.handles = []
+        self.cuda = flat.is_cuda
+        self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.world > 1) else None
+
+    def _launch(self, lo, hi):
+        view = self.flat[lo:hi]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.stream):
+                self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
+        else:
+            self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def ready(self, lo, hi):
+        """Gradients in [lo, hi) are final.  Ranges must arrive adjacent and descending (backward order)."""
+        if self.world == 1 or hi <= lo:
+            return
+        if self.pending_lo is not None and hi == self.pending_lo:
+            self.pending_lo = lo
+        else:
+            self.flush()
+            self.pending_lo, self.pending_hi = lo, hi
+        if self.pending_hi - self.pending_lo >= self.bucket_elems:
+            self.flush()
+
+    def flush(self):
+        if self.pending_lo is not None:
+            self._launch(self.pending_lo, self.pending_hi)
+            self.pending_lo = self.pending_hi = None
+
+    def wait(self):
+        self.flush()
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+
+
+class DistillationTrainer:
+    def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
+                 lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
+                 share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None):
+        self.ops = ops
+        self.sdims, self.tdims = WhisperDims.from_any(student_dims), WhisperDims.from_any(teacher_dims)
+        frozen = []
+        if freeze_encoder:
+            frozen.append("model.encoder.")
+        if freeze_embed_positions:
+            frozen.append("model.decoder.embed_positions.")
+        self.student_store = ParamStore(ops, self.sdims, student_sd, trainable=True, frozen_prefixes=tuple(frozen))
+        self.teacher_store = ParamStore(ops, self.tdims, teacher_sd, trainable=False, round_bf16=True)
+        self.student = WhisperEngine(ops, self.student_store, torch.float32)
+        self.teacher = WhisperEngine(ops, self.teacher_store, ops.lowp)
+        self.temperature, self.kl_weight = temperature, kl_weight
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self.freeze_encoder, self.share_encoder = freeze_encoder, share_encoder
+        if share_encoder and not freeze_encoder:
+            raise ValueError("share_encoder requires freeze_encoder (run_distillation.py:1046-1049)")
+        self.step_count = 0
+        st = self.student_store
+        self.reducer = GradReducer(st.G, process_group) if st.G is not None else None
+        self.world = self.reducer.world if self.reducer else 1
+        self.mel_filters = mel_filters
+        self._sumsq = ops.zeros((1,), torch.float32)
+        self.segments = st.adam_segments(weight_decay)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def features(self, audio):
+        """fp32 waveforms [B, 480000] on the device -> log-mel input_features [B, n_mels, 3000]."""
+        return self.ops.logmel(audio, self.mel_filters)
+
+    def forward_backward(self, input_features, decoder_input_ids, labels, lr=None):
+        """One micro-batch: returns losses fp32[4] = (ce, kl, loss, n_valid) on the device (no host sync)."""
+        ops, S, T = self.ops, self.student, self.teacher
+        B, Td = decoder_input_ids.shape
+        labels_flat = labels.reshape(-1).contiguous()
+        enc_s, ectx = S.encode(input_features, save=not self.freeze_encoder)
+        logits_s, dctx = S.decode(decoder_input_ids, enc_s, save=True)
+        if self.share_encoder:
+            t_ids = shift_tokens_right(labels, self.tdims.pad_token_id, self.tdims.decoder_start_token_id)
+            logits_t, _ = T.decode(t_ids, enc_s, save=False)
+        else:
+            enc_t, _ = T.encode(input_features, save=False)
+            logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False)
+            del enc_t
+        R = B * Td
+        losses = ops.distill_loss(logits_s[:R], logits_t[:R], labels_flat, self.sdims.vocab, self.temperature, 0.8,
+                                  self.kl_weight, 1.0, True)
+        del logits_t
+        S.zero_small_grads()
+        st = self.student_store
+        denc = S.backward_decoder(dctx, logits_s, want_denc=not self.freeze_encoder)
+        del logits_s, dctx
+        if self.reducer is not None and self.world > 1:
+            self.reducer.ready(st.train_start if self.freeze_encoder else st.dec_start, st.train_end)
+        if not self.freeze_encoder:
+            S.backward_encoder(ectx, denc)
+            if self.reducer is not None and self.world > 1:
+                self.reducer.ready(st.train_start, st.dec_start)
+        return losses
+
+    def optimizer_step(self, lr=None):
+        """clip_grad_norm_ + AdamW over the flat buffers; refreshes the bf16 shadow weights (fused) and the packed
+        conv weights."""
+        ops, st = self.ops, self.student_store
+        if self.reducer is not None:
+            self.reducer.wait()
+        self.step_count += 1
+        lo, hi = st.train_start, st.train_end
+        gm = 1.0 / self.world
+        self._sumsq.zero_()
+        ops.sumsq(st.G[lo:hi], self._sumsq)
+        for a, b, wd in self.segments:
+            ops.adamw(st.P[a:b], st.G[a:b], st.M[a:b], st.V[a:b], st.S[a:b], self._sumsq, self.max_grad_norm, gm,
+                      self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, wd, self.step_count)
+        if not self.freeze_encoder:
+            st.repack_conv()
+
+    def train_step(self, input_features, decoder_input_ids, labels, lr=None):
+        losses = self.forward_backward(input_features, decoder_input_ids, labels)
+        self.optimizer_step(lr)
+        return losses
+
+    def grad_norm(self):
+        return torch.sqrt(self._sumsq[0]) / self.world

@@ -1,0 +1,489 @@
+"""Host engine of the MI355X Whisper distillation path: parameter store, hand-written forward and backward of the
+Whisper encoder-decoder over the `ops` interface (distil_whisper_amd.ops_hip.HipOps -> libdwamd.so HIP kernels).
+
+What it replaces in the reference: WhisperForConditionalGeneration.forward + autograd backward
+(TF:modeling_whisper.py:592-646 encoder, 690-795 decoder, 994-1099 LM head) as driven by `train_step`
+(run_distillation.py:1465-1495).  The dtype flow reproduces the reference under `--dtype bfloat16`
+(SURVEY.md section 8 a'): student = fp32 master weights, bf16 GEMM/attention operands, fp32 residual stream and LayerNorm;
+teacher = bf16 weights and bf16 residual stream.  Activations kept for backward are exactly the ones autograd would
+keep (no recompute); weight gradients are produced in fp32 straight into one flat gradient buffer so that the
+data-parallel all-reduce and the fused clip+AdamW run over contiguous memory.
+
+No autograd, no nn.Module here: modeling.py wraps this engine behind the reference's module surface.
+"""
+from dataclasses import dataclass
+
+import torch
+
+
+@dataclass
+class WhisperDims:
+    d_model: int
+    heads: int
+    ffn: int
+    enc_layers: int
+    dec_layers: int
+    vocab: int
+    n_mels: int
+    max_src: int = 1500
+    max_tgt: int = 448
+    pad_token_id: int = 50256
+    decoder_start_token_id: int = 50257
+
+    @staticmethod
+    def from_any(c):
+        """Accepts a transformers WhisperConfig, an oracle OracleConfig or a WhisperDims."""
+        if isinstance(c, WhisperDims):
+            return c
+        if hasattr(c, "encoder_attention_heads"):
+            return WhisperDims(c.d_model, c.encoder_attention_heads, c.encoder_ffn_dim, c.encoder_layers,
+                               c.decoder_layers, c.vocab_size, c.num_mel_bins, c.max_source_positions,
+                               c.max_target_positions, c.pad_token_id, c.decoder_start_token_id)
+        return WhisperDims(c.d_model, c.heads, c.ffn, c.enc_layers, c.dec_layers, c.vocab, c.n_mels, c.max_src,
+                           c.max_tgt, c.pad_token_id, c.decoder_start_token_id)
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def layer_names(prefix, cross):
+    blocks = ["self_attn", "encoder_attn"] if cross else ["self_attn"]
+    out = []
+    for b in blocks:
+        out += [(f"{prefix}.{b}.q_proj.weight", "w"), (f"{prefix}.{b}.k_proj.weight", "w"),
+                (f"{prefix}.{b}.v_proj.weight", "w"), (f"{prefix}.{b}.q_proj.bias", "b"),
+                (f"{prefix}.{b}.k_proj.bias", "zero"), (f"{prefix}.{b}.v_proj.bias", "b"),
+                (f"{prefix}.{b}.out_proj.weight", "w"), (f"{prefix}.{b}.out_proj.bias", "b"),
+                (f"{prefix}.{b}_layer_norm.weight", "ln"), (f"{prefix}.{b}_layer_norm.bias", "ln")]
+    out += [(f"{prefix}.fc1.weight", "w"), (f"{prefix}.fc1.bias", "b"), (f"{prefix}.fc2.weight", "w"),
+            (f"{prefix}.fc2.bias", "b"), (f"{prefix}.final_layer_norm.weight", "ln"),
+            (f"{prefix}.final_layer_norm.bias", "ln")]
+    return out
+
+
+class ParamStore:
+    """All parameters of one model in flat device buffers.
+
+    p      fp32 master weights (HF names -> views; `k_proj.bias` are zero dummies that keep q/k/v biases contiguous)
+    s      bf16 shadow of p with identical offsets (GEMM operands); q/k/v weights are adjacent, so the fused
+           [3D, D] QKV weight is a plain view
+    g,m,v  fp32 gradient and Adam moments (trainable models only), same offsets
+    Frozen tensors come first, trainable ones after, so gradient all-reduce / clip / AdamW see one contiguous range.
+    """
+
+    def __init__(self, ops, dims: WhisperDims, state_dict, trainable=False, frozen_prefixes=(), round_bf16=False):
+        self.ops, self.dims, self.trainable = ops, dims, trainable
+        D, Fd = dims.d_model, dims.ffn
+        spec = [("model.encoder.conv1.weight", (D, dims.n_mels, 3), "conv"), ("model.encoder.conv1.bias", (D,), "b"),
+                ("model.encoder.conv2.weight", (D, D, 3), "conv"), ("model.encoder.conv2.bias", (D,), "b"),
+                ("model.encoder.embed_positions.weight", (dims.max_src, D), "frozen")]
+
+        def shapes(name, kind):
+            if kind == "w":
+                if name.endswith("fc1.weight"):
+                    return (Fd, D)
+                if name.endswith("fc2.weight"):
+                    return (D, Fd)
+                return (D, D)
+            if name.endswith("fc1.bias"):
+                return (Fd,)
+            return (D,)
+
+        for i in range(dims.enc_layers):
+            spec += [(n, shapes(n, k), k) for n, k in layer_names(f"model.encoder.layers.{i}", False)]
+        spec += [("model.encoder.layer_norm.weight", (D,), "ln"), ("model.encoder.layer_norm.bias", (D,), "ln"),
+                 ("model.decoder.embed_positions.weight", (dims.max_tgt, D), "emb")]
+        for i in range(dims.dec_layers):
+            spec += [(n, shapes(n, k), k) for n, k in layer_names(f"model.decoder.layers.{i}", True)]
+        spec += [("model.decoder.layer_norm.weight", (D,), "ln"), ("model.decoder.layer_norm.bias", (D,), "ln"),
+                 ("model.decoder.embed_tokens.weight", (dims.vocab, D), "emb")]
+
+        def is_frozen(name, kind):
+            if kind == "frozen" or not trainable:
+                return True
+            return any(name.startswith(pf) for pf in frozen_prefixes)
+
+        ordered = [e for e in spec if is_frozen(e[0], e[2])] + [e for e in spec if not is_frozen(e[0], e[2])]
+        self.entries, off = {}, 0
+        self.train_start = None
+        for name, shape, kind in ordered:
+            if self.train_start is None and not is_frozen(name, kind):
+                self.train_start = off
+            n = 1
+            for d in shape:
+                n *= d
+            self.entries[name] = (off, shape, kind)
+            off += _rup(n, 64)
+        self.train_end = off
+        if self.train_start is None:
+            self.train_start = off
+        dec_offs = [o for n, (o, _, _) in self.entries.items() if n.startswith("model.decoder.") and o >= self.train_start]
+        self.dec_start = min(dec_offs) if dec_offs else self.train_end  # first trainable decoder-side element
+        total = off + 64 * max(D, 64)  # slack: the LM-head dX GEMM over-reads up to 63 rows past embed_tokens
+        self.total = total
+        self.P = ops.zeros((total,), torch.float32)
+        self.S = ops.zeros((total,), ops.lowp)
+        self.G = self.M = self.V = None
+        if trainable and self.train_end > self.train_start:
+            self.G = ops.zeros((total,), torch.float32)
+            self.M = ops.zeros((total,), torch.float32)
+            self.V = ops.zeros((total,), torch.float32)
+        self.p, self.s, self.g = {}, {}, {}
+        for name, (o, shape, kind) in self.entries.items():
+            n = 1
+            for d in shape:
+                n *= d
+            self.p[name] = self.P[o:o + n].view(shape)
+            self.s[name] = self.S[o:o + n].view(shape)
+            if self.G is not None and o >= self.train_start:
+                self.g[name] = self.G[o:o + n].view(shape)
+        self.kpad1 = _rup(3 * dims.n_mels, 64)
+        self.conv1_packed = ops.zeros((D, self.kpad1), ops.lowp)
+        self.conv2_packed = ops.zeros((D, 3 * D), ops.lowp)
+        self.load_state_dict(state_dict, round_bf16=round_bf16)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def real_names(self):
+        return [n for n, (_, _, k) in self.entries.items() if k != "zero"]
+
+    def load_state_dict(self, sd, round_bf16=False):
+        dev = self.P.device
+        for name in self.real_names():
+            src = sd[name].detach().to(device=dev, dtype=torch.float32)
+            if round_bf16:
+                src = src.to(torch.bfloat16).to(torch.float32)
+            self.p[name].copy_(src)
+        self.refresh_shadow()
+
+    def state_dict(self):
+        sd = {n: self.p[n].detach().clone() for n in self.real_names()}
+        sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]
+        return sd
+
+    def refresh_shadow(self):
+        """bf16 shadow <- master (whole buffer) and conv weights -> GEMM layout."""
+        self.ops.cast_bf16(self.P, out=self.S)
+        self.repack_conv()
+
+    def repack_conv(self):
+        self.ops.pack_conv_weight(self.p["model.encoder.conv1.weight"], self.kpad1, out=self.conv1_packed)
+        self.ops.pack_conv_weight(self.p["model.encoder.conv2.weight"], 3 * self.dims.d_model, out=self.conv2_packed)
+
+    def is_trainable(self, name):
+        return self.G is not None and self.entries[name][0] >= self.train_start
+
+    # fused views ------------------------------------------------------------------------------------------------
+    def attn_views(self, prefix, cross_kv=False):
+        """Views for one attention block: fused QKV (self) or Q + fused KV (cross)."""
+        D = self.dims.d_model
+        oq = self.entries[f"{prefix}.q_proj.weight"][0]
+        ob = self.entries[f"{prefix}.q_proj.bias"][0]
+        assert self.entries[f"{prefix}.k_proj.weight"][0] == oq + D * D
+        assert self.entries[f"{prefix}.v_proj.bias"][0] == ob + 2 * D
+        v = {"wqkv": self.S[oq:oq + 3 * D * D].view(3 * D, D), "bqkv": self.P[ob:ob + 3 * D],
+             "wo": self.s[f"{prefix}.out_proj.weight"], "bo": self.p[f"{prefix}.out_proj.bias"]}
+        if self.is_trainable(f"{prefix}.q_proj.weight"):
+            v["g_wqkv"] = self.G[oq:oq + 3 * D * D].view(3 * D, D)
+            v["g_bqkv"] = self.G[ob:ob + 3 * D]
+            v["g_wo"] = self.g[f"{prefix}.out_proj.weight"]
+            v["g_bo"] = self.g[f"{prefix}.out_proj.bias"]
+        return v
+
+    def adam_segments(self, weight_decay, decay_filter=None):
+        """Contiguous [start, end, wd) ranges of the trainable region (run_distillation.py:1386-1407: no decay for
+        LayerNorm parameters and biases)."""
+        segs = []
+        for name, (o, shape, kind) in self.entries.items():
+            if o < self.train_start:
+                continue
+            n = 1
+            for d in shape:
+                n *= d
+            wd = weight_decay if kind in ("w", "conv", "emb") else 0.0
+            end = o + _rup(n, 64)
+            if segs and segs[-1][2] == wd and segs[-1][1] == o:
+                segs[-1] = (segs[-1][0], end, wd)
+            else:
+                segs.append((o, end, wd))
+        return segs
+
+
+class WhisperEngine:
+    """Forward/backward of one Whisper model over a ParamStore.  `stream` is the residual-stream dtype: fp32 for the
+    student (autocast keeps residual adds and LayerNorm in fp32), the low-precision dtype for the bf16 teacher."""
+
+    def __init__(self, ops, store: ParamStore, stream_dtype=torch.float32):
+        self.ops, self.st, self.dims = ops, store, store.dims
+        self.stream = stream_dtype
+        self.lowp = ops.lowp
+        self.ldv = _rup(self.dims.vocab, 64)
+
+    # ---- helpers -------------------------------------------------------------------------------------------------
+    def act(self, rows, cols, dtype=None):
+        """Activation buffer with rows padded to a multiple of 64 and the pad rows zeroed: the weight-gradient GEMMs
+        contract over the token dimension in K-steps of 64 and must see zeros there."""
+        dtype = self.lowp if dtype is None else dtype
+        rp = _rup(rows, 64)
+        t = self.ops.empty((rp, cols), dtype)
+        if rp > rows:
+            t[rows:].zero_()
+        return t
+
+    def _ln(self, name, x, R, save):
+        y = self.act(R, x.shape[1])
+        _, mu, rs = self.ops.layernorm_fwd(x[:R] if x.shape[0] != R else x, self.st.p[f"{name}.weight"],
+                                           self.st.p[f"{name}.bias"], 1e-5, save_stats=save, out=y[:R])
+        return y, mu, rs
+
+    def _ln_bwd(self, name, dy, x, mu, rs, dres, R):
+        if self.st.is_trainable(f"{name}.weight"):
+            dg, db = self.st.g[f"{name}.weight"], self.st.g[f"{name}.bias"]
+        else:
+            dg, db = self._scratch_vec(x.shape[1]), self._scratch_vec(x.shape[1], 1)
+        return self.ops.layernorm_bwd(dy[:R], x[:R] if x.shape[0] != R else x, mu, rs, self.st.p[f"{name}.weight"],
+                                      dres, dg, db)
+
+    def _scratch_vec(self, n, slot=0):
+        key = (n, slot)
+        if not hasattr(self, "_sv"):
+            self._sv = {}
+        if key not in self._sv:
+            self._sv[key] = self.ops.zeros((n,), torch.float32)
+        return self._sv[key]
+
+    def _wgrad(self, dy, x, gout, gbias, R, bias_cols=None):
+        """gout (+)= dy^T . x over the (padded) token dimension; gbias (+)= column sums of dy."""
+        acc = self._accumulate
+        if gout is not None:
+            self.ops.gemm(dy, x, trans_a=True, trans_b=True, out_dtype=torch.float32, out=gout,
+                          residual=gout if acc else None, round_res=False)
+        if gbias is not None:
+            if bias_cols is None:
+                self.ops.colsum(dy[:R], gbias, accumulate=True)
+            else:
+                for lo, hi in bias_cols:
+                    self.ops.colsum(dy[:R, lo:hi], gbias[lo:hi], accumulate=True)
+
+    # ---- encoder -------------------------------------------------------------------------------------------------
+    def encode(self, mel, save=False):
+        """WhisperEncoder.forward (TF:modeling_whisper.py:592-646).  mel fp32 [B, n_mels, 3000] -> (enc_out
+        low-precision [rows_padded, D], ctx)."""
+        ops, st, d = self.ops, self.st, self.dims
+        B, _, T = mel.shape
+        D, H = d.d_model, d.heads
+        R1, R = B * T, B * T // 2
+        L = T // 2
+        ctx = {"B": B, "T": T, "R": R, "layers": []} if save else None
+        xcol1 = self.act(R1, st.kpad1)
+        ops.im2col_mel(mel, st.kpad1, out=xcol1[:R1])
+        a1 = self.act(R1, D)
+        _, z1 = ops.gemm(xcol1[:R1], st.conv1_packed, bias=st.p["model.encoder.conv1.bias"], act=1, want_z=True,
+                         out=a1[:R1])
+        xcol2 = self.act(R, 3 * D)
+        ops.im2col_s2(a1[:R1], B, T, out=xcol2[:R])
+        x = ops.empty((R, D), self.stream)
+        _, z2 = ops.gemm(xcol2[:R], st.conv2_packed, bias=st.p["model.encoder.conv2.bias"], act=1, want_z=True,
+                         residual=st.p["model.encoder.embed_positions.weight"], r_row_mod=L, round_res=True, out=x)
+        if save:
+            ctx.update(xcol1=xcol1, z1=z1, xcol2=xcol2, z2=z2)
+        else:
+            del xcol1, a1, z1, xcol2, z2
+        for i in range(d.enc_layers):
+            x, lc = self._layer_fwd(f"model.encoder.layers.{i}", x, B, L, None, 0, False, save)
+            if save:
+                ctx["layers"].append(lc)
+        y, mu, rs = self._ln("model.encoder.layer_norm", x, R, save)
+        if save:
+            ctx.update(x_final=x, mu=mu, rs=rs, enc_out=y)
+        return y, ctx
+
+    def _layer_fwd(self, p, x, B, L, enc_out, Lk, causal, save):
+        """One pre-LN transformer layer (TF:modeling_whisper.py:379-413 encoder, 448-505 decoder)."""
+        ops, st, d = self.ops, self.st, self.dims
+        D, H, R = d.d_model, d.heads, B * L
+        lc = {} if save else None
+        # --- self attention
+        av = st.attn_views(f"{p}.self_attn")
+        h, mu, rs = self._ln(f"{p}.self_attn_layer_norm", x, R, save)
+        qkv = self.act(R, 3 * D)
+        ops.gemm(h[:R], av["wqkv"], bias=av["bqkv"], out=qkv[:R])
+        o = self.act(R, D)
+        _, lse = ops.attn_fwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], B, H, L, L, causal, 0.125, out=o[:R])
+        x1 = ops.gemm(o[:R], av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
+        if save:
+            lc.update(x0=x, mu0=mu, rs0=rs, h0=h, qkv=qkv, o0=o, lse0=lse)
+        x = x1
+        # --- cross attention (decoder only)
+        if enc_out is not None:
+            cv = st.attn_views(f"{p}.encoder_attn")
+            Re = B * Lk
+            h, mu, rs = self._ln(f"{p}.encoder_attn_layer_norm", x, R, save)
+            q = self.act(R, D)
+            ops.gemm(h[:R], cv["wqkv"][:D], bias=cv["bqkv"][:D], out=q[:R])
+            kv = self.act(Re, 2 * D)
+            ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=kv[:Re])
+            o = self.act(R, D)
+            _, lse = ops.attn_fwd(q[:R], kv[:Re, :D], kv[:Re, D:], B, H, L, Lk, False, 0.125, out=o[:R])
+            x1 = ops.gemm(o[:R], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            if save:
+                lc.update(x1=x, mu1=mu, rs1=rs, h1=h, q1=q, kv1=kv, o1=o, lse1=lse)
+            x = x1
+        # --- feed forward
+        h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save)
+        a = self.act(R, d.ffn)
+        res = ops.gemm(h[:R], st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1, want_z=save, out=a[:R])
+        z = res[1] if save else None
+        x2 = ops.gemm(a[:R], st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
+                      out_dtype=self.stream)
+        if save:
+            lc.update(x2=x, mu2=mu, rs2=rs, h2=h, a=a, z=z)
+        return x2, lc
+
+    # ---- decoder -------------------------------------------------------------------------------------------------
+    def decode(self, ids, enc_out, save=False):
+        """WhisperDecoder.forward + tied LM head (TF:modeling_whisper.py:690-795, 965, 1080).  ids int64 [B, T];
+        enc_out low-precision [>= B*Lk, D].  Returns (logits low-precision [B*T, ldv] with V valid columns, ctx)."""
+        ops, st, d = self.ops, self.st, self.dims
+        B, T = ids.shape
+        R, Lk = B * T, d.max_src
+        ctx = {"B": B, "T": T, "R": R, "ids": ids, "layers": [], "enc_out": enc_out} if save else None
+        if self.stream == torch.float32:
+            x = ops.embed_fwd(ids, st.p["model.decoder.embed_tokens.weight"],
+                              st.p["model.decoder.embed_positions.weight"], torch.float32)
+        else:
+            x = ops.embed_fwd(ids, st.s["model.decoder.embed_tokens.weight"],
+                              st.s["model.decoder.embed_positions.weight"], self.lowp)
+        for i in range(d.dec_layers):
+            x, lc = self._layer_fwd(f"model.decoder.layers.{i}", x, B, T, enc_out, Lk, True, save)
+            if save:
+                ctx["layers"].append(lc)
+        hf, mu, rs = self._ln("model.decoder.layer_norm", x, R, save)
+        logits = self.act(R, self.ldv)
+        ops.gemm(hf[:R], st.s["model.decoder.embed_tokens.weight"], out=logits[:R, :d.vocab])
+        if save:
+            ctx.update(x_final=x, mu=mu, rs=rs, hf=hf)
+        return logits, ctx
+
+    # ---- backward --------------------------------------------------------------------------------------------------
+    def _layer_bwd(self, p, lc, dres, B, L, Lk, causal, denc):
+        """Backward of _layer_fwd.  dres: fp32 [R, D] gradient w.r.t. the layer output, updated in place to the
+        gradient w.r.t. the layer input.  denc: fp32 [Re, D] accumulator for the encoder output gradient."""
+        ops, st, d = self.ops, self.st, self.dims
+        D, H, R = d.d_model, d.heads, B * L
+        tr = st.is_trainable(f"{p}.fc1.weight")
+        # --- feed forward
+        dy = self.act(R, D)
+        ops.cast_bf16(dres, out=dy[:R])
+        dz = self.act(R, d.ffn)
+        ops.gemm(dy[:R], st.s[f"{p}.fc2.weight"], trans_b=True, zgrad=lc["z"], out=dz[:R])
+        if tr:
+            self._wgrad(dy, lc["a"], st.g[f"{p}.fc2.weight"], st.g[f"{p}.fc2.bias"], R)
+            self._wgrad(dz, lc["h2"], st.g[f"{p}.fc1.weight"], st.g[f"{p}.fc1.bias"], R)
+        dh = ops.gemm(dz[:R], st.s[f"{p}.fc1.weight"], trans_b=True)
+        self._ln_bwd(f"{p}.final_layer_norm", dh, lc["x2"], lc["mu2"], lc["rs2"], dres, R)
+        del dz, dh
+        # --- cross attention
+        if "x1" in lc:
+            cv = st.attn_views(f"{p}.encoder_attn")
+            Re = B * Lk
+            ops.cast_bf16(dres, out=dy[:R])
+            do = ops.gemm(dy[:R], cv["wo"], trans_b=True)
+            dq = self.act(R, D)
+            dkv = self.act(Re, 2 * D)
+            ops.attn_bwd(lc["q1"][:R], lc["kv1"][:Re, :D], lc["kv1"][:Re, D:], lc["o1"][:R], do, lc["lse1"], B, H, L,
+                         Lk, False, 0.125, dq=dq[:R], dk=dkv[:Re, :D], dv=dkv[:Re, D:])
+            if tr:
+                self._wgrad(dy, lc["o1"], cv["g_wo"], cv["g_bo"], R)
+                self._wgrad(dq, lc["h1"], cv["g_wqkv"][:D], cv["g_bqkv"][:D], R)
+                self._wgrad(dkv, lc["enc_out"], cv["g_wqkv"][D:], cv["g_bqkv"][D:], Re, bias_cols=[(D, 2 * D)])
+            if denc is not None:
+                ops.gemm(dkv[:Re], cv["wqkv"][D:], trans_b=True, residual=denc, round_res=True,
+                         out_dtype=torch.float32, out=denc)
+            dh = ops.gemm(dq[:R], cv["wqkv"][:D], trans_b=True)
+            self._ln_bwd(f"{p}.encoder_attn_layer_norm", dh, lc["x1"], lc["mu1"], lc["rs1"], dres, R)
+            del do, dq, dkv, dh
+        # --- self attention
+        av = st.attn_views(f"{p}.self_attn")
+        ops.cast_bf16(dres, out=dy[:R])
+        do = ops.gemm(dy[:R], av["wo"], trans_b=True)
+        dqkv = self.act(R, 3 * D)
+        qkv = lc["qkv"]
+        ops.attn_bwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], lc["o0"][:R], do, lc["lse0"], B, H, L, L, causal,
+                     0.125, dq=dqkv[:R, :D], dk=dqkv[:R, D:2 * D], dv=dqkv[:R, 2 * D:])
+        if tr:
+            self._wgrad(dy, lc["o0"], av["g_wo"], av["g_bo"], R)
+            self._wgrad(dqkv, lc["h0"], av["g_wqkv"], av["g_bqkv"], R, bias_cols=[(0, D), (2 * D, 3 * D)])
+        dh = ops.gemm(dqkv[:R], av["wqkv"], trans_b=True)
+        self._ln_bwd(f"{p}.self_attn_layer_norm", dh, lc["x0"], lc["mu0"], lc["rs0"], dres, R)
+        return dres
+
+    def backward_decoder(self, ctx, dlogits, want_denc=True, accumulate=False):
+        """dlogits: low-precision [>=R, ldv] (pad columns zero).  Accumulates parameter gradients into the store and
+        returns the fp32 gradient w.r.t. the encoder output ([B*max_src, D]) or None."""
+        ops, st, d = self.ops, self.st, self.dims
+        self._accumulate = accumulate
+        B, T, R, D = ctx["B"], ctx["T"], ctx["R"], d.d_model
+        Lk = d.max_src
+        emb = "model.decoder.embed_tokens.weight"
+        tr_emb = st.is_trainable(emb)
+        if tr_emb:
+            # tied head: dE = dlogits^T . hf  (rows beyond V of the padded dlogits are not stored: m = V)
+            ops.gemm(dlogits[:, :d.vocab], ctx["hf"], trans_a=True, trans_b=True, out_dtype=torch.float32,
+                     out=st.g[emb], residual=st.g[emb] if accumulate else None, round_res=False)
+        # dhf = dlogits . E : contraction over the padded vocabulary (pad columns of dlogits are zero; the rows of
+        # the shadow buffer behind E are finite parameters / zero slack)
+        eo = st.entries[emb][0]
+        e_pad = st.S[eo:eo + self.ldv * D].view(self.ldv, D)
+        dh = ops.gemm(dlogits[:R], e_pad, trans_b=True)
+        dres = self._ln_bwd("model.decoder.layer_norm", dh, ctx["x_final"], ctx["mu"], ctx["rs"], None, R)
+        denc = ops.zeros((B * Lk, D), torch.float32) if want_denc else None
+        for i in reversed(range(d.dec_layers)):
+            lc = ctx["layers"][i]
+            lc["enc_out"] = ctx["enc_out"]
+            self._layer_bwd(f"model.decoder.layers.{i}", lc, dres, B, T, Lk, True, denc)
+            ctx["layers"][i] = None
+        if tr_emb or st.is_trainable("model.decoder.embed_positions.weight"):
+            dtok = st.g[emb] if tr_emb else self._scratch_tok()
+            dpos = st.g.get("model.decoder.embed_positions.weight")
+            ops.embed_bwd(dres, ctx["ids"], dtok, dpos)
+        return denc
+
+    def _scratch_tok(self):
+        if not hasattr(self, "_stok"):
+            self._stok = self.ops.zeros((self.dims.vocab, self.dims.d_model), torch.float32)
+        return self._stok
+
+    def backward_encoder(self, ctx, denc, accumulate=False):
+        """denc: fp32 [R, D] gradient w.r.t. the encoder output (encoder_last_hidden_state)."""
+        ops, st, d = self.ops, self.st, self.dims
+        self._accumulate = accumulate
+        B, T, R, D = ctx["B"], ctx["T"], ctx["R"], d.d_model
+        L, R1 = T // 2, B * T
+        dy = self.act(R, D)
+        ops.cast_bf16(denc, out=dy[:R])
+        dres = self._ln_bwd("model.encoder.layer_norm", dy, ctx["x_final"], ctx["mu"], ctx["rs"], None, R)
+        for i in reversed(range(d.enc_layers)):
+            self._layer_bwd(f"model.encoder.layers.{i}", ctx["layers"][i], dres, B, L, 0, False, None)
+            ctx["layers"][i] = None
+        # conv stem: x0 = gelu(conv2(a1)) + pos ; a1 = gelu(conv1(mel))
+        dz2 = self.act(R, D)
+        ops.gelu_bwd(dres, ctx["z2"], out=dz2[:R])
+        gw2 = ops.empty((D, 3 * D), torch.float32)
+        ops.gemm(dz2, ctx["xcol2"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw2)
+        ops.unpack_conv_grad(gw2, st.g["model.encoder.conv2.weight"], accumulate)
+        ops.colsum(dz2[:R], st.g["model.encoder.conv2.bias"], accumulate=True)
+        dxcol2 = ops.gemm(dz2[:R], st.conv2_packed, trans_b=True)
+        dz1 = self.act(R1, D)
+        ops.col2im_s2_gelu_bwd(dxcol2, ctx["z1"], B, T, out=dz1[:R1])
+        gw1 = ops.empty((D, st.kpad1), torch.float32)
+        ops.gemm(dz1, ctx["xcol1"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw1)
+        ops.unpack_conv_grad(gw1, st.g["model.encoder.conv1.weight"], accumulate)
+        ops.colsum(dz1[:R1], st.g["model.encoder.conv1.bias"], accumulate=True)
+
+    def zero_small_grads(self):
+        """Bias / LayerNorm / embedding gradients are accumulated with atomics: zero the gradient buffer's trainable
+        range before a (non-accumulating) backward.  Weight-matrix gradients are overwritten by their GEMMs."""
+        st = self.st
+        if st.G is not None:
+            st.G[st.train_start:st.train_end].zero_()

@@ -49,6 +49,7 @@ _SIGS = {
     "dw_im2col_mel": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_im2col_s2": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_col2im_s2_gelu_bwd": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_gelu_bwd": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p], C.c_int),
     "dw_pack_conv_weight": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_unpack_conv_grad": ([C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_cast_f32_bf16": ([C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p], C.c_int),
@@ -56,7 +57,7 @@ _SIGS = {
     "dw_colsum_bf16": ([C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "dw_add": ([C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p], C.c_int),
     "dw_sumsq_f32": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p], C.c_int),
-    "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 8 + [C.c_int, C.c_void_p], C.c_int),
+    "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 2 + [C.c_double] * 5 + [C.c_int, C.c_void_p], C.c_int),
     "dw_selftest_tr16": ([C.c_void_p, C.c_void_p], C.c_int),
 }
 
@@ -93,6 +94,7 @@ class HipOps:
     """MI355X kernels behind the ops interface.  All tensors must live on the same cuda (HIP) device."""
 
     name = "hip"
+    lowp = torch.bfloat16  # dtype of GEMM/attention operands and saved activations
 
     def __init__(self, device="cuda:0"):
         if not torch.cuda.is_available():
@@ -137,7 +139,7 @@ class HipOps:
         return out
 
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
-             r_row_mod=0, round_res=True, out_dtype=torch.bfloat16, out=None, tile=0):
+             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0):
         """C = op(a) @ op(b) with the fused epilogue of dw_gemm_bf16.  a: [M,K] (or [K,M] if trans_a);
         b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1."""
         assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
@@ -152,7 +154,7 @@ class HipOps:
             N, Kb = b.shape
         assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
         if out is None:
-            out = self.empty((M, N), out_dtype)
+            out = self.empty((M, N), self.lowp if out_dtype is None else out_dtype)
         assert out.shape == (M, N) and out.stride(1) == 1
         g = DwGemm()
         g.a, g.b, g.c = a.data_ptr(), b.data_ptr(), out.data_ptr()
@@ -180,10 +182,11 @@ class HipOps:
         self._chk(self.lib.dw_gemm_bf16(C.byref(g), self._stream()), f"gemm m={M} n={N} k={K} ta={trans_a} tb={trans_b}")
         return (out, z) if want_z else out
 
-    def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True):
+    def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):
         rows, cols = x.shape
         assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
-        y = self.empty((rows, cols), torch.bfloat16)
+        y = self.empty((rows, cols), torch.bfloat16) if out is None else out
+        assert y.is_contiguous() and y.shape == (rows, cols) and y.dtype == torch.bfloat16
         mean = self.empty((rows,), torch.float32) if save_stats else None
         rstd = self.empty((rows,), torch.float32) if save_stats else None
         self._chk(self.lib.dw_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols,
@@ -202,10 +205,11 @@ class HipOps:
                                             _p(dgamma), _p(dbeta), rows, cols, self._stream()), "layernorm_bwd")
         return dres
 
-    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale):
+    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None):
         for t in (q, k, v):
             assert t.dtype == torch.bfloat16 and t.stride(1) == 1
-        o = self.empty((B * Lq, H * 64), torch.bfloat16)
+        o = self.empty((B * Lq, H * 64), torch.bfloat16) if out is None else out
+        assert o.dtype == torch.bfloat16 and o.stride(1) == 1 and o.shape == (B * Lq, H * 64)
         lse = self.empty((B, H, Lq), torch.float32)
         self._chk(self.lib.dw_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Lq, Lk, q.stride(0), k.stride(0),
                                        v.stride(0), o.stride(0), int(causal), float(scale), self._stream()), "attn_fwd")
@@ -260,25 +264,37 @@ class HipOps:
         assert dx.dtype == torch.float32 and dx.is_contiguous() and dtok.dtype == torch.float32
         self._chk(self.lib.dw_embed_bwd(_p(dx), _p(ids), _p(dtok), _p(dpos), B, T, D, self._stream()), "embed_bwd")
 
-    def im2col_mel(self, mel, kpad):
+    def im2col_mel(self, mel, kpad, out=None):
         B, Cc, T = mel.shape
         assert mel.dtype == torch.float32 and mel.is_contiguous()
-        out = self.empty((B * T, kpad), torch.bfloat16)
+        if out is None:
+            out = self.empty((B * T, kpad), torch.bfloat16)
+        assert out.is_contiguous() and out.shape == (B * T, kpad)
         self._chk(self.lib.dw_im2col_mel(_p(mel), _p(out), B, Cc, T, kpad, self._stream()), "im2col_mel")
         return out
 
-    def im2col_s2(self, a, B, T):
+    def im2col_s2(self, a, B, T, out=None):
         Cc = a.shape[1]
         assert a.dtype == torch.bfloat16 and a.is_contiguous() and a.shape[0] == B * T
-        out = self.empty((B * T // 2, 3 * Cc), torch.bfloat16)
+        if out is None:
+            out = self.empty((B * T // 2, 3 * Cc), torch.bfloat16)
+        assert out.is_contiguous() and out.shape == (B * T // 2, 3 * Cc)
         self._chk(self.lib.dw_im2col_s2(_p(a), _p(out), B, T, Cc, self._stream()), "im2col_s2")
         return out
 
-    def col2im_s2_gelu_bwd(self, dxcol, z, B, T):
+    def col2im_s2_gelu_bwd(self, dxcol, z, B, T, out=None):
         Cc = z.shape[1]
         assert dxcol.is_contiguous() and z.is_contiguous() and dxcol.dtype == torch.bfloat16
-        dz = self.empty((B * T, Cc), torch.bfloat16)
+        dz = self.empty((B * T, Cc), torch.bfloat16) if out is None else out
+        assert dz.is_contiguous() and dz.shape == (B * T, Cc)
         self._chk(self.lib.dw_col2im_s2_gelu_bwd(_p(dxcol), _p(z), _p(dz), B, T, Cc, self._stream()), "col2im")
+        return dz
+
+    def gelu_bwd(self, dy, z, out=None):
+        assert dy.is_contiguous() and z.is_contiguous() and z.dtype == torch.bfloat16 and dy.shape == z.shape
+        dz = self.empty(z.shape, torch.bfloat16) if out is None else out
+        assert dz.is_contiguous() and dz.shape == z.shape
+        self._chk(self.lib.dw_gelu_bwd(_p(dy), _dt(dy), _p(z), _p(dz), z.numel(), self._stream()), "gelu_bwd")
         return dz
 
     def pack_conv_weight(self, w, kpad, out=None):

@@ -123,6 +123,8 @@ int dw_im2col_mel(const float* mel, void* xcol, int B, int C, int T, int kpad, v
 int dw_im2col_s2(const void* a, void* xcol, int B, int T, int C, void* stream);
 /* col2im_s2 + GELU backward: dz[b][r][c] = gelu'(z[b][r][c]) * sum_{2t+k-1=r} dxcol[(b,t)][k*C+c]. */
 int dw_col2im_s2_gelu_bwd(const void* dxcol, const void* z, void* dz, int B, int T, int C, void* stream);
+/* dz = bf16(dy) * gelu'(z): backward of the GELU after conv2 (dy f32 or bf16, z/dz bf16, n %% 4 == 0). */
+int dw_gelu_bwd(const void* dy, int dy_dtype, const void* z, void* dz, int64_t n, void* stream);
 /* conv weight <-> GEMM weight layouts: w [D][C][3] f32 <-> wp [D][kpad] (bf16 pack / f32 grad unpack-accumulate). */
 int dw_pack_conv_weight(const float* w, void* wp_bf16, int D, int C, int kpad, void* stream);
 int dw_unpack_conv_grad(const float* gwp, float* gw, int D, int C, int kpad, int accumulate, void* stream);
@@ -141,7 +143,7 @@ int dw_add(const void* a, int a_dtype, const void* b, int b_dtype, void* y, int 
  * shadow copy used by the GEMMs is refreshed in the same pass (shadow may be NULL). */
 int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
 int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq,
-             float max_norm, float grad_mul, float lr, float beta1, float beta2, float eps, float weight_decay,
+             float max_norm, float grad_mul, double lr, double beta1, double beta2, double eps, double weight_decay,
              int step, void* stream);
 
 /* ---- self tests (diagnostics for bring-up; not on the hot path) --------------------------------------------------

@@ -15,15 +15,17 @@ import torch
 import torch.nn.functional as F
 
 
-def _bf(x):
-    return x.to(torch.bfloat16)
-
-
 class RefOps:
     name = "ref"
 
-    def __init__(self, device="cpu"):
+    def __init__(self, device="cpu", lowp=torch.bfloat16):
+        """lowp = torch.float32 turns every bf16 rounding into the identity: used to check the engine's hand-written
+        backward exactly against autograd."""
         self.device = torch.device(device)
+        self.lowp = lowp
+
+    def _bf(self, x):
+        return x.to(self.lowp)
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -54,15 +56,16 @@ class RefOps:
 
     # nn.Linear under bf16 autocast: bf16 operands, fp32 accumulation (TF:modeling_whisper.py:279-282 etc.)
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
-             r_row_mod=0, round_res=True, out_dtype=torch.bfloat16, out=None, tile=0):
+             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0):
+        out_dtype = self.lowp if out_dtype is None else out_dtype
         A = a.float().t() if trans_a else a.float()
         Bm = b.float() if trans_b else b.float().t()
         v = A @ Bm
         if bias is not None:
             v = v + bias
-        z = _bf(v) if want_z else None
+        z = self._bf(v) if want_z else None
         if act == 1:
-            v = F.gelu(_bf(v).float())
+            v = F.gelu(self._bf(v).float())
         if zgrad is not None:
             zz = zgrad.float()
             cdf = 0.5 * (1.0 + torch.erf(zz * 0.7071067811865476))
@@ -73,7 +76,7 @@ class RefOps:
             if r_row_mod > 0:
                 idx = torch.arange(v.shape[0], device=v.device) % r_row_mod
                 r = r[idx]
-            v = (_bf(v).float() if round_res else v) + r
+            v = (self._bf(v).float() if round_res else v) + r
         v = v.to(out_dtype)
         if out is not None:
             out.copy_(v)
@@ -81,13 +84,17 @@ class RefOps:
         return (v, z) if want_z else v
 
     # nn.LayerNorm in fp32 (autocast keeps layer_norm in fp32), output cast to bf16 by the consumer
-    def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True):
+    def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):
         xf = x.float()
         mu = xf.mean(-1)
         var = ((xf - mu[:, None]) ** 2).mean(-1)
         rstd = torch.rsqrt(var + eps)
         y = (xf - mu[:, None]) * rstd[:, None] * gamma + beta
-        return _bf(y), (mu if save_stats else None), (rstd if save_stats else None)
+        y = self._bf(y)
+        if out is not None:
+            out.copy_(y)
+            y = out
+        return y, (mu if save_stats else None), (rstd if save_stats else None)
 
     def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
         xf, d = x.float(), dy.float()
@@ -108,7 +115,7 @@ class RefOps:
     def _heads(t, B, L, H):
         return t.reshape(B, L, H, 64).permute(0, 2, 1, 3).float()
 
-    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale):
+    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None):
         qh, kh, vh = self._heads(q, B, Lq, H), self._heads(k, B, Lk, H), self._heads(v, B, Lk, H)
         s = (qh @ kh.transpose(-1, -2)) * scale
         if causal:
@@ -116,8 +123,11 @@ class RefOps:
             s = s.masked_fill(~mask, float("-inf"))
         lse = torch.logsumexp(s, -1)
         p = torch.exp(s - lse[..., None])
-        o = _bf(p).float() @ vh
-        o = _bf(o.permute(0, 2, 1, 3).reshape(B * Lq, H * 64))
+        o = self._bf(p).float() @ vh
+        o = self._bf(o.permute(0, 2, 1, 3).reshape(B * Lq, H * 64))
+        if out is not None:
+            out.copy_(o)
+            o = out
         return o, lse
 
     def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None):
@@ -129,14 +139,14 @@ class RefOps:
             s = s.masked_fill(~mask, float("-inf"))
         p = torch.exp(s - lse[..., None])
         delta = (oh * doh).sum(-1, keepdim=True)
-        dvh = _bf(p).float().transpose(-1, -2) @ doh
+        dvh = self._bf(p).float().transpose(-1, -2) @ doh
         dp = doh @ vh.transpose(-1, -2)
-        ds = _bf(p * (dp - delta)).float()
+        ds = self._bf(p * (dp - delta)).float()
         dqh = (ds @ kh) * scale
         dkh = (ds.transpose(-1, -2) @ qh) * scale
 
         def back(t, L):
-            return _bf(t.permute(0, 2, 1, 3).reshape(B * L, H * 64))
+            return self._bf(t.permute(0, 2, 1, 3).reshape(B * L, H * 64))
 
         rq, rk, rv = back(dqh, Lq), back(dkh, Lk), back(dvh, Lk)
         if dq is not None:
@@ -161,7 +171,7 @@ class RefOps:
         if want_grad:
             (g,) = torch.autograd.grad(total * grad_scale, zs)
             s_logits.zero_()
-            s_logits[:, :V] = g.to(torch.bfloat16)
+            s_logits[:, :V] = g.to(s_logits.dtype)
         n = (labels != -100).sum().float()
         return torch.stack([ce.detach(), kl.detach(), total.detach(), n]).float()
 
@@ -177,38 +187,62 @@ class RefOps:
             dpos[:T] += dx.reshape(B, T, -1).sum(0)
 
     # conv1d(k=3, pad=1) as im2col (TF:modeling_whisper.py:566-567)
-    def im2col_mel(self, mel, kpad):
+    def im2col_mel(self, mel, kpad, out=None):
         B, Cc, T = mel.shape
         xp = F.pad(mel, (1, 1))                                # [B, C, T+2]
         cols = torch.stack([xp[:, :, k:k + T] for k in range(3)], 1)  # [B, 3, C, T]
         cols = cols.permute(0, 3, 1, 2).reshape(B * T, 3 * Cc)
-        out = torch.zeros(B * T, kpad, dtype=torch.bfloat16, device=mel.device)
-        out[:, : 3 * Cc] = _bf(cols)
-        return out
+        res = torch.zeros(B * T, kpad, dtype=self.lowp, device=mel.device)
+        res[:, : 3 * Cc] = self._bf(cols)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
-    def im2col_s2(self, a, B, T):
+    def im2col_s2(self, a, B, T, out=None):
         Cc = a.shape[1]
         x = a.reshape(B, T, Cc)
         xp = F.pad(x, (0, 0, 1, 1))                             # [B, T+2, C]
         cols = torch.stack([xp[:, k:k + T:2] for k in range(3)], 2)   # [B, T/2, 3, C]
-        return cols.reshape(B * T // 2, 3 * Cc).contiguous()
+        res = cols.reshape(B * T // 2, 3 * Cc).contiguous()
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
-    def col2im_s2_gelu_bwd(self, dxcol, z, B, T):
+    @staticmethod
+    def _gelu_grad(zz):
+        cdf = 0.5 * (1.0 + torch.erf(zz * 0.7071067811865476))
+        pdf = 0.3989422804014327 * torch.exp(-0.5 * zz * zz)
+        return cdf + zz * pdf
+
+    def gelu_bwd(self, dy, z, out=None):
+        res = self._bf(self._bf(dy).float() * self._gelu_grad(z.float()))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def col2im_s2_gelu_bwd(self, dxcol, z, B, T, out=None):
         Cc = z.shape[1]
         d = dxcol.float().reshape(B, T // 2, 3, Cc)
         acc = torch.zeros(B, T + 2, Cc, dtype=torch.float32, device=z.device)
         for k in range(3):
             acc[:, k:k + T:2] += d[:, :, k]
-        da = _bf(acc[:, 1:T + 1].reshape(B * T, Cc)).float()
+        da = self._bf(acc[:, 1:T + 1].reshape(B * T, Cc)).float()
         zz = z.float()
         cdf = 0.5 * (1.0 + torch.erf(zz * 0.7071067811865476))
         pdf = 0.3989422804014327 * torch.exp(-0.5 * zz * zz)
-        return _bf(da * (cdf + zz * pdf))
+        res = self._bf(da * (cdf + zz * pdf))
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def pack_conv_weight(self, w, kpad, out=None):
         D, Cc, _ = w.shape
-        wp = torch.zeros(D, kpad, dtype=torch.bfloat16, device=w.device)
-        wp[:, : 3 * Cc] = _bf(w.permute(0, 2, 1).reshape(D, 3 * Cc))
+        wp = torch.zeros(D, kpad, dtype=self.lowp, device=w.device)
+        wp[:, : 3 * Cc] = self._bf(w.permute(0, 2, 1).reshape(D, 3 * Cc))
         if out is not None:
             out.copy_(wp)
             return out
@@ -226,7 +260,7 @@ class RefOps:
         if out is not None:
             out.copy_(x)
             return out
-        return _bf(x)
+        return self._bf(x)
 
     def cast_f32(self, x, out=None):
         if out is not None:
