@@ -1,0 +1,248 @@
+"""Contract benchmark: training audio-seconds/s of the Whisper distillation step on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference hot loop (run_distillation.py:1465-1495, 1606-1614) on one batch of synthetic audio that is
+already resident in HBM: log-mel front end + teacher forward + student forward/backward + gradient all-reduce (RCCL,
+N > 1) + global-norm clip + AdamW.  Workload = BASELINE.json configs[2]/[3]: whisper-large-v3-shaped teacher (32/32)
+-> distil-large-v3-shaped student (32 encoder / 2 decoder layers), per-GPU batch 32 x 30 s clips, nothing frozen
+("full" mode; `--mode recipe` = the README recipe with --freeze_encoder and a shared encoder).  Weights are seeded
+random (no checkpoints exist offline), data is synthetic.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel class (the bf16 MFMA GEMM): its launches are
+bracketed by HIP events on the launch stream during one extra instrumented step after the timed region.
+`cpu_baseline` times the CPU oracle (a port of the reference path, oracle/whisper_oracle.py) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
+
+
+def step_flops(d, mode):
+    """Algorithmic FLOPs per 30 s sample (2 x MAC, causal attention counted full, no recompute): SURVEY.md section 8(d)."""
+    S, T = 1500, 447
+    D, V, M = d.d_model, d.vocab, d.n_mels
+
+    def enc(le):
+        return 6 * M * D * 3000 + 6 * D * D * 1500 + le * (24 * S * D * D + 4 * S * S * D)
+
+    def dec(ld):
+        return ld * (28 * T * D * D + 4 * S * D * D + 4 * T * T * D + 4 * T * S * D)
+
+    head = 2 * T * D * V
+    return enc, dec, head
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of 30 s clips")
+    ap.add_argument("--model", default="large-v3", choices=["tiny.en", "small.en", "large-v3"])
+    ap.add_argument("--mode", default="full", choices=["full", "recipe"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        le0, ld0 = {"tiny.en": (4, 1), "small.en": (12, 4), "large-v3": (32, 2)}[args.model]
+        print(json.dumps(cpu_baseline_leg(args.model, le0, ld0, args.mode == "recipe")), flush=True)
+        return
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    dev = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+
+    from distil_whisper_amd.ops_hip import HipOps          # raises if the HIP library or the GPU is missing
+    from distil_whisper_amd.distill import DistillationTrainer
+    from distil_whisper_amd import student_init as si
+
+    ops = HipOps(dev)
+    tdims = si.PRESETS[args.model]
+    le, ld = si.STUDENT_LAYERS[args.model]
+    t_sd = si.random_state_dict(tdims, seed=0, device=dev)
+    s_sd, sdims = si.student_from_teacher(t_sd, tdims, le, ld)
+    filt = torch.tensor(si.mel_filter_bank(tdims.n_mels), dtype=torch.float32, device=dev).contiguous()
+    recipe = args.mode == "recipe"
+    tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
+                             weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
+                             mel_filters=filt)
+    del t_sd, s_sd
+    torch.cuda.empty_cache()
+
+    B, T = args.batch, 447
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    audio = 0.1 * torch.randn(B, 480000, generator=g, device=dev)
+    ids = torch.randint(0, 50257, (B, T + 1), generator=g, device=dev)
+    ids[:, 0] = tdims.decoder_start_token_id
+    lens = torch.randint(32, 225, (B,), generator=g, device=dev)
+    dec_in = ids[:, :-1].contiguous()
+    labels = ids[:, 1:].clone()
+    labels[torch.arange(T, device=dev)[None, :] >= lens[:, None]] = -100
+
+    def one_step():
+        feats = tr.features(audio)
+        return tr.train_step(feats, dec_in, labels)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"engine ready: {args.model} {args.mode} B={B} world={world}; warm-up x{args.warmup}")
+    for i in range(args.warmup):
+        losses = one_step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log(f"first step done, loss={float(losses[2].item()):.4f}, "
+                f"mem={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    sync()
+    log(f"timing {args.steps} steps")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    ms_per_step = dt / args.steps * 1e3
+    log(f"{ms_per_step:.1f} ms/step")
+    value = world * B * 30.0 * args.steps / dt
+    loss_val = float(losses[2].item())
+
+    enc, dec, head = step_flops(tdims, args.mode)
+    if recipe:
+        fl = enc(tdims.enc_layers) + (dec(tdims.dec_layers) + head) + 3 * (dec(ld) + head)
+    else:
+        fl = (enc(tdims.enc_layers) + dec(tdims.dec_layers) + head) + 3 * (enc(le) + dec(ld) + head)
+    step_tflops = value / 30.0 * fl / 1e12 / world
+
+    roofline = None
+    if not args.no_roofline:
+        ops.profile = {}
+        one_step()
+        torch.cuda.synchronize()
+        prof = ops.collect_profile()
+        ops.profile = None
+        log("per-kernel-class ms (instrumented step): " + json.dumps(
+            {k: {"n": v["n"], "ms": round(v["ms"], 2), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
+             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}))
+        if prof:
+            key = max(prof, key=lambda k: prof[k]["ms"])
+            p = prof[key]
+            roofline = {"bound": "mfma", "kernel": key, "launches": p["n"],
+                        "avg_launch_ms": p["ms"] / p["n"], "flops_per_launch": p["flops"] / p["n"],
+                        "achieved": p["flops"] / (p["ms"] * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                        "all_gemm_ms": sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")),
+                        "all_gemm_tflops": sum(v["flops"] for k, v in prof.items() if k.startswith("gemm")) /
+                        max(sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9,
+                        "attn_ms": sum(v["ms"] for k, v in prof.items() if k.startswith("attn")),
+                        "step_ms_instrumented": sum(v["ms"] for v in prof.values())}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline leg (subprocess, bounded to 300 s) ...")
+        cpu_baseline = run_cpu_baseline(args.model, args.mode)
+
+    if rank == 0:
+        out = {"metric": "training audio-seconds/s (distil-large-v3 student, 30 s clips)" if args.model == "large-v3"
+               else f"training audio-seconds/s ({args.model} student, 30 s clips)",
+               "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"whisper-{args.model} teacher ({tdims.enc_layers}/{tdims.dec_layers}) -> "
+                                      f"{le}/{ld} student KD step, mode={args.mode}",
+                          "global_batch": B * world, "per_gpu_batch": B, "clip_seconds": 30, "decoder_len": T,
+                          "parallelism": f"dp{world}", "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
+                          "bwd+allreduce+clip+adamw", "loss": loss_val},
+               "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
+               "flops_per_sample": fl, "roofline": roofline, "cpu_baseline": cpu_baseline}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Cores this process may actually use (affinity mask and cgroup quota), not the host's total."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def run_cpu_baseline(model, mode, limit_s=300):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", model, "--mode", mode]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "audio-s/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"failed: {r.stderr[-300:]}"}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "audio-s/s", "cores": usable_cores(), "kind": "port",
+                "sample": f"1 step, batch 1 x 30 s, {model} dims did not finish within {limit_s} s"}
+
+
+def cpu_baseline_leg(model, le, ld, recipe):
+    """The CPU oracle (port of the reference train_step + clip + AdamW, fp32) on a bounded sample: ONE step at
+    batch 1 of the same model configuration on the host cores of this box."""
+    from oracle import whisper_oracle as wo
+    cfg_t = wo.CONFIGS[model]
+    ncores = usable_cores()
+    torch.set_num_threads(ncores)
+    t_sd = wo.init_state_dict(cfg_t, 0)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, le, ld)
+    b = wo.synthetic_batch(cfg_t, 1, seed=1234, with_audio=False)
+    feats = torch.randn(1, cfg_t.n_mels, 3000) * 0.5
+    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
+    params = {}
+    for k, v in s_sd.items():
+        rg = k != "model.encoder.embed_positions.weight" and not (recipe and k.startswith("model.encoder."))
+        params[k] = v.requires_grad_(rg)
+    t0 = time.perf_counter()
+    loss, *_ = wo.train_step(params, cfg_s, t_sd, cfg_t, batch, 2.0, 1.0, recipe)
+    loss.backward()
+    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+    with torch.no_grad():
+        wo.clip_and_adamw({k: p.detach() for k, p in params.items()}, grads, {}, step=1)
+    dt = time.perf_counter() - t0
+    return {"value": 30.0 / dt, "unit": "audio-s/s", "cores": ncores, "kind": "port",
+            "sample": f"1 step, batch 1 x 30 s, {model} dims, fp32 torch CPU ({dt:.1f} s; log-mel excluded)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -373,6 +373,7 @@ static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
 extern "C" int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
                            int Lk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int causal, float scale,
                            void* stream) {
+    DW_CLEAR_ERR();
     if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
     if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || (ldo & 3)) return DW_EINVAL;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7)) return DW_EINVAL;
@@ -392,6 +393,7 @@ extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const vo
                            const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
                            int64_t lddk, int64_t lddv, int causal, float scale, void* stream) {
+    DW_CLEAR_ERR();
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return DW_EINVAL;
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
     if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || check_ld(ldo) || check_ld(lddo)) return DW_EINVAL;

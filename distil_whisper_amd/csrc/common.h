@@ -141,6 +141,9 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
+// hipGetLastError() reports the last error of ANY earlier HIP call on this thread (including benign probes made by
+// the host framework), so every launcher first clears it and then checks its own launches.
+#define DW_CLEAR_ERR() (void)hipGetLastError()
 #define DW_CHECK_LAUNCH()                                  \
     do {                                                   \
         hipError_t e__ = hipGetLastError();                \

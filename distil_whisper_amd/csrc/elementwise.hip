@@ -275,10 +275,12 @@ __global__ void selftest_tr16_kernel(int32_t* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int dw_version(void) { return 100; }
+extern "C" int dw_version(void) {
+    DW_CLEAR_ERR(); return 100; }
 
 extern "C" int dw_embed_fwd(const int64_t* ids, const void* tok, const void* pos, int tab_dtype, void* out,
                             int out_dtype, int B, int T, int D, void* stream) {
+    DW_CLEAR_ERR();
     if (!ids || !tok || !pos || !out || B <= 0 || T <= 0 || D <= 0 || (D & 3)) return DW_EINVAL;
     const long nvec = (long)B * T * (D >> 2);
     dim3 grid((nvec + 255) / 256), block(256);
@@ -297,6 +299,7 @@ extern "C" int dw_embed_fwd(const int64_t* ids, const void* tok, const void* pos
 
 extern "C" int dw_embed_bwd(const float* dx, const int64_t* ids, float* dtok, float* dpos, int B, int T, int D,
                             void* stream) {
+    DW_CLEAR_ERR();
     if (!dx || !ids || !dtok || B <= 0 || T <= 0 || D <= 0) return DW_EINVAL;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(T, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, ids, dtok,
                        dpos, B, T, D);
@@ -305,6 +308,7 @@ extern "C" int dw_embed_bwd(const float* dx, const int64_t* ids, float* dtok, fl
 }
 
 extern "C" int dw_im2col_mel(const float* mel, void* xcol, int B, int C, int T, int kpad, void* stream) {
+    DW_CLEAR_ERR();
     if (!mel || !xcol || B <= 0 || C <= 0 || T <= 0 || kpad < 3 * C || (kpad & 63)) return DW_EINVAL;
     hipLaunchKernelGGL(im2col_mel_kernel, dim3((T + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, mel, (bf16*)xcol,
                        C, T, kpad);
@@ -313,6 +317,7 @@ extern "C" int dw_im2col_mel(const float* mel, void* xcol, int B, int C, int T, 
 }
 
 extern "C" int dw_im2col_s2(const void* a, void* xcol, int B, int T, int C, void* stream) {
+    DW_CLEAR_ERR();
     if (!a || !xcol || B <= 0 || T <= 0 || (T & 1) || C <= 0 || (C & 7)) return DW_EINVAL;
     const long nvec = (long)B * (T / 2) * ((3 * C) >> 3);
     hipLaunchKernelGGL(im2col_s2_kernel, dim3((nvec + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)a,
@@ -322,6 +327,7 @@ extern "C" int dw_im2col_s2(const void* a, void* xcol, int B, int T, int C, void
 }
 
 extern "C" int dw_col2im_s2_gelu_bwd(const void* dxcol, const void* z, void* dz, int B, int T, int C, void* stream) {
+    DW_CLEAR_ERR();
     if (!dxcol || !z || !dz || B <= 0 || T <= 0 || (T & 1) || C <= 0 || (C & 7)) return DW_EINVAL;
     const long nvec = (long)B * T * (C >> 3);
     hipLaunchKernelGGL(col2im_s2_gelu_bwd_kernel, dim3((nvec + 255) / 256), dim3(256), 0, (hipStream_t)stream,
@@ -331,6 +337,7 @@ extern "C" int dw_col2im_s2_gelu_bwd(const void* dxcol, const void* z, void* dz,
 }
 
 extern "C" int dw_gelu_bwd(const void* dy, int dy_dtype, const void* z, void* dz, int64_t n, void* stream) {
+    DW_CLEAR_ERR();
     if (!dy || !z || !dz || n <= 0 || (n & 3)) return DW_EINVAL;
     dim3 grid((n / 4 + 255) / 256), block(256);
     if (dy_dtype == DW_BF16)
@@ -344,6 +351,7 @@ extern "C" int dw_gelu_bwd(const void* dy, int dy_dtype, const void* z, void* dz
 }
 
 extern "C" int dw_pack_conv_weight(const float* w, void* wp, int D, int C, int kpad, void* stream) {
+    DW_CLEAR_ERR();
     if (!w || !wp || D <= 0 || C <= 0 || kpad < 3 * C) return DW_EINVAL;
     const long n = (long)D * kpad;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, (bf16*)wp,
@@ -353,6 +361,7 @@ extern "C" int dw_pack_conv_weight(const float* w, void* wp, int D, int C, int k
 }
 
 extern "C" int dw_unpack_conv_grad(const float* gwp, float* gw, int D, int C, int kpad, int accumulate, void* stream) {
+    DW_CLEAR_ERR();
     if (!gwp || !gw || D <= 0 || C <= 0 || kpad < 3 * C) return DW_EINVAL;
     const long n = (long)D * C * 3;
     hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gwp, gw, D, C,
@@ -362,6 +371,7 @@ extern "C" int dw_unpack_conv_grad(const float* gwp, float* gw, int D, int C, in
 }
 
 extern "C" int dw_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+    DW_CLEAR_ERR();
     if (!x || !y || n <= 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return DW_EINVAL;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(((n + 3) / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x,
                        (bf16*)y, (long)n);
@@ -369,6 +379,7 @@ extern "C" int dw_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream
     return DW_OK;
 }
 extern "C" int dw_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream) {
+    DW_CLEAR_ERR();
     if (!x || !y || n <= 0 || ((uintptr_t)x & 7) || ((uintptr_t)y & 15)) return DW_EINVAL;
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(((n + 3) / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)x, y, (long)n);
@@ -378,6 +389,7 @@ extern "C" int dw_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream
 
 extern "C" int dw_colsum_bf16(const void* x, int64_t ld, int rows, int cols, float* out, int accumulate,
                               void* stream) {
+    DW_CLEAR_ERR();
     if (!x || !out || rows <= 0 || cols <= 0 || (cols & 7) || (ld & 7) || ((uintptr_t)x & 15)) return DW_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) hipLaunchKernelGGL(zero_f32_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, out, cols);
@@ -391,6 +403,7 @@ extern "C" int dw_colsum_bf16(const void* x, int64_t ld, int rows, int cols, flo
 
 extern "C" int dw_add(const void* a, int a_dtype, const void* b, int b_dtype, void* y, int y_dtype, int64_t n,
                       void* stream) {
+    DW_CLEAR_ERR();
     if (!a || !b || !y || n <= 0) return DW_EINVAL;
     long nb = (n + 255) / 256;
     if (nb > 4096) nb = 4096;
@@ -401,6 +414,7 @@ extern "C" int dw_add(const void* a, int a_dtype, const void* b, int b_dtype, vo
 }
 
 extern "C" int dw_selftest_tr16(int32_t* out, void* stream) {
+    DW_CLEAR_ERR();
     if (!out) return DW_EINVAL;
     hipLaunchKernelGGL(selftest_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
     DW_CHECK_LAUNCH();

@@ -241,6 +241,7 @@ static int launch_tile(const GemmP& p0, int ta, int tb, hipStream_t s) {
 }
 
 extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
+    DW_CLEAR_ERR();
     if (!g || !g->a || !g->b || !g->c) return DW_EINVAL;
     if (g->m <= 0 || g->n <= 0 || g->k <= 0 || (g->k & 63)) return DW_EINVAL;
     if ((g->lda & 7) || (g->ldb & 7)) return DW_EINVAL;

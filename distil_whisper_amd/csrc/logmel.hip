@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void logmel_norm_kernel(float* out, const floa
 
 extern "C" int dw_logmel(const float* audio, int batch, int n_samples, const float* mel_filters, int n_mels,
                          const float* twiddle, const float* window, float* out, float* clipmax, void* stream) {
+    DW_CLEAR_ERR();
     if (!audio || !mel_filters || !twiddle || !window || !out || !clipmax) return DW_EINVAL;
     if (batch <= 0 || n_samples < 400 || (n_samples % 160) || n_mels <= 0 || n_mels > 256) return DW_EINVAL;
     const int n_frames = n_samples / 160;

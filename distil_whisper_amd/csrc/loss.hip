@@ -138,6 +138,7 @@ extern "C" int dw_distill_loss(const void* s_logits, const void* t_logits, const
                                int64_t ld, float temperature, float ce_weight, float kl_weight, float grad_scale,
                                float* losses, void* dlogits, float* row_ce, float* row_kl, int32_t* counts,
                                void* stream) {
+    DW_CLEAR_ERR();
     if (!s_logits || !t_logits || !labels || !losses || !row_ce || !row_kl || !counts) return DW_EINVAL;
     if (rows <= 0 || V <= 0 || ld < V || (ld & 7) || temperature <= 0.f) return DW_EINVAL;
     if (((uintptr_t)s_logits & 15) || ((uintptr_t)t_logits & 15) || ((uintptr_t)dlogits & 15)) return DW_EINVAL;

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void*
 
 extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
                                 float* mean, float* rstd, int rows, int cols, float eps, void* stream) {
+    DW_CLEAR_ERR();
     if (!x || !gamma || !beta || !y || rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
     if ((mean == nullptr) != (rstd == nullptr)) return DW_EINVAL;
     dim3 grid((rows + 3) / 4), block(256);
@@ -172,6 +173,7 @@ extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
 extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
                                 const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, int rows,
                                 int cols, void* stream) {
+    DW_CLEAR_ERR();
     if (!dy || !x || !mean || !rstd || !gamma || !dres || !dgamma || !dbeta) return DW_EINVAL;
     if (rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
     int nb = (rows + 3) / 4;

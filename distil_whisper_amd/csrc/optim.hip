@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 }
 
 extern "C" int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
+    DW_CLEAR_ERR();
     if (!g || !out || n <= 0 || ((uintptr_t)g & 15)) return DW_EINVAL;
     long nb = (n / 4 + 255) / 256;
     if (nb > 2048) nb = 2048;
@@ -79,6 +80,7 @@ extern "C" int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream)
 extern "C" int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, const float* sumsq,
                         float max_norm, float grad_mul, double lr, double beta1, double beta2, double eps,
                         double weight_decay, int step, void* stream) {
+    DW_CLEAR_ERR();
     if (!p || !g || !m || !v || n <= 0 || step < 1) return DW_EINVAL;
     if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) ||
         ((uintptr_t)shadow & 7))

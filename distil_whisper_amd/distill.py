@@ -112,6 +112,8 @@ class DistillationTrainer:
         """One micro-batch: returns losses fp32[4] = (ce, kl, loss, n_valid) on the device (no host sync)."""
         ops, S, T = self.ops, self.student, self.teacher
         B, Td = decoder_input_ids.shape
+        input_features = input_features.to(torch.float32).contiguous()
+        decoder_input_ids = decoder_input_ids.contiguous()
         labels_flat = labels.reshape(-1).contiguous()
         enc_s, ectx = S.encode(input_features, save=not self.freeze_encoder)
         logits_s, dctx = S.decode(decoder_input_ids, enc_s, save=True)

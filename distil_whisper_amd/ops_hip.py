@@ -105,6 +105,8 @@ class HipOps:
         ang = 2.0 * math.pi * i / 400.0
         self._twiddle = torch.stack([torch.cos(ang), torch.sin(ang)], 1).to(torch.float32).contiguous().to(self.device)
         self._window = torch.hann_window(400, periodic=True, dtype=torch.float64).to(torch.float32).to(self.device)
+        self.profile = None       # set to {} to bracket every launch with HIP events on the launch stream
+        self._prof_events = []
 
     # ------------------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -114,6 +116,39 @@ class HipOps:
     def _chk(rc, what):
         if rc != 0:
             raise RuntimeError(f"libdwamd: {what} failed with code {rc}")
+
+    # ---- optional per-launch timing (bench.py roofline leg): HIP events on the stream the kernels are launched on --
+    def _t0(self):
+        if self.profile is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
+
+    def _t1(self, e0, key, flops=0.0, nbytes=0.0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream(self.device))
+        self._prof_events.append((key, flops, nbytes, e0, e1))
+
+    def collect_profile(self):
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for key, flops, nbytes, e0, e1 in self._prof_events:
+            d = out.setdefault(key, {"n": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["n"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        self._prof_events = []
+        return out
+
+    @staticmethod
+    def pick_tile(M, N):
+        """256x256 block tiles once there are at least two full rounds of them over the 256 CUs, else 128x128."""
+        t256 = ((M + 255) // 256) * ((N + 255) // 256)
+        return 256 if t256 >= 512 else 128
 
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
@@ -163,7 +198,7 @@ class HipOps:
         g.trans_a, g.trans_b = int(trans_a), int(trans_b)
         g.act = int(act)
         g.c_dtype = _dt(out)
-        g.tile = int(tile)
+        g.tile = int(tile) if tile else self.pick_tile(M, N)
         z = None
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
@@ -179,7 +214,9 @@ class HipOps:
             g.r, g.ldr, g.r_dtype = residual.data_ptr(), residual.stride(0), _dt(residual)
             g.r_row_mod = int(r_row_mod)
             g.round_res = int(bool(round_res))
+        e0 = self._t0()
         self._chk(self.lib.dw_gemm_bf16(C.byref(g), self._stream()), f"gemm m={M} n={N} k={K} ta={trans_a} tb={trans_b}")
+        self._t1(e0, f"gemm_t{g.tile}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}", 2.0 * M * N * K)
         return (out, z) if want_z else out
 
     def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):
@@ -211,8 +248,10 @@ class HipOps:
         o = self.empty((B * Lq, H * 64), torch.bfloat16) if out is None else out
         assert o.dtype == torch.bfloat16 and o.stride(1) == 1 and o.shape == (B * Lq, H * 64)
         lse = self.empty((B, H, Lq), torch.float32)
+        e0 = self._t0()
         self._chk(self.lib.dw_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Lq, Lk, q.stride(0), k.stride(0),
                                        v.stride(0), o.stride(0), int(causal), float(scale), self._stream()), "attn_fwd")
+        self._t1(e0, "attn_fwd", 4.0 * B * H * Lq * Lk * 64)
         return o, lse
 
     def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None):
@@ -225,10 +264,12 @@ class HipOps:
         delta = self.empty((B, H, Lq), torch.float32)
         for t in (q, k, v, o, do, dq, dk, dv):
             assert t.dtype == torch.bfloat16 and t.stride(1) == 1
+        e0 = self._t0()
         self._chk(self.lib.dw_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv),
                                        B, H, Lq, Lk, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
                                        dq.stride(0), dk.stride(0), dv.stride(0), int(causal), float(scale),
                                        self._stream()), "attn_bwd")
+        self._t1(e0, "attn_bwd", 10.0 * B * H * Lq * Lk * 64)
         return dq, dk, dv
 
     def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad):
@@ -348,3 +389,23 @@ class HipOps:
         self._chk(self.lib.dw_adamw(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(sumsq), float(max_norm),
                                     float(grad_mul), float(lr), float(beta1), float(beta2), float(eps),
                                     float(weight_decay), int(step), self._stream()), "adamw")
+
+
+def _timed(key):
+    def deco(fn):
+        def wrapper(self, *a, **k):
+            e0 = self._t0()
+            r = fn(self, *a, **k)
+            self._t1(e0, key)
+            return r
+        wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+        return wrapper
+    return deco
+
+
+for _name, _key in (("layernorm_fwd", "ln_fwd"), ("layernorm_bwd", "ln_bwd"), ("distill_loss", "loss"),
+                    ("logmel", "logmel"), ("adamw", "adamw"), ("cast_bf16", "cast"), ("colsum", "colsum"),
+                    ("sumsq", "sumsq"), ("embed_fwd", "embed"), ("embed_bwd", "embed"), ("im2col_mel", "conv_aux"),
+                    ("im2col_s2", "conv_aux"), ("col2im_s2_gelu_bwd", "conv_aux"), ("gelu_bwd", "conv_aux"),
+                    ("pack_conv_weight", "conv_aux"), ("unpack_conv_grad", "conv_aux")):
+    setattr(HipOps, _name, _timed(_key)(getattr(HipOps, _name)))

@@ -319,7 +319,7 @@ def logmel(audio: np.ndarray, n_mels: int) -> np.ndarray:
     log_spec = np.log10(np.maximum(mel, 1e-10)).transpose(0, 2, 1)
     mx = log_spec.max(axis=(1, 2), keepdims=True)
     log_spec = np.maximum(log_spec, mx - 8.0)
-    return ((log_spec + 4.0) / 4.0).astype(np.float32)
+    return np.ascontiguousarray(((log_spec + 4.0) / 4.0).astype(np.float32))
 
 
 # ---- synthetic workload of BASELINE.md section 3 / SURVEY.md section 8(d) -----------------------------------------------
