@@ -46,5 +46,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# NOTE for callers that dlopen the result: import torch BEFORE loading libdwamd.so.  torch bundles its own copy of
+# libamdhip64; loading this library first would pull a second HIP runtime into the process and every launch would
+# fail with hipErrorNoDevice (100).  ops_hip.load_library() does this in the right order.
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
