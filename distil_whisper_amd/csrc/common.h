@@ -42,6 +42,24 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// Fast erf (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7: far below the bf16 rounding applied to every GELU output)
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    y = 1.0f - y * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
 // ---- LDS tile swizzle for [rows][64 bf16] (=128-byte rows) tiles ------------------------------------------------
 // 16-byte slot s (0..7) of row r is stored at physical slot s ^ swz7(r).  The permutation of row bits
 // (bit1->bit2, bit3->bit1, bit2->bit0) makes BOTH access patterns conflict free on gfx950:

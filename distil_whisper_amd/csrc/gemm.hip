@@ -28,7 +28,9 @@ struct GemmP {
     long lda, ldb, ldc, ldz, ldzg, ldr;
     int m, n, k;
     int act, c_dtype, r_dtype, r_row_mod, round_res;
-    int tiles_n, nwg;
+    int tiles_n, nwg;      // output tiles
+    int split_k, atomic;   // K slices per tile (grid = nwg * split_k); atomic: C (f32) += v with atomics
+    int vec;               // all epilogue pointers / leading dimensions allow 4-wide vector access
 };
 
 // transposed (k-major) tile [64][BX]: fragment X^T[i = x + ...][k-slots] for one 16-deep k step
@@ -70,11 +72,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
     // XCD-aware bijective remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous tile range.
     int id;
     {
+        const int total = p.nwg * p.split_k;
         const int bid = blockIdx.x;
         const int xcd = bid & 7, local = bid >> 3;
-        const int q = p.nwg >> 3, r = p.nwg & 7;
+        const int q = total >> 3, r = total & 7;
         id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
+    const int ks = id / p.nwg;          // K slice (slice-major: neighbouring blocks share operand panels in L2)
+    id -= ks * p.nwg;
     const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -141,7 +146,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nt = p.k >> 6;
+    int nt = p.k >> 6;
+    {
+        const int base = nt / p.split_k, rem = nt - base * p.split_k;
+        const int first = ks * base + (ks < rem ? ks : rem);
+        nt = base + (ks < rem ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < CA; ++i) srcA[i] += (long)first * stepA;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) srcB[i] += (long)first * stepB;
+    }
 
     auto stage = [&](int buf) {
         char* tA = smem + buf * STAGE;
@@ -183,45 +197,133 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                 constexpr int i = decltype(ic)::value;
                 static_for<0, FN>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 });
             });
         }
     }
 
-    // ---- epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    // (compile-time indices only: a runtime-indexed accumulator array would be demoted to scratch memory)
+    // ---- epilogue ----
+    // The MFMAs were issued as (B-fragment, A-fragment), so each 32x32 accumulator holds the TRANSPOSED output tile:
+    // lane&31 = output row, register r = output column (r&3) + 8*(r>>2) + 4*(lane>>5).  Every wave turns its
+    // accumulators into row-major order through a private LDS patch (32 rows x TN fp32, padded stride: conflict-free
+    // b128 writes), then walks it 4 rows x TN columns per instruction: every global access of the epilogue (C and Z
+    // stores, residual and GELU' loads, atomics) is 4-wide per lane and contiguous along the row across 16 lanes.
+    // (compile-time accumulator indices only: a runtime-indexed accumulator array would be demoted to scratch)
+    constexpr int PLD = TN + 4;                    // patch row stride in floats (TN = 64 -> 68: 8 rows x 4 banks)
+    constexpr int LPR = TN / 4;                    // lanes per row in the row-major walk
+    constexpr int RPI = 64 / LPR;                  // rows per instruction
+    __syncthreads();                               // every wave is done reading the operand tiles
+    float* patch = (float*)smem + wave * (32 * PLD);
     const int hi = lane >> 5, ln = lane & 31;
     const bool plain = !p.bias && !p.z_out && p.act == 0 && !p.zgrad && !p.r;
+    const int pr = lane / LPR, pc = (lane % LPR) * 4;
+    const int n = n0 + wn0 + pc;
+    const bool n_in = n < p.n;
+    const bool full = p.vec && n + 3 < p.n;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n_in) {
+        if (full) b4 = *(const f32x4*)(p.bias + n);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < p.n) b4[e] = p.bias[n + e];
+        }
+    }
     static_for<0, FM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         static_for<0, FN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            const int n = n0 + wn0 + j * 32 + ln;
-            const bool n_ok = n < p.n;
-            const float bv = (p.bias && n_ok) ? p.bias[n] : 0.f;
-            static_for<0, 16>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (n_ok && m < p.m) {
-                    float v = acc[i][j][r];
-                    if (!plain) {
-                        v += bv;
-                        if (p.z_out) p.z_out[(long)m * p.ldz + n] = f2bf(v);
-                        if (p.act == 1) v = gelu_f(round_bf16(v));
-                        if (p.zgrad) v *= gelu_grad_f(bf2f(p.zgrad[(long)m * p.ldzg + n]));
-                        if (p.r) {
-                            const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
-                            const float rv = p.r_dtype == DW_F32 ? ((const float*)p.r)[(long)rr * p.ldr + n]
-                                                                 : bf2f(((const bf16*)p.r)[(long)rr * p.ldr + n]);
-                            v = (p.round_res ? round_bf16(v) : v) + rv;
-                        }
-                    }
-                    if (p.c_dtype == DW_F32) ((float*)p.c)[(long)m * p.ldc + n] = v;
-                    else ((bf16*)p.c)[(long)m * p.ldc + n] = f2bf(v);
-                }
+            static_for<0, 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                f32x4 v4;
+                v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1];
+                v4[2] = acc[i][j][g * 4 + 2]; v4[3] = acc[i][j][g * 4 + 3];
+                *(f32x4*)(patch + ln * PLD + j * 32 + g * 8 + hi * 4) = v4;
             });
         });
+        // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads below)
+#pragma unroll 2
+        for (int it = 0; it < 32 / RPI; ++it) {
+            const int rl = it * RPI + pr;
+            const int m = m0 + wm0 + i * 32 + rl;
+            const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
+            if (m >= p.m || !n_in) continue;
+            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+            if (p.atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.n) atomicAdd((float*)p.c + (long)m * p.ldc + n + e, v[e]);
+                continue;
+            }
+            const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
+            if (full) {
+                if (!plain) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                    if (p.z_out) {
+                        bf16x4 z4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
+                        *(bf16x4*)(p.z_out + (long)m * p.ldz + n) = z4;
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(round_bf16(v[e]));
+                    }
+                    if (p.zgrad) {
+                        const bf16x4 z4 = *(const bf16x4*)(p.zgrad + (long)m * p.ldzg + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(bf2f(z4[e]));
+                    }
+                    if (p.r) {
+                        float rv[4];
+                        if (p.r_dtype == DW_F32) {
+                            const f32x4 r4 = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rv[e] = r4[e];
+                        } else {
+                            const bf16x4 r4 = *(const bf16x4*)((const bf16*)p.r + (long)rr * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rv[e] = bf2f(r4[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
+                    }
+                }
+                if (p.c_dtype == DW_F32) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[e];
+                    *(f32x4*)((float*)p.c + (long)m * p.ldc + n) = o;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                    *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
+                }
+            } else {
+                // ragged / unaligned columns: scalar path
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int nn = n + e;
+                    if (nn >= p.n) continue;
+                    float x = v[e];
+                    if (!plain) {
+                        x += b4[e];
+                        if (p.z_out) p.z_out[(long)m * p.ldz + nn] = f2bf(x);
+                        if (p.act == 1) x = gelu_fast(round_bf16(x));
+                        if (p.zgrad) x *= gelu_grad_fast(bf2f(p.zgrad[(long)m * p.ldzg + nn]));
+                        if (p.r) {
+                            const float rv = p.r_dtype == DW_F32 ? ((const float*)p.r)[(long)rr * p.ldr + nn]
+                                                                 : bf2f(((const bf16*)p.r)[(long)rr * p.ldr + nn]);
+                            x = (p.round_res ? round_bf16(x) : x) + rv;
+                        }
+                    }
+                    if (p.c_dtype == DW_F32) ((float*)p.c)[(long)m * p.ldc + nn] = x;
+                    else ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x);
+                }
+            }
+        }
     });
 }
 
@@ -231,7 +333,7 @@ static int launch_tile(const GemmP& p0, int ta, int tb, hipStream_t s) {
     const int tiles_m = (p.m + BM - 1) / BM;
     p.tiles_n = (p.n + BN - 1) / BN;
     p.nwg = tiles_m * p.tiles_n;
-    dim3 grid(p.nwg), block(64 * WM * WN);
+    dim3 grid(p.nwg * p.split_k), block(64 * WM * WN);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
@@ -257,6 +359,20 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.m = g->m; p.n = g->n; p.k = g->k;
     p.act = g->act; p.c_dtype = g->c_dtype; p.r_dtype = g->r_dtype; p.r_row_mod = g->r_row_mod;
     p.round_res = g->round_res; p.tiles_n = 0; p.nwg = 0;
+    p.split_k = g->split_k > 1 ? g->split_k : 1;
+    p.atomic = g->atomic_acc ? 1 : 0;
+    if (p.split_k > (g->k >> 6)) p.split_k = g->k >> 6;
+    if (p.split_k > 1 && !p.atomic) return DW_EINVAL;  // K slices can only be combined by atomic accumulation
+    if (p.atomic && (g->c_dtype != DW_F32 || g->bias || g->z_out || g->zgrad_in || g->r || g->act)) return DW_EINVAL;
+    {
+        const int es = g->c_dtype == DW_F32 ? 4 : 2;
+        bool v = ((uintptr_t)g->c % (4 * es)) == 0 && (g->ldc & 3) == 0;
+        if (g->bias) v = v && ((uintptr_t)g->bias & 15) == 0;
+        if (g->z_out) v = v && ((uintptr_t)g->z_out & 7) == 0 && (g->ldz & 3) == 0;
+        if (g->zgrad_in) v = v && ((uintptr_t)g->zgrad_in & 7) == 0 && (g->ldzg & 3) == 0;
+        if (g->r) v = v && ((uintptr_t)g->r % (g->r_dtype == DW_F32 ? 16 : 8)) == 0 && (g->ldr & 3) == 0;
+        p.vec = v ? 1 : 0;
+    }
     int tile = g->tile;
     if (tile != 128 && tile != 256) {
         const long t256 = (long)((g->m + 255) / 256) * ((g->n + 255) / 256);

@@ -254,10 +254,8 @@ class WhisperEngine:
 
     def _wgrad(self, dy, x, gout, gbias, R, bias_cols=None):
         """gout (+)= dy^T . x over the (padded) token dimension; gbias (+)= column sums of dy."""
-        acc = self._accumulate
-        if gout is not None:
-            self.ops.gemm(dy, x, trans_a=True, trans_b=True, out_dtype=torch.float32, out=gout,
-                          residual=gout if acc else None, round_res=False)
+        if gout is not None:  # the gradient buffer was zeroed (or holds earlier micro-batches): always accumulate
+            self.ops.gemm(dy, x, trans_a=True, trans_b=True, out_dtype=torch.float32, out=gout, atomic_acc=True)
         if gbias is not None:
             if bias_cols is None:
                 self.ops.colsum(dy[:R], gbias, accumulate=True)
@@ -360,7 +358,11 @@ class WhisperEngine:
                 ctx["layers"].append(lc)
         hf, mu, rs = self._ln("model.decoder.layer_norm", x, R, save)
         logits = self.act(R, self.ldv)
-        ops.gemm(hf[:R], st.s["model.decoder.embed_tokens.weight"], out=logits[:R, :d.vocab])
+        # N = padded vocabulary (multiple of 64): the rows of the shadow buffer behind E are finite parameters / zero
+        # slack, the resulting pad columns are never read as logits (the loss kernel stops at V and zeroes them)
+        eo = st.entries["model.decoder.embed_tokens.weight"][0]
+        e_pad = st.S[eo:eo + self.ldv * d.d_model].view(self.ldv, d.d_model)
+        ops.gemm(hf[:R], e_pad, out=logits[:R])
         if save:
             ctx.update(x_final=x, mu=mu, rs=rs, hf=hf)
         return logits, ctx
@@ -430,7 +432,7 @@ class WhisperEngine:
         if tr_emb:
             # tied head: dE = dlogits^T . hf  (rows beyond V of the padded dlogits are not stored: m = V)
             ops.gemm(dlogits[:, :d.vocab], ctx["hf"], trans_a=True, trans_b=True, out_dtype=torch.float32,
-                     out=st.g[emb], residual=st.g[emb] if accumulate else None, round_res=False)
+                     out=st.g[emb], atomic_acc=True)
         # dhf = dlogits . E : contraction over the padded vocabulary (pad columns of dlogits are zero; the rows of
         # the shadow buffer behind E are finite parameters / zero slack)
         eo = st.entries[emb][0]
@@ -469,15 +471,15 @@ class WhisperEngine:
         # conv stem: x0 = gelu(conv2(a1)) + pos ; a1 = gelu(conv1(mel))
         dz2 = self.act(R, D)
         ops.gelu_bwd(dres, ctx["z2"], out=dz2[:R])
-        gw2 = ops.empty((D, 3 * D), torch.float32)
-        ops.gemm(dz2, ctx["xcol2"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw2)
+        gw2 = ops.zeros((D, 3 * D), torch.float32)
+        ops.gemm(dz2, ctx["xcol2"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw2, atomic_acc=True)
         ops.unpack_conv_grad(gw2, st.g["model.encoder.conv2.weight"], accumulate)
         ops.colsum(dz2[:R], st.g["model.encoder.conv2.bias"], accumulate=True)
         dxcol2 = ops.gemm(dz2[:R], st.conv2_packed, trans_b=True)
         dz1 = self.act(R1, D)
         ops.col2im_s2_gelu_bwd(dxcol2, ctx["z1"], B, T, out=dz1[:R1])
-        gw1 = ops.empty((D, st.kpad1), torch.float32)
-        ops.gemm(dz1, ctx["xcol1"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw1)
+        gw1 = ops.zeros((D, st.kpad1), torch.float32)
+        ops.gemm(dz1, ctx["xcol1"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw1, atomic_acc=True)
         ops.unpack_conv_grad(gw1, st.g["model.encoder.conv1.weight"], accumulate)
         ops.colsum(dz1[:R1], st.g["model.encoder.conv1.bias"], accumulate=True)
 

@@ -26,6 +26,7 @@ class DwGemm(C.Structure):
         ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("act", C.c_int32), ("c_dtype", C.c_int32),
         ("r_dtype", C.c_int32), ("r_row_mod", C.c_int32), ("round_res", C.c_int32), ("tile", C.c_int32),
+        ("split_k", C.c_int32), ("atomic_acc", C.c_int32),
     ]
 
 
@@ -174,9 +175,11 @@ class HipOps:
         return out
 
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
-             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0):
+             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0):
         """C = op(a) @ op(b) with the fused epilogue of dw_gemm_bf16.  a: [M,K] (or [K,M] if trans_a);
-        b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1."""
+        b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1.
+        atomic_acc: out (fp32) += result via float atomics, with the K range split over several workgroups when the
+        output has too few tiles to fill the 256 CUs (weight-gradient GEMMs: small M x N, K = all tokens)."""
         assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
         assert a.stride(1) == 1 and b.stride(1) == 1
         if trans_a:
@@ -199,6 +202,18 @@ class HipOps:
         g.act = int(act)
         g.c_dtype = _dt(out)
         g.tile = int(tile) if tile else self.pick_tile(M, N)
+        if atomic_acc:
+            assert out.dtype == torch.float32 and bias is None and residual is None and not want_z and zgrad is None
+            g.atomic_acc = 1
+            if not tile:
+                t256 = ((M + 255) // 256) * ((N + 255) // 256)
+                g.tile = 256 if t256 >= 64 else 128
+            tiles = ((M + g.tile - 1) // g.tile) * ((N + g.tile - 1) // g.tile)
+            # measured on MI355X (tools/bench_kernels.py): aim at ~1 resident 256-tile or ~2 resident 128-tiles per
+            # CU; more K slices only add atomic traffic
+            target = 256 if g.tile == 256 else 448
+            sk = int(split_k) if split_k else max(1, min(8, int(round(target / tiles))))
+            g.split_k = max(1, min(sk, (K // 64) // 8))
         z = None
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()

@@ -56,7 +56,7 @@ class RefOps:
 
     # nn.Linear under bf16 autocast: bf16 operands, fp32 accumulation (TF:modeling_whisper.py:279-282 etc.)
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
-             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0):
+             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0):
         out_dtype = self.lowp if out_dtype is None else out_dtype
         A = a.float().t() if trans_a else a.float()
         Bm = b.float() if trans_b else b.float().t()
@@ -79,7 +79,10 @@ class RefOps:
             v = (self._bf(v).float() if round_res else v) + r
         v = v.to(out_dtype)
         if out is not None:
-            out.copy_(v)
+            if atomic_acc:
+                out += v
+            else:
+                out.copy_(v)
             v = out
         return (v, z) if want_z else v
 

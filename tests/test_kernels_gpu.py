@@ -105,6 +105,18 @@ def test_gemm_epilogues(ops, ref, tile):
     assert relerr(c, rc) < 6e-3
 
 
+@pytest.mark.parametrize("tile,split_k", [(128, 1), (128, 5), (256, 3), (0, 0)])
+def test_gemm_atomic_split_k(ops, ref, tile, split_k):
+    """Weight-gradient form: out (fp32) += A^T . B over a long token dimension, K range split across workgroups."""
+    K, M, N = 64 * 37, 328, 520
+    a, b = rnd((K, M), 1.0, seed=15), rnd((K, N), 1.0, seed=16)
+    base = rnd((M, N), 1.0, torch.float32, seed=17)
+    out = base.clone()
+    ops.gemm(a, b, trans_a=True, trans_b=True, out=out, atomic_acc=True, tile=tile, split_k=split_k)
+    r = base + ref.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32)
+    assert relerr(out, r) < 1e-5
+
+
 def test_gemm_full_size_linearity(ops):
     """BASELINE-size property check (no oracle needed): (A1+A2).W == A1.W + A2.W up to fp32 accumulation, and the
     256-tile and 128-tile kernels agree, at the distil-large-v3 encoder FFN shape."""
