@@ -106,34 +106,46 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
             for (int kk = 0; kk < 4; ++kk)
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, kb, kk, lane), qf[kk], s[kb], 0, 0, 0);
         }
-        // mask (key tail, causal) and running max
+        // mask (key tail / causal diagonal) only on the tiles that need it -- a wave-uniform test
+        const int wq0 = qb0 + wave * 32;
+        const bool need_mask = ((kt + 1) * 64 > p.Lk) || (CAUSAL && kt * 64 + 63 > wq0);
+        if (CAUSAL && kt * 64 > wq0 + 31) continue;  // every key of this tile is in the future of all 32 queries
         float mx = NEG_BIG;
+        if (need_mask) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < p.Lk && (!CAUSAL || key <= q);
+                    s[kb][r] = ok ? s[kb][r] : NEG_BIG;
+                }
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const bool ok = key < p.Lk && (!CAUSAL || key <= q);
-                s[kb][r] = ok ? s[kb][r] : NEG_BIG;
-                mx = fmaxf(mx, s[kb][r]);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f((s[kb][r] - m_new) * c);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc));
                 s[kb][r] = pv;
                 rs += pv;
             }
         rs += __shfl_xor(rs, 32);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
+        if (__any(m_new != m_run)) {  // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
         // O^T += V^T . P^T
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -226,6 +238,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
         }
         const char* tK = smem + buf * 16384;
         const char* tV = tK + 8192;
+        const int wq0 = qb0 + wave * 32;
+        const bool need_mask = ((kt + 1) * 64 > p.Lk) || (CAUSAL && kt * 64 + 63 > wq0);
+        if (CAUSAL && kt * 64 > wq0 + 31) continue;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
@@ -238,9 +253,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const bool ok = key < p.Lk && (!CAUSAL || key <= q);
-                const float pv = ok ? exp2f(s[r] * c - lse2) : 0.f;
+                float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
+                if (need_mask) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    pv = (key < p.Lk && (!CAUSAL || key <= q)) ? pv : 0.f;
+                }
                 s[r] = pv * (dp[r] - dl);  // dS^T
             }
 #pragma unroll
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP p) {
 //   dV^T[d][key] += dO^T . P,   dK^T[d][key] += Q^T . dS
 // ---------------------------------------------------------------------------------------------------------------
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     // [buf][Q tile 8K | dO tile 8K | lse 64 f32 | delta 64 f32]
     constexpr int STG = 16384 + 512;
     __shared__ __attribute__((aligned(1024))) char smem[2 * 17408];
@@ -321,6 +338,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
         const char* tG = tQ + 8192;
         const float* tL = (const float*)(tQ + 16384);
         const float* tD = tL + 64;
+        const int wk0 = kb0 + wave * 32;
+        // mask needed on the query tail, on a partially valid key block, or on the causal diagonal
+        const bool need_mask = ((qt + 1) * 64 > p.Lq) || (wk0 + 31 >= p.Lk) || (CAUSAL && wk0 + 31 > qt * 64);
+        if (CAUSAL && wk0 > qt * 64 + 63) continue;  // all 64 queries of this tile precede every key of this wave
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
@@ -341,8 +362,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP p) {
                 for (int e = 0; e < 4; ++e) {
                     const int r = g * 4 + e;
                     const int qi = qt * 64 + ql + e;
-                    const bool ok = qi < p.Lq && k_ok && (!CAUSAL || key <= qi);
-                    const float pv = ok ? exp2f(s[r] * c - l4[e] * 1.4426950408889634f) : 0.f;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[e] * 1.4426950408889634f));
+                    if (need_mask) pv = (qi < p.Lq && k_ok && (!CAUSAL || key <= qi)) ? pv : 0.f;
                     pr[r] = pv;
                     s[r] = pv * (dp[r] - d4[e]);  // dS
                 }
