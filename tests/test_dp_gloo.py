@@ -1,0 +1,74 @@
+"""Data-parallel path on CPU: world_size 2 over gloo, one process per rank (the GPU run uses the same code over RCCL).
+Checks DDP semantics of the reference (per-rank token-mean loss, gradients averaged over ranks: SURVEY.md 2.2 C1):
+parameters stay bit-identical across ranks and match a single process that averages the two ranks' gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from distil_whisper_amd.distill import DistillationTrainer
+from oracle import whisper_oracle as wo
+from oracle.ref_ops import RefOps
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(seed=7):
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, seed)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(4, cfg_t.n_mels, 3000, generator=g) * 0.5
+    b = wo.synthetic_batch(cfg_t, 4, seed=seed + 1, T=33, with_audio=False)
+    return cfg_t, cfg_s, t_sd, s_sd, feats, b["decoder_input_ids"], b["labels"]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg_t, cfg_s, t_sd, s_sd, feats, ids, labels = _make()
+    tr = DistillationTrainer(RefOps("cpu", lowp=torch.float32), s_sd, cfg_s, t_sd, cfg_t, weight_decay=0.05)
+    tr.reducer.bucket_elems = 20000  # several buckets
+    sl = slice(rank * 2, rank * 2 + 2)
+    for _ in range(2):
+        tr.train_step(feats[sl], ids[sl], labels[sl])
+    torch.save({"P": tr.student_store.P.clone(), "world": tr.world}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_match_averaged_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    assert r0["world"] == 2
+    assert torch.equal(r0["P"], r1["P"])  # replicas stay identical
+
+    # single process: gradients of the two shards averaged by hand, same optimizer
+    cfg_t, cfg_s, t_sd, s_sd, feats, ids, labels = _make()
+    ops = RefOps("cpu", lowp=torch.float32)
+    tr = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, weight_decay=0.05)
+    aux = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, weight_decay=0.05)
+    for _ in range(2):
+        aux.student_store.P.copy_(tr.student_store.P)
+        aux.student_store.refresh_shadow()
+        tr.forward_backward(feats[0:2], ids[0:2], labels[0:2])
+        aux.forward_backward(feats[2:4], ids[2:4], labels[2:4])
+        tr.student_store.G.add_(aux.student_store.G).mul_(0.5)
+        tr.optimizer_step()
+    a, b = tr.student_store.P, r0["P"]
+    rel = ((a - b).norm() / b.norm()).item()
+    assert rel < 2e-6, rel

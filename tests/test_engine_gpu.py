@@ -117,3 +117,41 @@ def test_hip_engine_equals_torch_restatement_on_gpu(ops):
     assert relerr(out["hip"][0][:3], out["ref"][0][:3]) < 2e-4, (out["hip"][0], out["ref"][0])
     for n in out["ref"][1].g:
         assert relerr(out["hip"][1].g[n], out["ref"][1].g[n]) < 0.03, n
+
+
+def test_drop_in_module_and_feature_extractor_on_gpu(ops):
+    """WhisperFeatureExtractor / WhisperForConditionalGeneration mirrors: audio -> features -> loss -> .grad on the
+    HIP path vs the reference fixtures / the CPU oracle."""
+    from distil_whisper_amd.modeling import WhisperFeatureExtractor, WhisperForConditionalGeneration
+    g = np.load(os.path.join(GOLD, "logmel.npz"))
+    rng = np.random.default_rng(int(g["seed"]))
+    audio = (0.1 * rng.standard_normal((3, 480000))).astype(np.float32)
+    audio[1, 161234:] = 0.0
+    audio[2] *= np.linspace(0.0, 1.0, 480000, dtype=np.float32) ** 2
+    for M in (80, 128):
+        fe = WhisperFeatureExtractor(feature_size=M, ops=ops)
+        out = fe([a for a in audio], sampling_rate=16000, return_tensors="pt").input_features
+        assert out.shape == (3, M, 3000)
+        assert np.abs(out[:, :, ::25].cpu().numpy() - g[f"mel{M}"]).max() < 1e-4
+        with pytest.raises(ValueError, match="sampling rate"):
+            fe([audio[0]], sampling_rate=8000)
+    short = fe([audio[0][:100000]], sampling_rate=16000, return_tensors="pt").input_features  # zero-padded to 30 s
+    assert short.shape == (1, 128, 3000)
+
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 51)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    b = wo.synthetic_batch(cfg_s, 2, seed=52, T=60, with_audio=False)
+    feats = torch.randn(2, cfg_s.n_mels, 3000, generator=torch.Generator().manual_seed(2)) * 0.5
+    params = {k: v.clone().requires_grad_(k != "model.encoder.embed_positions.weight") for k, v in s_sd.items()}
+    loss_ref, logits_ref, _ = wo.model_forward(params, cfg_s, feats, b["decoder_input_ids"], b["labels"])
+    loss_ref.backward()
+    model = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+    out = model(input_features=feats.cuda(), decoder_input_ids=b["decoder_input_ids"].cuda(), labels=b["labels"].cuda())
+    assert abs(out.loss.item() - loss_ref.item()) < 1e-3 * abs(loss_ref.item())
+    out.loss.backward()
+    for n in ("model.decoder.layers.0.fc1.weight", "model.encoder.layers.1.self_attn.v_proj.weight",
+              "model.decoder.embed_tokens.weight", "model.encoder.conv2.weight"):
+        assert relerr(model.get_parameter(n).grad, params[n].grad) < 0.1, n
+    ids = model.generate(feats.cuda(), max_new_tokens=3)
+    assert ids.shape == (2, 4)
