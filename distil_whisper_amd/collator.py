@@ -1,0 +1,59 @@
+"""Batch assembly of the reference hot loop, producing device-resident inputs for the engine.
+
+`DataCollatorSpeechSeq2SeqWithPadding` mirrors run_distillation.py:405-478 (same constructor fields and the same
+returned keys): labels padded to `max_target_length`, `decoder_input_ids = labels[:, :-1]`, `labels = labels[:, 1:]`,
+padding -> -100, prompt tokens up to and including <|startoftranscript|> -> -100.  The integer work is vectorised
+torch on the target device (a few KB per batch; not a kernel-worthy hot spot).
+`linear_schedule_lr` restates `get_scheduler("linear", ...)` as the reference configures it (1409-1415: warm-up and
+total steps are multiplied by the number of processes because every process steps the scheduler).
+"""
+from dataclasses import dataclass
+from typing import Any, Optional, Union
+
+import numpy as np
+import torch
+
+
+@dataclass
+class DataCollatorSpeechSeq2SeqWithPadding:
+    processor: Any = None
+    decoder_start_token_id: int = 50257
+    decoder_prev_token_id: int = 50360
+    input_padding: Union[bool, str] = "max_length"
+    target_padding: Union[bool, str] = "max_length"
+    max_target_length: Optional[int] = 448
+    pad_token_id: int = 50256
+    device: str = "cuda:0"
+
+    def __call__(self, features):
+        B = len(features)
+        L = self.max_target_length
+        ids = torch.full((B, L), self.pad_token_id, dtype=torch.long)
+        att = torch.zeros((B, L), dtype=torch.bool)
+        for i, f in enumerate(features):
+            lab = torch.as_tensor(np.asarray(f["labels"], dtype=np.int64))
+            if lab.numel() > L:
+                raise ValueError(f"labels of length {lab.numel()} exceed max_target_length={L}")
+            ids[i, : lab.numel()] = lab
+            att[i, : lab.numel()] = True
+        ids, att = ids.to(self.device), att.to(self.device)
+        decoder_input_ids = ids[:, :-1].contiguous()
+        labels = ids[:, 1:].masked_fill(~att[:, 1:], -100)
+        bos_index = torch.argmax((labels == self.decoder_start_token_id).long(), dim=1)
+        bos_index = torch.where(bos_index > 0, bos_index + 1, bos_index)
+        prompt_mask = torch.arange(labels.shape[1], device=labels.device) < bos_index[:, None]
+        labels = torch.where(prompt_mask, torch.full_like(labels, -100), labels).contiguous()
+        batch = {"labels": labels, "decoder_input_ids": decoder_input_ids}
+        if "input_features" in features[0]:
+            feats = np.stack([np.asarray(f["input_features"], dtype=np.float32) for f in features])
+            batch["input_features"] = torch.from_numpy(feats).to(self.device)
+        return batch
+
+
+def linear_schedule_lr(step: int, base_lr: float, warmup_steps: int, total_steps: int, num_processes: int = 1):
+    """LR at optimizer step `step` (0-based) under the reference's scheduler set-up: linear warm-up then linear decay,
+    the scheduler being stepped `num_processes` times per optimizer step with both horizons scaled accordingly."""
+    s, w, t = step * num_processes, warmup_steps * num_processes, total_steps * num_processes
+    if s < w:
+        return base_lr * s / max(1, w)
+    return base_lr * max(0.0, (t - s) / max(1, t - w))

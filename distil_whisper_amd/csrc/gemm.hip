@@ -29,6 +29,7 @@ struct GemmP {
     int m, n, k;
     int act, c_dtype, r_dtype, r_row_mod, round_res;
     int tiles_n, nwg;      // output tiles
+    int strip;             // rasterisation strip width in tiles (see the kernel)
     int split_k, atomic;   // K slices per tile (grid = nwg * split_k); atomic: C (f32) += v with atomics
     int vec;               // all epilogue pointers / leading dimensions allow 4-wide vector access
 };
@@ -53,7 +54,7 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, i
     return r;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int VAR>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -80,7 +81,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
     }
     const int ks = id / p.nwg;          // K slice (slice-major: neighbouring blocks share operand panels in L2)
     id -= ks * p.nwg;
-    const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+    // Tile rasterisation: the 32 CUs of an XCD walk column strips of `sw` output tiles (strip-major, then down M),
+    // so a strip of B (sw x BN x K, <= ~2.6 MB for K = 1280) stays resident in the XCD's 4 MiB L2 while A streams
+    // through once per strip and every A panel is shared by sw concurrently running workgroups.
+    int tm, tn;
+    {
+        const int tiles_m = p.nwg / p.tiles_n;
+        const int nstrips = (p.tiles_n + p.strip - 1) / p.strip;
+        const int sw = (p.tiles_n + nstrips - 1) / nstrips;          // balanced strip width
+        const int per_strip = sw * tiles_m;
+        int strip = id / per_strip;
+        int within = id - strip * per_strip;
+        int width = sw;
+        const int full = p.tiles_n - (nstrips - 1) * sw;             // width of the last (possibly narrower) strip
+        if (strip >= nstrips - 1) {                                  // ids past the full strips belong to the last
+            strip = nstrips - 1;
+            within = id - strip * per_strip;
+            width = full;
+        }
+        tm = within / width;
+        tn = strip * sw + (within - tm * width);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane source pointers of the staging loads (advance by one K-step per iteration) ----
@@ -172,27 +193,96 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
         }
     };
 
-    stage(0);
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        wait_vm0();        // this wave's pieces of tile t have landed in LDS
-        __syncthreads();   // ... everybody's have; and everybody finished reading buffer buf^1 (tile t-1)
-        if (t + 1 < nt) stage(buf ^ 1);
+    // One K tile (64 deep) of MFMAs for this wave out of LDS buffer `buf`.
+    auto compute = [&](int buf) {
         const char* tA = smem + buf * STAGE;
         const char* tB = tA + BM * 128;
+        if (VAR == 0 || VAR == 5 || VAR >= 6) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[FM], bfr[FN];
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                if (TA) af[i] = frag_kmajor<BM>(tA, wm0 + i * 32, kk, lane);
-                else af[i] = frag_rows(tA, (wm0 >> 5) + i, kk, lane);
+                for (int i = 0; i < FM; ++i) {
+                    if (TA) af[i] = frag_kmajor<BM>(tA, wm0 + i * 32, kk, lane);
+                    else af[i] = frag_rows(tA, (wm0 >> 5) + i, kk, lane);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if (TB) bfr[j] = frag_kmajor<BN>(tB, wn0 + j * 32, kk, lane);
+                    else bfr[j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane);
+                }
+                static_for<0, FM>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, FN>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    });
+                });
             }
+        } else {
+            // explicit register double buffer: the fragments of sub-step kk+1 are requested from LDS before the
+            // MFMA cluster of sub-step kk is issued, so the LDS latency hides behind FM*FN matrix instructions
+            bf16x8 af[2][FM], bfr[2][FN];
+            auto load = [&](auto kc, auto sc) {
+                constexpr int kk = decltype(kc)::value;
+                constexpr int sl = decltype(sc)::value;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if (TB) bfr[j] = frag_kmajor<BN>(tB, wn0 + j * 32, kk, lane);
-                else bfr[j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane);
-            }
+                for (int i = 0; i < FM; ++i) {
+                    if (TA) af[sl][i] = frag_kmajor<BM>(tA, wm0 + i * 32, kk, lane);
+                    else af[sl][i] = frag_rows(tA, (wm0 >> 5) + i, kk, lane);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if (TB) bfr[sl][j] = frag_kmajor<BN>(tB, wn0 + j * 32, kk, lane);
+                    else bfr[sl][j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane);
+                }
+            };
+            load(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            static_for<0, 4>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                constexpr int cur = kk & 1;
+                if constexpr (kk < 3) load(std::integral_constant<int, kk + 1>{}, std::integral_constant<int, cur ^ 1>{});
+                if (VAR == 3) __builtin_amdgcn_s_setprio(1);
+                static_for<0, FM>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, FN>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
+                    });
+                });
+                if (VAR == 3) __builtin_amdgcn_s_setprio(0);
+                if (VAR == 1 || VAR == 4) {
+                    // pin the interleave: LDS reads between consecutive MFMAs (DS_READ mask 0x100, MFMA 0x8)
+#pragma unroll
+                    for (int q = 0; q < FM * FN; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, (TA || TB) ? 2 : 1, 0);
+                    }
+                }
+            });
+        }
+    };
+
+    stage(0);
+    if (VAR < 4 || VAR == 6 || VAR == 7) {
+        // lock-step schedule: every wave prefetches its pieces of tile t+1, then computes tile t
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            wait_vm0();        // this wave's pieces of tile t have landed in LDS
+            __syncthreads();   // ... everybody's have; and everybody finished reading buffer buf^1 (tile t-1)
+            if (t + 1 < nt && VAR != 6) stage(buf ^ 1);     // VAR 6: ablation, no operand traffic in the loop
+            if (VAR != 7) compute(VAR == 6 ? 0 : buf);       // VAR 7: ablation, operand traffic only
+        }
+    } else if (VAR == 8) {
+        // ablation: MFMA only (operands loaded once into registers)
+        bf16x8 af[FM], bfr[FN];
+        wait_vm0();
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = frag_rows(smem, (wm0 >> 5) + i, 0, lane);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[j] = frag_rows(smem + BM * 128, (wn0 >> 5) + j, 0, lane);
+        for (int t = 0; t < nt * 4; ++t) {
             static_for<0, FM>([&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 static_for<0, FN>([&](auto jc) {
@@ -200,6 +290,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 });
             });
+        }
+    } else {
+        // ping-pong schedule: the two wave groups (upper / lower half of the tile rows; one wave of each group per
+        // SIMD) alternate between a compute phase and a memory phase, so that while one wave of a SIMD issues its
+        // LDS-DMA pieces of the next K tile and waits for them, the other one keeps the matrix pipe busy.
+        //   phase A: group 0 computes tile t          | group 1 issues its pieces of tile t+1
+        //   phase B: group 0 issues its pieces of t+1 | group 1 computes tile t
+        // Buffer (t+1)&1 was last read in phase B of iteration t-1 (closed by a barrier), and all pieces of tile t+1
+        // are waited for (vmcnt) by their issuing waves before the barrier that ends phase B.
+        const bool g0 = wave < NW / 2;
+        wait_vm0();
+        __syncthreads();
+        const int mine = g0 ? 0 : 1;
+        for (int ph = 0; ph < 2 * nt; ++ph) {  // single call site for compute/stage: no code (or register) duplication
+            const int t = ph >> 1;
+            const int buf = t & 1;
+            if ((ph & 1) == mine) compute(buf);
+            else if (t + 1 < nt) stage(buf ^ 1);
+            if (ph & 1) wait_vm0();
+            __syncthreads();
         }
     }
 
@@ -327,17 +437,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
     });
 }
 
-template <int BM, int BN, int WM, int WN>
+static int g_gemm_variant = 1;  // 1 = register double-buffered fragments with pinned MFMA/LDS interleave
+static int g_gemm_strip = 0;
+extern "C" int dw_debug_set(int key, int value) {
+    if (key == 0) { g_gemm_variant = value; return DW_OK; }
+    if (key == 1) { g_gemm_strip = value; return DW_OK; }
+    return DW_EINVAL;
+}
+
+template <int BM, int BN, int WM, int WN, int VAR>
 static int launch_tile(const GemmP& p0, int ta, int tb, hipStream_t s) {
     GemmP p = p0;
     const int tiles_m = (p.m + BM - 1) / BM;
     p.tiles_n = (p.n + BN - 1) / BN;
     p.nwg = tiles_m * p.tiles_n;
+    {
+        // strip width: as many B tiles as stay resident in ~3 MB of the XCD's L2; row-major when that is < 2 tiles
+        const long tile_bytes = (long)BN * p.k * 2;
+        int sw = (int)((3L << 20) / tile_bytes);
+        if (sw < 2 || sw >= p.tiles_n) sw = p.tiles_n;
+        p.strip = g_gemm_strip > 0 ? g_gemm_strip : sw;
+    }
     dim3 grid(p.nwg * p.split_k), block(64 * WM * WN);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, VAR>), grid, block, 0, s, p);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, VAR>), grid, block, 0, s, p);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, VAR>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, VAR>), grid, block, 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }
@@ -379,6 +504,18 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         tile = t256 >= 512 ? 256 : 128;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 256) return launch_tile<256, 256, 2, 4>(p, g->trans_a, g->trans_b, s);
-    return launch_tile<128, 128, 2, 2>(p, g->trans_a, g->trans_b, s);
+    if (tile == 256) {
+        switch (g_gemm_variant) {
+            case 1: return launch_tile<256, 256, 2, 4, 1>(p, g->trans_a, g->trans_b, s);
+            case 2: return launch_tile<256, 256, 2, 4, 2>(p, g->trans_a, g->trans_b, s);
+            case 3: return launch_tile<256, 256, 2, 4, 3>(p, g->trans_a, g->trans_b, s);
+            case 4: return launch_tile<256, 256, 2, 4, 4>(p, g->trans_a, g->trans_b, s);
+            case 5: return launch_tile<256, 256, 2, 4, 5>(p, g->trans_a, g->trans_b, s);
+            case 6: return launch_tile<256, 256, 2, 4, 6>(p, g->trans_a, g->trans_b, s);
+            case 7: return launch_tile<256, 256, 2, 4, 7>(p, g->trans_a, g->trans_b, s);
+            case 8: return launch_tile<256, 256, 2, 4, 8>(p, g->trans_a, g->trans_b, s);
+            default: return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
+        }
+    }
+    return launch_tile<128, 128, 2, 2, 0>(p, g->trans_a, g->trans_b, s);
 }

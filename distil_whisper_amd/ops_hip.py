@@ -60,6 +60,7 @@ _SIGS = {
     "dw_sumsq_f32": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p], C.c_int),
     "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 2 + [C.c_double] * 5 + [C.c_int, C.c_void_p], C.c_int),
     "dw_selftest_tr16": ([C.c_void_p, C.c_void_p], C.c_int),
+    "dw_debug_set": ([C.c_int, C.c_int], C.c_int),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

@@ -151,6 +151,8 @@ int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, in
 /* ---- self tests (diagnostics for bring-up; not on the hot path) --------------------------------------------------
  * Runs ds_read_b64_tr_b16 on a known LDS image: out int32 [64][4] = element ids received by each lane. */
 int dw_selftest_tr16(int32_t* out, void* stream);
+/* Tuning knob for kernel A/B experiments (key 0 = GEMM main-loop variant); not part of the hot path. */
+int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus
 }

@@ -254,22 +254,28 @@ def clip_and_adamw(params, grads, state, step, lr=1e-4, betas=(0.9, 0.999), eps=
     return total
 
 
-def collate(label_lists, decoder_start_token_id, max_target_length=448, decoder_prev_token_id=None):
-    """DataCollatorSpeechSeq2SeqWithPadding.__call__ label side (run_distillation.py:438-478): pad labels to
-    max_target_length with -100, decoder_input_ids = labels[:, :-1] (pad -> 0 is irrelevant: masked by the loss),
-    labels = labels[:, 1:]; prompt tokens up to and including <|startoftranscript|> are masked."""
+def collate(label_lists, decoder_start_token_id, max_target_length=448, pad_token_id=50256):
+    """DataCollatorSpeechSeq2SeqWithPadding.__call__ label side (run_distillation.py:438-478), restated with plain
+    loops: tokenizer.pad to max_target_length (pad id + attention mask), decoder_input_ids = labels[:, :-1],
+    labels = labels[:, 1:], padding -> -100, then every position before (and including) a <|startoftranscript|>
+    found at index > 0 of the shifted labels (i.e. a prompt) -> -100."""
     B = len(label_lists)
-    lab = torch.full((B, max_target_length), -100, dtype=torch.long)
+    ids = torch.full((B, max_target_length), pad_token_id, dtype=torch.long)
+    att = torch.zeros((B, max_target_length), dtype=torch.long)
     for i, l in enumerate(label_lists):
-        lab[i, : len(l)] = torch.tensor(l, dtype=torch.long)
-    dec_in = lab[:, :-1].clone()
-    labels = lab[:, 1:].clone()
-    if decoder_prev_token_id is not None:
-        bos = torch.argmax((labels == decoder_start_token_id).long(), dim=1)
-        bos = torch.where(bos > 0, bos + 1, bos)
-        prompt_mask = torch.arange(labels.shape[1]) < bos[:, None]
-        labels = torch.where(prompt_mask, -100, labels)
-    dec_in = dec_in.masked_fill(dec_in == -100, 0)
+        ids[i, : len(l)] = torch.tensor(l, dtype=torch.long)
+        att[i, : len(l)] = 1
+    dec_in = ids[:, :-1].clone()
+    labels = ids[:, 1:].clone()
+    labels[att[:, 1:] != 1] = -100
+    for i in range(B):
+        bos = 0
+        for j in range(labels.shape[1]):
+            if labels[i, j] == decoder_start_token_id:
+                bos = j
+                break
+        if bos > 0:
+            labels[i, : bos + 1] = -100
     return dec_in, labels
 
 

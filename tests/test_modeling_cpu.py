@@ -95,3 +95,21 @@ def test_greedy_generate_runs():
     cfg_s, s_sd, model, feats, ids, labels = build()
     out = model.generate(feats, max_new_tokens=4)
     assert out.shape == (2, 5) and int(out[0, 0]) == cfg_s.decoder_start_token_id
+
+
+def test_collator_matches_oracle_and_lr_schedule():
+    from distil_whisper_amd.collator import DataCollatorSpeechSeq2SeqWithPadding, linear_schedule_lr
+    sot, prev, pad = 50257, 50360, 50256
+    lists = [[prev, 11, 12, sot, 5, 6, 7], [sot, 8, 9], [sot] + list(range(100, 140))]
+    coll = DataCollatorSpeechSeq2SeqWithPadding(decoder_start_token_id=sot, decoder_prev_token_id=prev,
+                                                max_target_length=64, pad_token_id=pad, device="cpu")
+    out = coll([{"labels": l} for l in lists])
+    dec_in, labels = wo.collate(lists, sot, max_target_length=64, pad_token_id=pad)
+    assert torch.equal(out["labels"], labels) and torch.equal(out["decoder_input_ids"], dec_in)
+    # transformers' linear schedule, stepped num_processes times per optimizer step (run_distillation.py:1409-1415)
+    from transformers import get_scheduler
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-4)
+    sched = get_scheduler("linear", opt, num_warmup_steps=10 * 2, num_training_steps=50 * 2)
+    for step in range(50):
+        assert abs(sched.get_last_lr()[0] - linear_schedule_lr(step, 1e-4, 10, 50, 2)) < 1e-12
+        sched.step(); sched.step()
