@@ -32,6 +32,7 @@ struct GemmP {
     int strip;             // rasterisation strip width in tiles (see the kernel)
     int split_k, atomic;   // K slices per tile (grid = nwg * split_k); atomic: C (f32) += v with atomics
     int vec;               // all epilogue pointers / leading dimensions allow 4-wide vector access
+    long slice_stride;     // split-K without atomics: slice ks stores its partial tile at c + ks * slice_stride
 };
 
 // transposed (k-major) tile [64][BX]: fragment X^T[i = x + ...][k-slots] for one 16-deep k step
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
     float* patch = (float*)smem + wave * (32 * PLD);
     const int hi = lane >> 5, ln = lane & 31;
     const bool plain = !p.bias && !p.z_out && p.act == 0 && !p.zgrad && !p.r;
+    float* const cf = (float*)p.c + (long)ks * p.slice_stride;  // (fp32 outputs only; slice_stride = 0 otherwise)
     const int pr = lane / LPR, pc = (lane % LPR) * 4;
     const int n = n0 + wn0 + pc;
     const bool n_in = n < p.n;
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
             if (p.atomic) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < p.n) atomicAdd((float*)p.c + (long)m * p.ldc + n + e, v[e]);
+                    if (n + e < p.n) atomicAdd(cf + (long)m * p.ldc + n + e, v[e]);
                 continue;
             }
             const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = v[e];
-                    *(f32x4*)((float*)p.c + (long)m * p.ldc + n) = o;
+                    *(f32x4*)(cf + (long)m * p.ldc + n) = o;
                 } else {
                     bf16x4 o;
 #pragma unroll
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                             x = (p.round_res ? round_bf16(x) : x) + rv;
                         }
                     }
-                    if (p.c_dtype == DW_F32) ((float*)p.c)[(long)m * p.ldc + nn] = x;
+                    if (p.c_dtype == DW_F32) cf[(long)m * p.ldc + nn] = x;
                     else ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x);
                 }
             }
@@ -467,6 +469,32 @@ static int launch_tile(const GemmP& p0, int ta, int tb, hipStream_t s) {
     return DW_OK;
 }
 
+// out[i] (+)= sum_s part[s * stride + i]   (combination of split-K partial tiles; deterministic, no atomics)
+__global__ __launch_bounds__(256) void reduce_slices_kernel(const float* part, long stride, int slices, float* out,
+                                                            long n, int accumulate) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 acc = accumulate ? *(const f32x4*)(out + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < slices; ++s) {
+        const f32x4 v = *(const f32x4*)(part + s * stride + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    *(f32x4*)(out + i) = acc;
+}
+
+extern "C" int dw_reduce_slices(const float* part, int64_t stride, int slices, float* out, int64_t n, int accumulate,
+                                void* stream) {
+    DW_CLEAR_ERR();
+    if (!part || !out || slices < 1 || n <= 0 || (n & 3) || (stride & 3) || ((uintptr_t)part & 15) ||
+        ((uintptr_t)out & 15))
+        return DW_EINVAL;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, part,
+                       (long)stride, slices, out, (long)n, accumulate);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
 extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     DW_CLEAR_ERR();
     if (!g || !g->a || !g->b || !g->c) return DW_EINVAL;
@@ -487,7 +515,14 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.split_k = g->split_k > 1 ? g->split_k : 1;
     p.atomic = g->atomic_acc ? 1 : 0;
     if (p.split_k > (g->k >> 6)) p.split_k = g->k >> 6;
-    if (p.split_k > 1 && !p.atomic) return DW_EINVAL;  // K slices can only be combined by atomic accumulation
+    p.slice_stride = 0;
+    if (p.split_k > 1 && !p.atomic) {
+        // K slices without atomics: every slice stores a plain fp32 partial at c + ks * slice_stride (the caller
+        // reduces them, see dw_reduce_slices); only the bare epilogue makes sense here
+        if (g->c_dtype != DW_F32 || g->bias || g->z_out || g->zgrad_in || g->r || g->act || g->slice_stride <= 0)
+            return DW_EINVAL;
+        p.slice_stride = g->slice_stride;
+    }
     if (p.atomic && (g->c_dtype != DW_F32 || g->bias || g->z_out || g->zgrad_in || g->r || g->act)) return DW_EINVAL;
     {
         const int es = g->c_dtype == DW_F32 ? 4 : 2;

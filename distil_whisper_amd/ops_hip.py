@@ -26,7 +26,7 @@ class DwGemm(C.Structure):
         ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("act", C.c_int32), ("c_dtype", C.c_int32),
         ("r_dtype", C.c_int32), ("r_row_mod", C.c_int32), ("round_res", C.c_int32), ("tile", C.c_int32),
-        ("split_k", C.c_int32), ("atomic_acc", C.c_int32),
+        ("split_k", C.c_int32), ("atomic_acc", C.c_int32), ("slice_stride", C.c_int64),
     ]
 
 
@@ -61,6 +61,7 @@ _SIGS = {
     "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 2 + [C.c_double] * 5 + [C.c_int, C.c_void_p], C.c_int),
     "dw_selftest_tr16": ([C.c_void_p, C.c_void_p], C.c_int),
     "dw_debug_set": ([C.c_int, C.c_int], C.c_int),
+    "dw_reduce_slices": ([C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p], C.c_int),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
@@ -203,18 +204,34 @@ class HipOps:
         g.act = int(act)
         g.c_dtype = _dt(out)
         g.tile = int(tile) if tile else self.pick_tile(M, N)
+        ws = None
         if atomic_acc:
+            # out (fp32, contiguous) += A^T.B : weight-gradient form.  Few output tiles and a very long K: cut K into
+            # slices so that ~all 256 CUs get one 256x256 tile job (or two rounds of them), each slice stores its fp32
+            # partial into a workspace and dw_reduce_slices adds them to `out` (deterministic; float atomics measured
+            # slower beyond 2 slices).  A single slice accumulates directly with atomics.
             assert out.dtype == torch.float32 and bias is None and residual is None and not want_z and zgrad is None
-            g.atomic_acc = 1
             if not tile:
-                t256 = ((M + 255) // 256) * ((N + 255) // 256)
-                g.tile = 256 if t256 >= 64 else 128
+                g.tile = 256
             tiles = ((M + g.tile - 1) // g.tile) * ((N + g.tile - 1) // g.tile)
-            # measured on MI355X (tools/bench_kernels.py): aim at ~1 resident 256-tile or ~2 resident 128-tiles per
-            # CU; more K slices only add atomic traffic
-            target = 256 if g.tile == 256 else 448
-            sk = int(split_k) if split_k else max(1, min(8, int(round(target / tiles))))
-            g.split_k = max(1, min(sk, (K // 64) // 8))
+            nt = K // 64
+            if split_k:
+                sk = int(split_k)
+            else:
+                # fill whole rounds of the 256 CUs: maximise (tiles*sk) / (ceil(tiles*sk/256)*256), mild penalty per slice
+                best, sk = -1.0, 1
+                for cand in range(1, max(1, min(16, nt // 16)) + 1):
+                    jobs = tiles * cand
+                    eff = jobs / (-(-jobs // 256) * 256) - 0.004 * cand
+                    if eff > best + 1e-9:
+                        best, sk = eff, cand
+            sk = max(1, min(sk, nt // 16))
+            if sk > 1 and out.is_contiguous() and (M * N) % 4 == 0:
+                ws = self.empty((sk, M, N), torch.float32)
+                g.c, g.ldc = ws.data_ptr(), N
+                g.split_k, g.slice_stride = sk, M * N
+            else:
+                g.atomic_acc, g.split_k = 1, 1
         z = None
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
@@ -232,6 +249,9 @@ class HipOps:
             g.round_res = int(bool(round_res))
         e0 = self._t0()
         self._chk(self.lib.dw_gemm_bf16(C.byref(g), self._stream()), f"gemm m={M} n={N} k={K} ta={trans_a} tb={trans_b}")
+        if ws is not None:
+            self._chk(self.lib.dw_reduce_slices(ws.data_ptr(), M * N, g.split_k, out.data_ptr(), M * N, 1,
+                                                self._stream()), "reduce_slices")
         self._t1(e0, f"gemm_t{g.tile}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}", 2.0 * M * N * K)
         return (out, z) if want_z else out
 

@@ -73,10 +73,14 @@ typedef struct DwGemm {
     int32_t r_row_mod;  /* 0: R row = m; >0: R row = m %% r_row_mod (positional table broadcast) */
     int32_t round_res;  /* 1: round v to bf16 before adding R (autocast semantics) */
     int32_t tile;       /* 0 auto, 128 or 256: force the block tile */
-    int32_t split_k;    /* > 1: the K range is cut into that many slices (needs atomic_acc) */
+    int32_t split_k;    /* > 1: the K range is cut into that many slices, combined either by atomic_acc or by
+                           storing fp32 partials at c + slice * slice_stride (then call dw_reduce_slices) */
     int32_t atomic_acc; /* 1: C (f32, plain epilogue) += result with float atomics (gradient accumulation) */
+    int64_t slice_stride; /* elements between the partial outputs of consecutive K slices (split_k > 1, no atomics) */
 } DwGemm;
 int dw_gemm_bf16(const DwGemm* g, void* stream);
+/* out[i] (+)= sum over slices of part[s*stride + i]; n, stride multiples of 4 (split-K combination, deterministic). */
+int dw_reduce_slices(const float* part, int64_t stride, int slices, float* out, int64_t n, int accumulate, void* stream);
 
 /* ---- LayerNorm (TF:modeling_whisper.py:371,377,434,443,446,573,682), eps 1e-5, statistics in f32 ---------------
  * x [rows][cols] f32 or bf16 (x_dtype), y bf16 [rows][cols]; mean/rstd f32 [rows] (may be NULL for inference). */

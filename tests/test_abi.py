@@ -31,7 +31,7 @@ def test_binding_covers_header_and_struct_layout():
     from distil_whisper_amd import ops_hip
     assert set(declared()) == set(ops_hip.EXPORTED_SYMBOLS)
     # DwGemm: 7 pointers, 6 int64, 13 int32 (padded to 8)
-    assert ctypes.sizeof(ops_hip.DwGemm) == 7 * 8 + 6 * 8 + 14 * 4
+    assert ctypes.sizeof(ops_hip.DwGemm) == 7 * 8 + 6 * 8 + 14 * 4 + 8  # 7 ptr, 6 i64, 13 i32 (+pad), 1 i64
 
 
 def test_invalid_arguments_are_rejected_without_touching_the_gpu():

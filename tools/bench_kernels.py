@@ -78,12 +78,16 @@ def main():
     t = timeit(lambda: ops.gemm(dy, w2, trans_b=True, zgrad=zz))
     res.append({"kernel": "gemm fc2 dX *gelu'", "ms": t * 1e3, "tflops": 2.0 * M * 5120 * 1280 / t / 1e12}); print(res[-1], flush=True)
     gw = torch.zeros(5120, 1280, device="cuda")
-    for sk in (1, 2, 4, 8):
+    t = timeit(lambda: ops.gemm(zz, x, trans_a=True, trans_b=True, out=gw, atomic_acc=True))
+    res.append({"kernel": "gemm fc1 dW auto", "ms": t * 1e3, "tflops": 2.0 * M * 5120 * 1280 / t / 1e12}); print(res[-1], flush=True)
+    for sk in (2, 3, 5):
         for tile in (128, 256):
             t = timeit(lambda: ops.gemm(zz, x, trans_a=True, trans_b=True, out=gw, atomic_acc=True, tile=tile, split_k=sk))
             res.append({"kernel": f"gemm fc1 dW atomic t{tile} sk{sk}", "ms": t * 1e3, "tflops": 2.0 * M * 5120 * 1280 / t / 1e12}); print(res[-1], flush=True)
     gw = torch.zeros(1280, 1280, device="cuda")
-    for sk in (1, 4, 8):
+    t = timeit(lambda: ops.gemm(dy, x, trans_a=True, trans_b=True, out=gw, atomic_acc=True))
+    res.append({"kernel": "gemm out dW auto", "ms": t * 1e3, "tflops": 2.0 * M * 1280 * 1280 / t / 1e12}); print(res[-1], flush=True)
+    for sk in (5, 10, 20):
         for tile in (128, 256):
             t = timeit(lambda: ops.gemm(dy, x, trans_a=True, trans_b=True, out=gw, atomic_acc=True, tile=tile, split_k=sk))
             res.append({"kernel": f"gemm out dW atomic t{tile} sk{sk}", "ms": t * 1e3, "tflops": 2.0 * M * 1280 * 1280 / t / 1e12}); print(res[-1], flush=True)
