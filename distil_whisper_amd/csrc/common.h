@@ -42,23 +42,41 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-// Fast erf (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7: far below the bf16 rounding applied to every GELU output)
-__device__ __forceinline__ float erf_fast(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-    float y = fmaf(1.061405429f, t, -1.453152027f);
-    y = fmaf(y, t, 1.421413741f);
-    y = fmaf(y, t, -0.284496736f);
-    y = fmaf(y, t, 0.254829592f);
-    y = 1.0f - y * t * __expf(-ax * ax);
-    return copysignf(y, x);
+// Fast exact-erf GELU for the GEMM epilogues (Abramowitz & Stegun 7.1.26, |erf error| <= 1.5e-7: far below the
+// bf16 rounding applied to every GELU output).  Written on 2-vectors so that hipcc emits packed fp32 VALU ops
+// (v_pk_fma_f32 / v_pk_mul_f32: two elements per instruction); one v_exp and one v_rcp per element, shared between
+// the cdf and the pdf (exp(-x^2/2) is both the erf tail factor at x/sqrt2 and the Gaussian density).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    f32x2 ax; ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+    const f32x2 u = ax * 0.70710678118654752f;                 // |x| / sqrt(2)
+    f32x2 den = u * 0.3275911f + 1.0f;
+    // raw v_rcp_f32 / v_exp_f32 (1 ulp, no IEEE fix-up sequences: the result is rounded to bf16 anyway)
+    f32x2 t; t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
+    const f32x2 xx = x * x * -0.72134752044448170f;            // -0.5 * log2(e) * x^2
+    f32x2 e; e[0] = __builtin_amdgcn_exp2f(xx[0]); e[1] = __builtin_amdgcn_exp2f(xx[1]);
+    f32x2 y = t * 1.061405429f + (-1.453152027f);
+    y = y * t + 1.421413741f;
+    y = y * t + (-0.284496736f);
+    y = y * t + 0.254829592f;
+    const f32x2 tail = y * t * e;                               // 1 - erf(|x|/sqrt2)
+    f32x2 half_tail = tail * 0.5f;                              // cdf = 1 - tail/2 (x >= 0), tail/2 (x < 0)
+    cdf[0] = x[0] >= 0.f ? 1.0f - half_tail[0] : half_tail[0];
+    cdf[1] = x[1] >= 0.f ? 1.0f - half_tail[1] : half_tail[1];
+    pdf = e * 0.39894228040143268f;
 }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    f32x2 cdf, pdf;
+    gelu_parts2(x, cdf, pdf);
+    return x * cdf;
+}
+__device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
+    f32x2 cdf, pdf;
+    gelu_parts2(x, cdf, pdf);
     return cdf + x * pdf;
 }
+__device__ __forceinline__ float gelu_fast(float x) { f32x2 v; v[0] = x; v[1] = x; return gelu_fast2(v)[0]; }
+__device__ __forceinline__ float gelu_grad_fast(float x) { f32x2 v; v[0] = x; v[1] = x; return gelu_grad_fast2(v)[0]; }
 
 // ---- LDS tile swizzle for [rows][64 bf16] (=128-byte rows) tiles ------------------------------------------------
 // 16-byte slot s (0..7) of row r is stored at physical slot s ^ swz7(r).  The permutation of row bits

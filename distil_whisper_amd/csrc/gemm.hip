@@ -71,15 +71,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
     const int wm0 = (wave / WN) * TM;
     const int wn0 = (wave % WN) * TN;
 
-    // XCD-aware bijective remap: the dispatcher places block b on XCD b%8; give every XCD a contiguous tile range.
-    int id;
-    {
-        const int total = p.nwg * p.split_k;
-        const int bid = blockIdx.x;
+    // Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.
+    // The stores of tile i are still draining while the operand loads and MFMAs of tile i+1 run (a wave cannot
+    // retire before its stores are acknowledged, so one-tile workgroups expose the whole write burst).
+    // XCD-aware: the dispatcher places block b on XCD b%8; every XCD owns a contiguous range of the job list.
+    const int total = p.nwg * p.split_k;
+    const int bid = blockIdx.x;
+    int job_first, job_count, job_step;
+    if ((int)gridDim.x == total) {           // one job per workgroup (small problems)
         const int xcd = bid & 7, local = bid >> 3;
         const int q = total >> 3, r = total & 7;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        job_first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        job_count = 1;
+        job_step = 1;
+    } else {                                 // gridDim.x is a multiple of 8: gridDim.x / 8 workgroups per XCD
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int cnt = q + (xcd < r ? 1 : 0);
+        job_step = gridDim.x >> 3;
+        job_first = start + local;
+        job_count = local < cnt ? (cnt - local + job_step - 1) / job_step : 0;
     }
+  for (int job = 0; job < job_count; ++job) {
+    int id = job_first + job * job_step;
     const int ks = id / p.nwg;          // K slice (slice-major: neighbouring blocks share operand panels in L2)
     id -= ks * p.nwg;
     // Tile rasterisation: the 32 CUs of an XCD walk column strips of `sw` output tiles (strip-major, then down M),
@@ -354,8 +369,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
             });
         });
         // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads below)
-#pragma unroll 2
-        for (int it = 0; it < 32 / RPI; ++it) {
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {  // fully unrolled: all loads of a 32-row slab are in flight at once
             const int rl = it * RPI + pr;
             const int m = m0 + wm0 + i * 32 + rl;
             const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
@@ -380,12 +395,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                     }
                     if (p.act == 1) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_fast(round_bf16(v[e]));
+                        for (int e = 0; e < 4; e += 2) {
+                            f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
+                            const f32x2 g2 = gelu_fast2(x2);
+                            v[e] = g2[0]; v[e + 1] = g2[1];
+                        }
                     }
                     if (p.zgrad) {
                         const bf16x4 z4 = *(const bf16x4*)(p.zgrad + (long)m * p.ldzg + n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_fast(bf2f(z4[e]));
+                        for (int e = 0; e < 4; e += 2) {
+                            f32x2 x2; x2[0] = bf2f(z4[e]); x2[1] = bf2f(z4[e + 1]);
+                            const f32x2 g2 = gelu_grad_fast2(x2);
+                            v[e] *= g2[0]; v[e + 1] *= g2[1];
+                        }
                     }
                     if (p.r) {
                         float rv[4];
@@ -437,13 +460,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
             }
         }
     });
+    __syncthreads();  // the LDS patches are reused as operand buffers by the next job
+  }  // job loop
 }
 
+static int g_gemm_persistent = 1;
 static int g_gemm_variant = 1;  // 1 = register double-buffered fragments with pinned MFMA/LDS interleave
 static int g_gemm_strip = 0;
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
     if (key == 1) { g_gemm_strip = value; return DW_OK; }
+    if (key == 2) { g_gemm_persistent = value; return DW_OK; }
     return DW_EINVAL;
 }
 
@@ -460,7 +487,10 @@ static int launch_tile(const GemmP& p0, int ta, int tb, hipStream_t s) {
         if (sw < 2 || sw >= p.tiles_n) sw = p.tiles_n;
         p.strip = g_gemm_strip > 0 ? g_gemm_strip : sw;
     }
-    dim3 grid(p.nwg * p.split_k), block(64 * WM * WN);
+    // persistent launch for the 256-tile (one workgroup per CU, 256 CUs): only when there are more jobs than CUs
+    int nblk = p.nwg * p.split_k;
+    if (BM == 256 && nblk > 256 && g_gemm_persistent) nblk = 256;
+    dim3 grid(nblk), block(64 * WM * WN);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, VAR>), grid, block, 0, s, p);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, VAR>), grid, block, 0, s, p);
     else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, VAR>), grid, block, 0, s, p);

@@ -155,3 +155,22 @@ def test_drop_in_module_and_feature_extractor_on_gpu(ops):
         assert relerr(model.get_parameter(n).grad, params[n].grad) < 0.1, n
     ids = model.generate(feats.cuda(), max_new_tokens=3)
     assert ids.shape == (2, 4)
+
+
+def test_large_v3_loss_matches_cpu_oracle(ops):
+    """BASELINE config 3 model (whisper-large-v3-shaped 32/32 teacher -> 32/2 student, 128 mel, V=51866) at batch 1:
+    the bf16 HIP step vs the fp32 CPU oracle on identical seeded weights/inputs, loss within 1e-3 relative."""
+    cfg_t = wo.CONFIGS["large-v3"]
+    t_sd = wo.init_state_dict(cfg_t, 61)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 32, 2)
+    b = wo.synthetic_batch(cfg_t, 1, seed=62, with_audio=False)
+    feats = torch.randn(1, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(3)) * 0.5
+    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        loss, metrics, *_ = wo.train_step(s_sd, cfg_s, t_sd, cfg_t, batch)
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    losses = tr.forward_backward(feats.cuda(), batch["decoder_input_ids"].cuda(), batch["labels"].cuda()).cpu()
+    assert abs(losses[0].item() - metrics["ce_loss"].item()) < 1e-3 * abs(metrics["ce_loss"].item()), losses
+    assert abs(losses[2].item() - loss.item()) < 1e-3 * abs(loss.item()), (losses.tolist(), loss.item())
+    assert torch.isfinite(tr.student_store.G).all()

@@ -25,6 +25,8 @@ def timeit(fn, iters=10, warmup=2):
 
 def main():
     ops = HipOps("cuda:0")
+    if os.environ.get("DW_PERSIST"):
+        ops.lib.dw_debug_set(2, int(os.environ["DW_PERSIST"]))
     res = []
     B = int(os.environ.get("DW_B", "32"))
 
