@@ -66,17 +66,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float*
 template <bool XBF, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void* x, const float* mean,
                                                      const float* rstd, const float* gamma, float* dres,
-                                                     int accumulate, float* dgamma, float* dbeta, int rows, int cols) {
-    __shared__ float red[2 * 4 * 512];  // [dgamma|dbeta][wave][512-column window]
+                                                     int accumulate, float* dgamma, float* dbeta, bf16* dres_lowp,
+                                                     float* dres_colsum, int rows, int cols) {
+    __shared__ float red[3 * 4 * 512];  // [dgamma|dbeta|colsum][wave][512-column window]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nvec = cols >> 2;
-    f32x4 gm[NV], ag[NV], ab[NV];
+    f32x4 gm[NV], ag[NV], ab[NV], ac[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = lane + 64 * j;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 0.f; ac[j][e] = 0.f; }
         if (idx < nvec) gm[j] = *(const f32x4*)(gamma + idx * 4);
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
@@ -116,12 +117,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void*
                     for (int e = 0; e < 4; ++e) o[e] += old[e];
                 }
                 *(f32x4*)dst = o;
+                if (dres_lowp) {
+                    // the low-precision copy the next branch's GEMMs consume (autocast: the gradient of a bf16 Linear
+                    // output is bf16) and its column sums = the bias gradient of that Linear
+                    bf16x4 lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lo[e] = f2bf(o[e]); ac[j][e] += bf2f(lo[e]); }
+                    *(bf16x4*)(dres_lowp + (long)row * cols + idx * 4) = lo;
+                }
             }
         }
     }
     // block reduction of the per-wave dgamma / dbeta partials, then one atomic per column per block
     float* r0 = red;
     float* r1 = red + 2048;
+    float* r2 = red + 4096;
     // windows of 512 columns: red[k][wave][col - base]
     for (int base = 0; base < cols; base += 512) {
 #pragma unroll
@@ -133,6 +143,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void*
                 for (int e = 0; e < 4; ++e) {
                     r0[wave * 512 + (col - base) + e] = ag[j][e];
                     r1[wave * 512 + (col - base) + e] = ab[j][e];
+                    r2[wave * 512 + (col - base) + e] = ac[j][e];
                 }
             }
         }
@@ -142,6 +153,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void*
             const float sb = r1[cidx] + r1[512 + cidx] + r1[1024 + cidx] + r1[1536 + cidx];
             atomicAdd(dgamma + base + cidx, sg);
             atomicAdd(dbeta + base + cidx, sb);
+            if (dres_colsum)
+                atomicAdd(dres_colsum + base + cidx, r2[cidx] + r2[512 + cidx] + r2[1024 + cidx] + r2[1536 + cidx]);
         }
         __syncthreads();
     }
@@ -171,8 +184,8 @@ extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
 }
 
 extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
-                                const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, int rows,
-                                int cols, void* stream) {
+                                const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta,
+                                void* dres_lowp, float* dres_colsum, int rows, int cols, void* stream) {
     DW_CLEAR_ERR();
     if (!dy || !x || !mean || !rstd || !gamma || !dres || !dgamma || !dbeta) return DW_EINVAL;
     if (rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
@@ -184,10 +197,10 @@ extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, cons
     do {                                                                                                              \
         if (x_dtype == DW_BF16)                                                                                       \
             hipLaunchKernelGGL((ln_bwd_kernel<true, NVV>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, x, mean, rstd, \
-                               gamma, dres, accumulate, dgamma, dbeta, rows, cols);                                   \
+                               gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols);  \
         else                                                                                                          \
             hipLaunchKernelGGL((ln_bwd_kernel<false, NVV>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, x, mean,      \
-                               rstd, gamma, dres, accumulate, dgamma, dbeta, rows, cols);                             \
+                               rstd, gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols); \
     } while (0)
     if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 5) LN_BWD(5); else LN_BWD(8);
 #undef LN_BWD

@@ -236,13 +236,19 @@ class WhisperEngine:
                                            self.st.p[f"{name}.bias"], 1e-5, save_stats=save, out=y[:R])
         return y, mu, rs
 
-    def _ln_bwd(self, name, dy, x, mu, rs, dres, R):
+    def _ln_bwd(self, name, dy, x, mu, rs, dres, R, emit=False, colsum_to=None):
+        """LayerNorm backward into the fp32 residual-gradient stream.  With emit=True the kernel also writes the
+        low-precision copy of the updated stream (what the next residual branch's GEMMs consume) and adds its column
+        sums to `colsum_to` (the bias gradient of that branch's output projection).  Returns (dres, dy_next)."""
         if self.st.is_trainable(f"{name}.weight"):
             dg, db = self.st.g[f"{name}.weight"], self.st.g[f"{name}.bias"]
         else:
             dg, db = self._scratch_vec(x.shape[1]), self._scratch_vec(x.shape[1], 1)
-        return self.ops.layernorm_bwd(dy[:R], x[:R] if x.shape[0] != R else x, mu, rs, self.st.p[f"{name}.weight"],
-                                      dres, dg, db)
+        nxt = self.act(R, x.shape[1]) if emit else None
+        dres = self.ops.layernorm_bwd(dy[:R], x[:R] if x.shape[0] != R else x, mu, rs, self.st.p[f"{name}.weight"],
+                                      dres, dg, db, out_lowp=nxt[:R] if emit else None,
+                                      colsum=colsum_to if emit else None)
+        return dres, nxt
 
     def _scratch_vec(self, n, slot=0):
         key = (n, slot)
@@ -368,57 +374,62 @@ class WhisperEngine:
         return logits, ctx
 
     # ---- backward --------------------------------------------------------------------------------------------------
-    def _layer_bwd(self, p, lc, dres, B, L, Lk, causal, denc):
-        """Backward of _layer_fwd.  dres: fp32 [R, D] gradient w.r.t. the layer output, updated in place to the
-        gradient w.r.t. the layer input.  denc: fp32 [Re, D] accumulator for the encoder output gradient."""
+    def _bias_grad(self, name):
+        return self.st.g[name] if self.st.is_trainable(name) else None
+
+    def _layer_bwd(self, p, lc, dres, dy, B, L, Lk, causal, denc, emit_last, colsum_last):
+        """Backward of _layer_fwd.  dres: fp32 [R, D] gradient w.r.t. the layer output (updated in place to the
+        gradient w.r.t. the layer input); dy: its low-precision copy, whose column sums were already added to this
+        layer's fc2.bias gradient by the kernel that produced it.  denc: fp32 [Re, D] accumulator for the encoder
+        output gradient.  Returns (dres, dy_for_the_layer_below)."""
         ops, st, d = self.ops, self.st, self.dims
         D, H, R = d.d_model, d.heads, B * L
         tr = st.is_trainable(f"{p}.fc1.weight")
+        cross = "x1" in lc
         # --- feed forward
-        dy = self.act(R, D)
-        ops.cast_bf16(dres, out=dy[:R])
         dz = self.act(R, d.ffn)
         ops.gemm(dy[:R], st.s[f"{p}.fc2.weight"], trans_b=True, zgrad=lc["z"], out=dz[:R])
         if tr:
-            self._wgrad(dy, lc["a"], st.g[f"{p}.fc2.weight"], st.g[f"{p}.fc2.bias"], R)
+            self._wgrad(dy, lc["a"], st.g[f"{p}.fc2.weight"], None, R)
             self._wgrad(dz, lc["h2"], st.g[f"{p}.fc1.weight"], st.g[f"{p}.fc1.bias"], R)
         dh = ops.gemm(dz[:R], st.s[f"{p}.fc1.weight"], trans_b=True)
-        self._ln_bwd(f"{p}.final_layer_norm", dh, lc["x2"], lc["mu2"], lc["rs2"], dres, R)
+        nb = f"{p}.encoder_attn.out_proj.bias" if cross else f"{p}.self_attn.out_proj.bias"
+        dres, dy = self._ln_bwd(f"{p}.final_layer_norm", dh, lc["x2"], lc["mu2"], lc["rs2"], dres, R, emit=True,
+                                colsum_to=self._bias_grad(nb))
         del dz, dh
         # --- cross attention
-        if "x1" in lc:
+        if cross:
             cv = st.attn_views(f"{p}.encoder_attn")
             Re = B * Lk
-            ops.cast_bf16(dres, out=dy[:R])
             do = ops.gemm(dy[:R], cv["wo"], trans_b=True)
             dq = self.act(R, D)
             dkv = self.act(Re, 2 * D)
             ops.attn_bwd(lc["q1"][:R], lc["kv1"][:Re, :D], lc["kv1"][:Re, D:], lc["o1"][:R], do, lc["lse1"], B, H, L,
                          Lk, False, 0.125, dq=dq[:R], dk=dkv[:Re, :D], dv=dkv[:Re, D:])
             if tr:
-                self._wgrad(dy, lc["o1"], cv["g_wo"], cv["g_bo"], R)
+                self._wgrad(dy, lc["o1"], cv["g_wo"], None, R)
                 self._wgrad(dq, lc["h1"], cv["g_wqkv"][:D], cv["g_bqkv"][:D], R)
                 self._wgrad(dkv, lc["enc_out"], cv["g_wqkv"][D:], cv["g_bqkv"][D:], Re, bias_cols=[(D, 2 * D)])
             if denc is not None:
                 ops.gemm(dkv[:Re], cv["wqkv"][D:], trans_b=True, residual=denc, round_res=True,
                          out_dtype=torch.float32, out=denc)
             dh = ops.gemm(dq[:R], cv["wqkv"][:D], trans_b=True)
-            self._ln_bwd(f"{p}.encoder_attn_layer_norm", dh, lc["x1"], lc["mu1"], lc["rs1"], dres, R)
+            dres, dy = self._ln_bwd(f"{p}.encoder_attn_layer_norm", dh, lc["x1"], lc["mu1"], lc["rs1"], dres, R,
+                                    emit=True, colsum_to=self._bias_grad(f"{p}.self_attn.out_proj.bias"))
             del do, dq, dkv, dh
         # --- self attention
         av = st.attn_views(f"{p}.self_attn")
-        ops.cast_bf16(dres, out=dy[:R])
         do = ops.gemm(dy[:R], av["wo"], trans_b=True)
         dqkv = self.act(R, 3 * D)
         qkv = lc["qkv"]
         ops.attn_bwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], lc["o0"][:R], do, lc["lse0"], B, H, L, L, causal,
                      0.125, dq=dqkv[:R, :D], dk=dqkv[:R, D:2 * D], dv=dqkv[:R, 2 * D:])
         if tr:
-            self._wgrad(dy, lc["o0"], av["g_wo"], av["g_bo"], R)
+            self._wgrad(dy, lc["o0"], av["g_wo"], None, R)
             self._wgrad(dqkv, lc["h0"], av["g_wqkv"], av["g_bqkv"], R, bias_cols=[(0, D), (2 * D, 3 * D)])
         dh = ops.gemm(dqkv[:R], av["wqkv"], trans_b=True)
-        self._ln_bwd(f"{p}.self_attn_layer_norm", dh, lc["x0"], lc["mu0"], lc["rs0"], dres, R)
-        return dres
+        return self._ln_bwd(f"{p}.self_attn_layer_norm", dh, lc["x0"], lc["mu0"], lc["rs0"], dres, R, emit=emit_last,
+                            colsum_to=colsum_last)
 
     def backward_decoder(self, ctx, dlogits, want_denc=True, accumulate=False):
         """dlogits: low-precision [>=R, ldv] (pad columns zero).  Accumulates parameter gradients into the store and
@@ -438,12 +449,15 @@ class WhisperEngine:
         eo = st.entries[emb][0]
         e_pad = st.S[eo:eo + self.ldv * D].view(self.ldv, D)
         dh = ops.gemm(dlogits[:R], e_pad, trans_b=True)
-        dres = self._ln_bwd("model.decoder.layer_norm", dh, ctx["x_final"], ctx["mu"], ctx["rs"], None, R)
+        nl = d.dec_layers
+        dres, dy = self._ln_bwd("model.decoder.layer_norm", dh, ctx["x_final"], ctx["mu"], ctx["rs"], None, R,
+                                emit=True, colsum_to=self._bias_grad(f"model.decoder.layers.{nl - 1}.fc2.bias"))
         denc = ops.zeros((B * Lk, D), torch.float32) if want_denc else None
-        for i in reversed(range(d.dec_layers)):
+        for i in reversed(range(nl)):
             lc = ctx["layers"][i]
             lc["enc_out"] = ctx["enc_out"]
-            self._layer_bwd(f"model.decoder.layers.{i}", lc, dres, B, T, Lk, True, denc)
+            below = self._bias_grad(f"model.decoder.layers.{i - 1}.fc2.bias") if i > 0 else None
+            dres, dy = self._layer_bwd(f"model.decoder.layers.{i}", lc, dres, dy, B, T, Lk, True, denc, i > 0, below)
             ctx["layers"][i] = None
         if tr_emb or st.is_trainable("model.decoder.embed_positions.weight"):
             dtok = st.g[emb] if tr_emb else self._scratch_tok()
@@ -462,11 +476,15 @@ class WhisperEngine:
         self._accumulate = accumulate
         B, T, R, D = ctx["B"], ctx["T"], ctx["R"], d.d_model
         L, R1 = T // 2, B * T
-        dy = self.act(R, D)
-        ops.cast_bf16(denc, out=dy[:R])
-        dres = self._ln_bwd("model.encoder.layer_norm", dy, ctx["x_final"], ctx["mu"], ctx["rs"], None, R)
-        for i in reversed(range(d.enc_layers)):
-            self._layer_bwd(f"model.encoder.layers.{i}", ctx["layers"][i], dres, B, L, 0, False, None)
+        dyf = self.act(R, D)
+        ops.cast_bf16(denc, out=dyf[:R])
+        nl = d.enc_layers
+        dres, dy = self._ln_bwd("model.encoder.layer_norm", dyf, ctx["x_final"], ctx["mu"], ctx["rs"], None, R,
+                                emit=True, colsum_to=self._bias_grad(f"model.encoder.layers.{nl - 1}.fc2.bias"))
+        for i in reversed(range(nl)):
+            below = self._bias_grad(f"model.encoder.layers.{i - 1}.fc2.bias") if i > 0 else None
+            dres, dy = self._layer_bwd(f"model.encoder.layers.{i}", ctx["layers"][i], dres, dy, B, L, 0, False, None,
+                                       i > 0, below)
             ctx["layers"][i] = None
         # conv stem: x0 = gelu(conv2(a1)) + pos ; a1 = gelu(conv1(mel))
         dz2 = self.act(R, D)

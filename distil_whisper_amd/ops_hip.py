@@ -38,7 +38,7 @@ _SIGS = {
     "dw_layernorm_fwd": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                           C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_layernorm_bwd": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_attn_fwd": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_bwd": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_distill_loss": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float,
@@ -266,16 +266,21 @@ class HipOps:
                                             float(eps), self._stream()), "layernorm_fwd")
         return y, mean, rstd
 
-    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
-        """dres (f32 [rows,cols]) += LN'(dy) if dres is given, else a new tensor is returned.  dgamma/dbeta += ..."""
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta, out_lowp=None, colsum=None):
+        """dres (f32 [rows,cols]) += LN'(dy) if dres is given, else a new tensor is returned.  dgamma/dbeta += ...
+        out_lowp (bf16 [rows,cols]) receives bf16(dres) and colsum (f32 [cols]) += its column sums (fused)."""
         rows, cols = x.shape
         assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
         acc = dres is not None
         if dres is None:
             dres = self.empty((rows, cols), torch.float32)
         assert dres.dtype == torch.float32 and dres.is_contiguous()
+        if out_lowp is not None:
+            assert out_lowp.dtype == torch.bfloat16 and out_lowp.is_contiguous() and out_lowp.shape == (rows, cols)
+        assert colsum is None or out_lowp is not None
         self._chk(self.lib.dw_layernorm_bwd(_p(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(dres), int(acc),
-                                            _p(dgamma), _p(dbeta), rows, cols, self._stream()), "layernorm_bwd")
+                                            _p(dgamma), _p(dbeta), _p(out_lowp), _p(colsum), rows, cols,
+                                            self._stream()), "layernorm_bwd")
         return dres
 
     def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None):

@@ -87,10 +87,12 @@ int dw_reduce_slices(const float* part, int64_t stride, int slices, float* out, 
 int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, float* mean,
                      float* rstd, int rows, int cols, float eps, void* stream);
 /* dx = LN'(dy); if accumulate: dres[rows][cols] (f32) += dx else dres = dx.  dgamma/dbeta f32 [cols] are ADDED to
- * (atomics; zero them first). */
+ * (atomics; zero them first).  Optional fused outputs: dres_lowp (bf16 [rows][cols]) = bf16(dres) -- the gradient the
+ * next residual branch's GEMMs consume -- and dres_colsum (f32 [cols], ADDED to) = its column sums = the bias gradient
+ * of that branch's output projection. */
 int dw_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const float* mean, const float* rstd,
-                     const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, int rows, int cols,
-                     void* stream);
+                     const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, void* dres_lowp,
+                     float* dres_colsum, int rows, int cols, void* stream);
 
 /* ---- attention core (TF:modeling_whisper.py:215-238 / integrations/sdpa_attention.py), head_dim 64 --------------
  * q [B*Lq rows], k,v [B*Lk rows]: bf16, head h of a row at element offset h*64, row strides ldq/ldk/ldv/ldo

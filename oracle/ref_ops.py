@@ -99,7 +99,7 @@ class RefOps:
             y = out
         return y, (mu if save_stats else None), (rstd if save_stats else None)
 
-    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
+    def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta, out_lowp=None, colsum=None):
         xf, d = x.float(), dy.float()
         xh = (xf - mean[:, None]) * rstd[:, None]
         g = d * gamma
@@ -109,8 +109,13 @@ class RefOps:
         dgamma += (d * xh).sum(0)
         dbeta += d.sum(0)
         if dres is None:
-            return dx
-        dres += dx
+            dres = dx
+        else:
+            dres += dx
+        if out_lowp is not None:
+            out_lowp.copy_(self._bf(dres))
+            if colsum is not None:
+                colsum += out_lowp.float().sum(0)
         return dres
 
     # softmax(scale q k^T + mask) v  (TF:modeling_whisper.py:215-238), bf16 in/out, fp32 softmax

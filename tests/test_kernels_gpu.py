@@ -152,6 +152,12 @@ def test_layernorm(ops, ref, D, x_dtype):
     assert relerr(dg, rdg) < 1e-4 and relerr(db, rdb) < 1e-4
     out2 = ops.layernorm_bwd(dy, x, mu, rs, gamma, None, dg, db)
     assert relerr(out2, rout - dres) < 1e-4
+    # fused low-precision copy + column sums (bias gradient of the next branch)
+    lo, rlo = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16), torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    cs, rcs = torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
+    o3 = ops.layernorm_bwd(dy, x, mu, rs, gamma, dres.clone(), dg, db, out_lowp=lo, colsum=cs)
+    r3 = ref.layernorm_bwd(dy, x, rmu, rrs, gamma, dres.clone(), rdg, rdb, out_lowp=rlo, colsum=rcs)
+    assert relerr(o3, r3) < 1e-5 and relerr(lo, rlo) < 3e-3 and relerr(cs, rcs) < 1e-3
 
 
 ATTN_CASES = [
