@@ -108,8 +108,10 @@ class DistillationTrainer:
         """fp32 waveforms [B, 480000] on the device -> log-mel input_features [B, n_mels, 3000]."""
         return self.ops.logmel(audio, self.mel_filters)
 
-    def forward_backward(self, input_features, decoder_input_ids, labels, lr=None):
-        """One micro-batch: returns losses fp32[4] = (ce, kl, loss, n_valid) on the device (no host sync)."""
+    def forward_backward(self, input_features, decoder_input_ids, labels, zero_grad=True, sync_grads=True):
+        """One micro-batch: returns losses fp32[4] = (ce, kl, loss, n_valid) on the device (no host sync).
+        zero_grad=False accumulates onto the gradients already in the flat buffer and sync_grads=False skips the
+        all-reduce (gradient accumulation, `accelerator.accumulate` / DDP no_sync of run_distillation.py:1607)."""
         ops, S, T = self.ops, self.student, self.teacher
         B, Td = decoder_input_ids.shape
         input_features = input_features.to(torch.float32).contiguous()
@@ -128,16 +130,16 @@ class DistillationTrainer:
         losses = ops.distill_loss(logits_s[:R], logits_t[:R], labels_flat, self.sdims.vocab, self.temperature, 0.8,
                                   self.kl_weight, 1.0, True)
         del logits_t
-        S.zero_small_grads()
+        if zero_grad:
+            S.zero_small_grads()
         st = self.student_store
+        dp = self.reducer is not None and self.world > 1 and sync_grads
         denc = S.backward_decoder(dctx, logits_s, want_denc=not self.freeze_encoder)
         del logits_s, dctx
-        if self.reducer is not None and self.world > 1:
+        if dp:
             self.reducer.ready(st.train_start if self.freeze_encoder else st.dec_start, st.train_end)
         if not self.freeze_encoder:
-            S.backward_encoder(ectx, denc)
-            if self.reducer is not None and self.world > 1:
-                self.reducer.ready(st.train_start, st.dec_start)
+            S.backward_encoder(ectx, denc, on_ready=self.reducer.ready if dp else None)
         return losses
 
     def optimizer_step(self, lr=None):
@@ -148,7 +150,7 @@ class DistillationTrainer:
             self.reducer.wait()
         self.step_count += 1
         lo, hi = st.train_start, st.train_end
-        gm = 1.0 / self.world
+        gm = 1.0 / (self.world * getattr(self, "_accum", 1))
         self._sumsq.zero_()
         ops.sumsq(st.G[lo:hi], self._sumsq)
         for a, b, wd in self.segments:
@@ -161,6 +163,19 @@ class DistillationTrainer:
         losses = self.forward_backward(input_features, decoder_input_ids, labels)
         self.optimizer_step(lr)
         return losses
+
+    def train_step_accumulated(self, micro_batches, lr=None):
+        """Gradient accumulation over a list of (input_features, decoder_input_ids, labels): gradients are summed in
+        the flat buffer, all-reduced once (with the last micro-batch) and averaged over the micro-batches in the fused
+        AdamW, like accelerate's `accumulate` context (loss / gradient_accumulation_steps)."""
+        n = len(micro_batches)
+        out = []
+        for i, (f, d, l) in enumerate(micro_batches):
+            out.append(self.forward_backward(f, d, l, zero_grad=(i == 0), sync_grads=(i == n - 1)))
+        self._accum = n
+        self.optimizer_step(lr)
+        self._accum = 1
+        return torch.stack(out).mean(0)
 
     def grad_norm(self):
         return torch.sqrt(self._sumsq[0]) / self.world

@@ -470,8 +470,19 @@ class WhisperEngine:
             self._stok = self.ops.zeros((self.dims.vocab, self.dims.d_model), torch.float32)
         return self._stok
 
-    def backward_encoder(self, ctx, denc, accumulate=False):
-        """denc: fp32 [R, D] gradient w.r.t. the encoder output (encoder_last_hidden_state)."""
+    def param_range(self, prefix):
+        """[lo, hi) of the flat buffers covered by the trainable parameters whose name starts with `prefix`."""
+        st = self.st
+        offs = [(o, o + _rup(int(torch.tensor(shape).prod()), 64)) for n, (o, shape, _) in st.entries.items()
+                if n.startswith(prefix) and o >= st.train_start]
+        if not offs:
+            return None
+        return min(a for a, _ in offs), max(b for _, b in offs)
+
+    def backward_encoder(self, ctx, denc, accumulate=False, on_ready=None):
+        """denc: fp32 [R, D] gradient w.r.t. the encoder output (encoder_last_hidden_state).  on_ready(lo, hi) is
+        called as soon as the gradients of a flat-buffer range are final (layer by layer, top down) so that the
+        data-parallel all-reduce of that range can start while the layers below are still in their backward."""
         ops, st, d = self.ops, self.st, self.dims
         self._accumulate = accumulate
         B, T, R, D = ctx["B"], ctx["T"], ctx["R"], d.d_model
@@ -486,20 +497,33 @@ class WhisperEngine:
             dres, dy = self._layer_bwd(f"model.encoder.layers.{i}", ctx["layers"][i], dres, dy, B, L, 0, False, None,
                                        i > 0, below)
             ctx["layers"][i] = None
+            if on_ready is not None:
+                # everything above layer i-1's last parameter is final (fc2.bias of layer i-1 still receives the
+                # column sums emitted by this layer's last LayerNorm backward, so the cut is at layer i's first entry)
+                rng = self.param_range(f"model.encoder.layers.{i}.")
+                if rng is not None:
+                    hi = self._enc_ready_hi if hasattr(self, "_enc_ready_hi") and self._enc_ready_hi else \
+                        self.param_range("model.encoder.layer_norm.")[1]
+                    on_ready(rng[0], hi)
+                    self._enc_ready_hi = rng[0]
         # conv stem: x0 = gelu(conv2(a1)) + pos ; a1 = gelu(conv1(mel))
         dz2 = self.act(R, D)
         ops.gelu_bwd(dres, ctx["z2"], out=dz2[:R])
         gw2 = ops.zeros((D, 3 * D), torch.float32)
         ops.gemm(dz2, ctx["xcol2"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw2, atomic_acc=True)
-        ops.unpack_conv_grad(gw2, st.g["model.encoder.conv2.weight"], accumulate)
+        ops.unpack_conv_grad(gw2, st.g["model.encoder.conv2.weight"], True)
         ops.colsum(dz2[:R], st.g["model.encoder.conv2.bias"], accumulate=True)
         dxcol2 = ops.gemm(dz2[:R], st.conv2_packed, trans_b=True)
         dz1 = self.act(R1, D)
         ops.col2im_s2_gelu_bwd(dxcol2, ctx["z1"], B, T, out=dz1[:R1])
         gw1 = ops.zeros((D, st.kpad1), torch.float32)
         ops.gemm(dz1, ctx["xcol1"], trans_a=True, trans_b=True, out_dtype=torch.float32, out=gw1, atomic_acc=True)
-        ops.unpack_conv_grad(gw1, st.g["model.encoder.conv1.weight"], accumulate)
+        ops.unpack_conv_grad(gw1, st.g["model.encoder.conv1.weight"], True)
         ops.colsum(dz1[:R1], st.g["model.encoder.conv1.bias"], accumulate=True)
+        if on_ready is not None:
+            hi = self._enc_ready_hi if getattr(self, "_enc_ready_hi", None) else st.dec_start
+            on_ready(st.train_start, hi)
+        self._enc_ready_hi = None
 
     def zero_small_grads(self):
         """Bias / LayerNorm / embedding gradients are accumulated with atomics: zero the gradient buffer's trainable

@@ -113,3 +113,25 @@ def test_param_store_layout_and_state_dict_roundtrip():
     D = cfg_s.d_model
     assert torch.equal(av["wqkv"][D:2 * D].float(), s_sd["model.decoder.layers.0.self_attn.k_proj.weight"].bfloat16().float())
     assert av["bqkv"][D:2 * D].abs().max().item() == 0.0
+
+
+def test_gradient_accumulation_equals_mean_of_microbatch_gradients():
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(seed=8, B=2)
+    ops = RefOps("cpu", lowp=torch.float32)
+    f, d, l = batch["input_features"], batch["decoder_input_ids"], batch["labels"]
+    a = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+    b = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+    c = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+    a.forward_backward(f[:1], d[:1], l[:1])
+    b.forward_backward(f[1:], d[1:], l[1:])
+    mean_g = 0.5 * (a.student_store.G + b.student_store.G)
+    c.forward_backward(f[:1], d[:1], l[:1], zero_grad=True)
+    c.forward_backward(f[1:], d[1:], l[1:], zero_grad=False)
+    assert relerr(0.5 * c.student_store.G, mean_g) < 1e-6
+    # and the fused optimizer applies the 1/n average
+    ref = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+    ref.student_store.G.copy_(mean_g)
+    ref.optimizer_step()
+    d2 = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+    d2.train_step_accumulated([(f[:1], d[:1], l[:1]), (f[1:], d[1:], l[1:])])
+    assert relerr(d2.student_store.P, ref.student_store.P) < 1e-6
