@@ -25,7 +25,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "dwamd.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"),
+               os.path.join(HERE, "..", "include", "dwamd.h")]
     objs, procs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

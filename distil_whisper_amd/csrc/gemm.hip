@@ -14,46 +14,7 @@
 //     staged k-major and their MFMA fragments are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose read), so
 //     no transposed copies of activations or weights are ever materialised in HBM;
 //   * blockIdx is remapped so that each XCD (private 4 MiB L2) walks a contiguous range of output tiles.
-#include "common.h"
-#include "../../include/dwamd.h"
-
-struct GemmP {
-    const bf16* a;
-    const bf16* b;
-    void* c;
-    const float* bias;
-    bf16* z_out;
-    const bf16* zgrad;
-    const void* r;
-    long lda, ldb, ldc, ldz, ldzg, ldr;
-    int m, n, k;
-    int act, c_dtype, r_dtype, r_row_mod, round_res;
-    int tiles_n, nwg;      // output tiles
-    int strip;             // rasterisation strip width in tiles (see the kernel)
-    int split_k, atomic;   // K slices per tile (grid = nwg * split_k); atomic: C (f32) += v with atomics
-    int vec;               // all epilogue pointers / leading dimensions allow 4-wide vector access
-    long slice_stride;     // split-K without atomics: slice ks stores its partial tile at c + ks * slice_stride
-};
-
-// transposed (k-major) tile [64][BX]: fragment X^T[i = x + ...][k-slots] for one 16-deep k step
-template <int BX>
-__device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, int lane) {
-    constexpr int RB = BX * 2;
-    const int g = lane >> 4, p = lane & 15;
-    const int col = x + ((g & 1) << 4) + ((p & 3) << 2);
-    const int k0 = kk * 16 + ((g >> 1) << 3) + (p >> 2);
-    const int ls = col >> 3;
-    const int inb = (p & 1) << 3;
-    const int sw = ((p >> 2) & 3) << 2;  // (krow & 3) << 2 ; krow & 3 == p >> 2 for both reads
-    const char* a0 = tile + k0 * RB + ((ls ^ sw) << 4) + inb;
-    const char* a1 = a0 + 4 * RB;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)a0);
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)a1);
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
+#include "gemm_common.h"
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, int VAR>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
@@ -213,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
     auto compute = [&](int buf) {
         const char* tA = smem + buf * STAGE;
         const char* tB = tA + BM * 128;
-        if (VAR == 0 || VAR == 5 || VAR >= 6) {
+        if (VAR == 0) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 bf16x8 af[FM], bfr[FN];
@@ -258,7 +219,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                 constexpr int kk = decltype(kc)::value;
                 constexpr int cur = kk & 1;
                 if constexpr (kk < 3) load(std::integral_constant<int, kk + 1>{}, std::integral_constant<int, cur ^ 1>{});
-                if (VAR == 3) __builtin_amdgcn_s_setprio(1);
                 static_for<0, FM>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
                     static_for<0, FN>([&](auto jc) {
@@ -266,8 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cur][j], af[cur][i], acc[i][j], 0, 0, 0);
                     });
                 });
-                if (VAR == 3) __builtin_amdgcn_s_setprio(0);
-                if (VAR == 1 || VAR == 4) {
+                if (VAR == 1) {
                     // pin the interleave: LDS reads between consecutive MFMAs (DS_READ mask 0x100, MFMA 0x8)
 #pragma unroll
                     for (int q = 0; q < FM * FN; ++q) {
@@ -279,187 +238,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
         }
     };
 
+    // lock-step schedule: every wave prefetches its pieces of tile t+1, then computes tile t (one barrier per tile).
+    // Measured alternatives that did NOT pay on MI355X (kept out of the code): staging pieces
+    // interleaved between MFMA clusters, s_setprio around the clusters, a two-group ping-pong schedule, and a 4-stage
+    // ring of 32-deep stages with counted vmcnt across raw barriers.
     stage(0);
-    if (VAR < 4 || VAR == 6 || VAR == 7) {
-        // lock-step schedule: every wave prefetches its pieces of tile t+1, then computes tile t
-        for (int t = 0; t < nt; ++t) {
-            const int buf = t & 1;
-            wait_vm0();        // this wave's pieces of tile t have landed in LDS
-            __syncthreads();   // ... everybody's have; and everybody finished reading buffer buf^1 (tile t-1)
-            if (t + 1 < nt && VAR != 6) stage(buf ^ 1);     // VAR 6: ablation, no operand traffic in the loop
-            if (VAR != 7) compute(VAR == 6 ? 0 : buf);       // VAR 7: ablation, operand traffic only
-        }
-    } else if (VAR == 8) {
-        // ablation: MFMA only (operands loaded once into registers)
-        bf16x8 af[FM], bfr[FN];
-        wait_vm0();
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = frag_rows(smem, (wm0 >> 5) + i, 0, lane);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bfr[j] = frag_rows(smem + BM * 128, (wn0 >> 5) + j, 0, lane);
-        for (int t = 0; t < nt * 4; ++t) {
-            static_for<0, FM>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                static_for<0, FN>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                });
-            });
-        }
-    } else {
-        // ping-pong schedule: the two wave groups (upper / lower half of the tile rows; one wave of each group per
-        // SIMD) alternate between a compute phase and a memory phase, so that while one wave of a SIMD issues its
-        // LDS-DMA pieces of the next K tile and waits for them, the other one keeps the matrix pipe busy.
-        //   phase A: group 0 computes tile t          | group 1 issues its pieces of tile t+1
-        //   phase B: group 0 issues its pieces of t+1 | group 1 computes tile t
-        // Buffer (t+1)&1 was last read in phase B of iteration t-1 (closed by a barrier), and all pieces of tile t+1
-        // are waited for (vmcnt) by their issuing waves before the barrier that ends phase B.
-        const bool g0 = wave < NW / 2;
-        wait_vm0();
-        __syncthreads();
-        const int mine = g0 ? 0 : 1;
-        for (int ph = 0; ph < 2 * nt; ++ph) {  // single call site for compute/stage: no code (or register) duplication
-            const int t = ph >> 1;
-            const int buf = t & 1;
-            if ((ph & 1) == mine) compute(buf);
-            else if (t + 1 < nt) stage(buf ^ 1);
-            if (ph & 1) wait_vm0();
-            __syncthreads();
-        }
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        wait_vm0();        // this wave's pieces of tile t have landed in LDS
+        __syncthreads();   // ... everybody's have; and everybody finished reading buffer buf^1 (tile t-1)
+        if (t + 1 < nt) stage(buf ^ 1);
+        compute(buf);
     }
-
-    // ---- epilogue ----
-    // The MFMAs were issued as (B-fragment, A-fragment), so each 32x32 accumulator holds the TRANSPOSED output tile:
-    // lane&31 = output row, register r = output column (r&3) + 8*(r>>2) + 4*(lane>>5).  Every wave turns its
-    // accumulators into row-major order through a private LDS patch (32 rows x TN fp32, padded stride: conflict-free
-    // b128 writes), then walks it 4 rows x TN columns per instruction: every global access of the epilogue (C and Z
-    // stores, residual and GELU' loads, atomics) is 4-wide per lane and contiguous along the row across 16 lanes.
-    // (compile-time accumulator indices only: a runtime-indexed accumulator array would be demoted to scratch)
-    constexpr int PLD = TN + 4;                    // patch row stride in floats (TN = 64 -> 68: 8 rows x 4 banks)
-    constexpr int LPR = TN / 4;                    // lanes per row in the row-major walk
-    constexpr int RPI = 64 / LPR;                  // rows per instruction
-    __syncthreads();                               // every wave is done reading the operand tiles
-    float* patch = (float*)smem + wave * (32 * PLD);
-    const int hi = lane >> 5, ln = lane & 31;
-    const bool plain = !p.bias && !p.z_out && p.act == 0 && !p.zgrad && !p.r;
-    float* const cf = (float*)p.c + (long)ks * p.slice_stride;  // (fp32 outputs only; slice_stride = 0 otherwise)
-    const int pr = lane / LPR, pc = (lane % LPR) * 4;
-    const int n = n0 + wn0 + pc;
-    const bool n_in = n < p.n;
-    const bool full = p.vec && n + 3 < p.n;
-    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n_in) {
-        if (full) b4 = *(const f32x4*)(p.bias + n);
-        else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (n + e < p.n) b4[e] = p.bias[n + e];
-        }
-    }
-    static_for<0, FM>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        static_for<0, FN>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            static_for<0, 4>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                f32x4 v4;
-                v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1];
-                v4[2] = acc[i][j][g * 4 + 2]; v4[3] = acc[i][j][g * 4 + 3];
-                *(f32x4*)(patch + ln * PLD + j * 32 + g * 8 + hi * 4) = v4;
-            });
-        });
-        // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads below)
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {  // fully unrolled: all loads of a 32-row slab are in flight at once
-            const int rl = it * RPI + pr;
-            const int m = m0 + wm0 + i * 32 + rl;
-            const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
-            if (m >= p.m || !n_in) continue;
-            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-            if (p.atomic) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < p.n) atomicAdd(cf + (long)m * p.ldc + n + e, v[e]);
-                continue;
-            }
-            const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
-            if (full) {
-                if (!plain) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                    if (p.z_out) {
-                        bf16x4 z4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
-                        *(bf16x4*)(p.z_out + (long)m * p.ldz + n) = z4;
-                    }
-                    if (p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
-                            const f32x2 g2 = gelu_fast2(x2);
-                            v[e] = g2[0]; v[e + 1] = g2[1];
-                        }
-                    }
-                    if (p.zgrad) {
-                        const bf16x4 z4 = *(const bf16x4*)(p.zgrad + (long)m * p.ldzg + n);
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            f32x2 x2; x2[0] = bf2f(z4[e]); x2[1] = bf2f(z4[e + 1]);
-                            const f32x2 g2 = gelu_grad_fast2(x2);
-                            v[e] *= g2[0]; v[e + 1] *= g2[1];
-                        }
-                    }
-                    if (p.r) {
-                        float rv[4];
-                        if (p.r_dtype == DW_F32) {
-                            const f32x4 r4 = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) rv[e] = r4[e];
-                        } else {
-                            const bf16x4 r4 = *(const bf16x4*)((const bf16*)p.r + (long)rr * p.ldr + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) rv[e] = bf2f(r4[e]);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
-                    }
-                }
-                if (p.c_dtype == DW_F32) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = v[e];
-                    *(f32x4*)(cf + (long)m * p.ldc + n) = o;
-                } else {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-                    *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
-                }
-            } else {
-                // ragged / unaligned columns: scalar path
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int nn = n + e;
-                    if (nn >= p.n) continue;
-                    float x = v[e];
-                    if (!plain) {
-                        x += b4[e];
-                        if (p.z_out) p.z_out[(long)m * p.ldz + nn] = f2bf(x);
-                        if (p.act == 1) x = gelu_fast(round_bf16(x));
-                        if (p.zgrad) x *= gelu_grad_fast(bf2f(p.zgrad[(long)m * p.ldzg + nn]));
-                        if (p.r) {
-                            const float rv = p.r_dtype == DW_F32 ? ((const float*)p.r)[(long)rr * p.ldr + nn]
-                                                                 : bf2f(((const bf16*)p.r)[(long)rr * p.ldr + nn]);
-                            x = (p.round_res ? round_bf16(x) : x) + rv;
-                        }
-                    }
-                    if (p.c_dtype == DW_F32) cf[(long)m * p.ldc + nn] = x;
-                    else ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x);
-                }
-            }
-        }
-    });
+    gemm_epilogue<FM, FN, TN>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
     __syncthreads();  // the LDS patches are reused as operand buffers by the next job
   }  // job loop
 }
@@ -570,17 +361,8 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     if (tile == 256) {
-        switch (g_gemm_variant) {
-            case 1: return launch_tile<256, 256, 2, 4, 1>(p, g->trans_a, g->trans_b, s);
-            case 2: return launch_tile<256, 256, 2, 4, 2>(p, g->trans_a, g->trans_b, s);
-            case 3: return launch_tile<256, 256, 2, 4, 3>(p, g->trans_a, g->trans_b, s);
-            case 4: return launch_tile<256, 256, 2, 4, 4>(p, g->trans_a, g->trans_b, s);
-            case 5: return launch_tile<256, 256, 2, 4, 5>(p, g->trans_a, g->trans_b, s);
-            case 6: return launch_tile<256, 256, 2, 4, 6>(p, g->trans_a, g->trans_b, s);
-            case 7: return launch_tile<256, 256, 2, 4, 7>(p, g->trans_a, g->trans_b, s);
-            case 8: return launch_tile<256, 256, 2, 4, 8>(p, g->trans_a, g->trans_b, s);
-            default: return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
-        }
+        if (g_gemm_variant == 0) return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
+        return launch_tile<256, 256, 2, 4, 1>(p, g->trans_a, g->trans_b, s);
     }
     return launch_tile<128, 128, 2, 2, 0>(p, g->trans_a, g->trans_b, s);
 }

@@ -1,0 +1,179 @@
+// Shared pieces of the bf16 MFMA GEMM kernel (gemm.hip): parameter block, k-major fragment fetch, fused epilogue.
+#pragma once
+#include "common.h"
+#include "../../include/dwamd.h"
+
+struct GemmP {
+    const bf16* a;
+    const bf16* b;
+    void* c;
+    const float* bias;
+    bf16* z_out;
+    const bf16* zgrad;
+    const void* r;
+    long lda, ldb, ldc, ldz, ldzg, ldr;
+    int m, n, k;
+    int act, c_dtype, r_dtype, r_row_mod, round_res;
+    int tiles_n, nwg;      // output tiles
+    int strip;             // rasterisation strip width in tiles (see the kernel)
+    int split_k, atomic;   // K slices per tile (grid = nwg * split_k); atomic: C (f32) += v with atomics
+    int vec;               // all epilogue pointers / leading dimensions allow 4-wide vector access
+    long slice_stride;     // split-K without atomics: slice ks stores its partial tile at c + ks * slice_stride
+};
+
+// transposed (k-major) tile [64][BX]: fragment X^T[i = x + ...][k-slots] for one 16-deep k step
+template <int BX>
+__device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, int lane) {
+    constexpr int RB = BX * 2;
+    const int g = lane >> 4, p = lane & 15;
+    const int col = x + ((g & 1) << 4) + ((p & 3) << 2);
+    const int k0 = kk * 16 + ((g >> 1) << 3) + (p >> 2);
+    const int ls = col >> 3;
+    const int inb = (p & 1) << 3;
+    const int sw = ((p >> 2) & 3) << 2;  // (krow & 3) << 2 ; krow & 3 == p >> 2 for both reads
+    const char* a0 = tile + k0 * RB + ((ls ^ sw) << 4) + inb;
+    const char* a1 = a0 + 4 * RB;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_t*)a1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+
+template <int FM, int FN, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
+                                              int m0, int wm0, int n0, int wn0, int ks) {
+    // ---- epilogue ----
+    // The MFMAs were issued as (B-fragment, A-fragment), so each 32x32 accumulator holds the TRANSPOSED output tile:
+    // lane&31 = output row, register r = output column (r&3) + 8*(r>>2) + 4*(lane>>5).  Every wave turns its
+    // accumulators into row-major order through a private LDS patch (32 rows x TN fp32, padded stride: conflict-free
+    // b128 writes), then walks it 4 rows x TN columns per instruction: every global access of the epilogue (C and Z
+    // stores, residual and GELU' loads, atomics) is 4-wide per lane and contiguous along the row across 16 lanes.
+    // (compile-time accumulator indices only: a runtime-indexed accumulator array would be demoted to scratch)
+    constexpr int PLD = TN + 4;                    // patch row stride in floats (TN = 64 -> 68: 8 rows x 4 banks)
+    constexpr int LPR = TN / 4;                    // lanes per row in the row-major walk
+    constexpr int RPI = 64 / LPR;                  // rows per instruction
+    __syncthreads();                               // every wave is done reading the operand tiles
+    float* patch = (float*)smem + wave * (32 * PLD);
+    const int hi = lane >> 5, ln = lane & 31;
+    const bool plain = !p.bias && !p.z_out && p.act == 0 && !p.zgrad && !p.r;
+    float* const cf = (float*)p.c + (long)ks * p.slice_stride;  // (fp32 outputs only; slice_stride = 0 otherwise)
+    const int pr = lane / LPR, pc = (lane % LPR) * 4;
+    const int n = n0 + wn0 + pc;
+    const bool n_in = n < p.n;
+    const bool full = p.vec && n + 3 < p.n;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && n_in) {
+        if (full) b4 = *(const f32x4*)(p.bias + n);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (n + e < p.n) b4[e] = p.bias[n + e];
+        }
+    }
+    static_for<0, FM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<0, FN>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            static_for<0, 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                f32x4 v4;
+                v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1];
+                v4[2] = acc[i][j][g * 4 + 2]; v4[3] = acc[i][j][g * 4 + 3];
+                *(f32x4*)(patch + ln * PLD + j * 32 + g * 8 + hi * 4) = v4;
+            });
+        });
+        // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads below)
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {  // fully unrolled: all loads of a 32-row slab are in flight at once
+            const int rl = it * RPI + pr;
+            const int m = m0 + wm0 + i * 32 + rl;
+            const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
+            if (m >= p.m || !n_in) continue;
+            float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+            if (p.atomic) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.n) atomicAdd(cf + (long)m * p.ldc + n + e, v[e]);
+                continue;
+            }
+            const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
+            if (full) {
+                if (!plain) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                    if (p.z_out) {
+                        bf16x4 z4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
+                        *(bf16x4*)(p.z_out + (long)m * p.ldz + n) = z4;
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
+                            const f32x2 g2 = gelu_fast2(x2);
+                            v[e] = g2[0]; v[e + 1] = g2[1];
+                        }
+                    }
+                    if (p.zgrad) {
+                        const bf16x4 z4 = *(const bf16x4*)(p.zgrad + (long)m * p.ldzg + n);
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            f32x2 x2; x2[0] = bf2f(z4[e]); x2[1] = bf2f(z4[e + 1]);
+                            const f32x2 g2 = gelu_grad_fast2(x2);
+                            v[e] *= g2[0]; v[e + 1] *= g2[1];
+                        }
+                    }
+                    if (p.r) {
+                        float rv[4];
+                        if (p.r_dtype == DW_F32) {
+                            const f32x4 r4 = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rv[e] = r4[e];
+                        } else {
+                            const bf16x4 r4 = *(const bf16x4*)((const bf16*)p.r + (long)rr * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) rv[e] = bf2f(r4[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
+                    }
+                }
+                if (p.c_dtype == DW_F32) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[e];
+                    *(f32x4*)(cf + (long)m * p.ldc + n) = o;
+                } else {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                    *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
+                }
+            } else {
+                // ragged / unaligned columns: scalar path
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int nn = n + e;
+                    if (nn >= p.n) continue;
+                    float x = v[e];
+                    if (!plain) {
+                        x += b4[e];
+                        if (p.z_out) p.z_out[(long)m * p.ldz + nn] = f2bf(x);
+                        if (p.act == 1) x = gelu_fast(round_bf16(x));
+                        if (p.zgrad) x *= gelu_grad_fast(bf2f(p.zgrad[(long)m * p.ldzg + nn]));
+                        if (p.r) {
+                            const float rv = p.r_dtype == DW_F32 ? ((const float*)p.r)[(long)rr * p.ldr + nn]
+                                                                 : bf2f(((const bf16*)p.r)[(long)rr * p.ldr + nn]);
+                            x = (p.round_res ? round_bf16(x) : x) + rv;
+                        }
+                    }
+                    if (p.c_dtype == DW_F32) cf[(long)m * p.ldc + nn] = x;
+                    else ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x);
+                }
+            }
+        }
+    });
+}
