@@ -23,6 +23,7 @@ struct AttnP {
     const bf16* d_o; float* delta; bf16* dq; bf16* dk; bf16* dv;
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Lq, Lk;
+    long q_rows, kv_rows;  // rows between consecutive batches in memory (= Lq / Lk unless reading a padded KV cache)
     float scale;
 };
 
@@ -66,9 +67,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
     const int q = qb0 + wave * 32 + ln;          // this lane's query (column of S^T)
     const bool q_ok = q < p.Lq;
     const int qc = q_ok ? q : p.Lq - 1;
-    const bf16* Q = p.q + (long)b * p.Lq * p.ldq + h * 64;
-    const bf16* K = p.k + (long)b * p.Lk * p.ldk + h * 64;
-    const bf16* V = p.v + (long)b * p.Lk * p.ldv + h * 64;
+    const bf16* Q = p.q + (long)b * p.q_rows * p.ldq + h * 64;
+    const bf16* K = p.k + (long)b * p.kv_rows * p.ldk + h * 64;
+    const bf16* V = p.v + (long)b * p.kv_rows * p.ldv + h * 64;
 
     bf16x8 qf[4];
 #pragma unroll
@@ -159,10 +160,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
             }
     }
     const float inv = 1.0f / l_run;
-    bf16* O = p.o + (long)b * p.Lq * p.ldo + h * 64;
+    bf16* O = p.o + (long)b * p.q_rows * p.ldo + h * 64;
     store_t(O, p.ldo, q, q_ok, 0, hi, o[0], inv);
     store_t(O, p.ldo, q, q_ok, 1, hi, o[1], inv);
-    if (q_ok && hi == 0) p.lse[((long)b * p.H + h) * p.Lq + q] = m_run * p.scale + __logf(l_run);
+    if (p.lse && q_ok && hi == 0) p.lse[((long)b * p.H + h) * p.Lq + q] = m_run * p.scale + __logf(l_run);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -391,17 +392,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 
 static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
 
+extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
+                              int Lk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_batch_rows,
+                              int64_t kv_batch_rows, int causal, float scale, void* stream);
+
 extern "C" int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
                            int Lk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int causal, float scale,
                            void* stream) {
+    if (!lse) return DW_EINVAL;
+    return dw_attn_fwd_ex(q, k, v, o, lse, B, H, Lq, Lk, ldq, ldk, ldv, ldo, Lq, Lk, causal, scale, stream);
+}
+
+extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
+                              int Lk, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_batch_rows,
+                              int64_t kv_batch_rows, int causal, float scale, void* stream) {
     DW_CLEAR_ERR();
-    if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
+    if (!q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
+    if (q_batch_rows < Lq || kv_batch_rows < Lk) return DW_EINVAL;
     if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || (ldo & 3)) return DW_EINVAL;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7)) return DW_EINVAL;
     AttnP p = {};
     p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
+    p.q_rows = q_batch_rows; p.kv_rows = kv_batch_rows;
     dim3 grid((Lq + 127) / 128, H, B), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, p);

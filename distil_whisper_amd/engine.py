@@ -373,6 +373,61 @@ class WhisperEngine:
             ctx.update(x_final=x, mu=mu, rs=rs, hf=hf)
         return logits, ctx
 
+    # ---- incremental decoding with a KV cache (TF:modeling_whisper.py:312-335, EncoderDecoderCache) -----------------
+    def decode_init(self, enc_out, B, max_len):
+        """Per decoder layer: the static cross-attention K/V projected once from the encoder output, and an empty
+        self-attention K/V cache laid out [B][max_len][2D] that the attention kernel reads in place (batch pitch =
+        max_len rows)."""
+        ops, st, d = self.ops, self.st, self.dims
+        D, Re = d.d_model, B * d.max_src
+        cache = {"B": B, "max_len": max_len, "t": 0, "cross": [], "self": []}
+        for i in range(d.dec_layers):
+            cv = st.attn_views(f"model.decoder.layers.{i}.encoder_attn")
+            kv = ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:])
+            cache["cross"].append(kv)
+            cache["self"].append(ops.zeros((B * max_len, 2 * D), self.lowp))
+        return cache
+
+    def decode_step(self, ids_t, cache):
+        """One greedy-decoding step: ids_t int64 [B, 1] at position cache["t"] -> logits low-precision [B, ldv]."""
+        ops, st, d = self.ops, self.st, self.dims
+        B, t, ML = cache["B"], cache["t"], cache["max_len"]
+        D, H, Lk = d.d_model, d.heads, d.max_src
+        assert ids_t.shape == (B, 1) and t < ML and t < d.max_tgt
+        f32 = self.stream == torch.float32
+        tok = (st.p if f32 else st.s)["model.decoder.embed_tokens.weight"]
+        pos = (st.p if f32 else st.s)["model.decoder.embed_positions.weight"][t:t + 1]
+        x = ops.embed_fwd(ids_t.contiguous(), tok, pos, torch.float32 if f32 else self.lowp)
+        for i in range(d.dec_layers):
+            p = f"model.decoder.layers.{i}"
+            av = st.attn_views(f"{p}.self_attn")
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.self_attn_layer_norm.weight"],
+                                        st.p[f"{p}.self_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            qkv = ops.gemm(h, av["wqkv"], bias=av["bqkv"])
+            kvc = cache["self"][i]
+            kvc.view(B, ML, 2 * D)[:, t].copy_(qkv[:, D:])  # append this step's K/V (plumbing copy of B rows)
+            o, _ = ops.attn_fwd(qkv[:, :D], kvc[:, :D], kvc[:, D:], B, H, 1, t + 1, False, 0.125, kv_batch_rows=ML)
+            x = ops.gemm(o, av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            cv = st.attn_views(f"{p}.encoder_attn")
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
+                                        st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            q = ops.gemm(h, cv["wqkv"][:D], bias=cv["bqkv"][:D])
+            kv = cache["cross"][i]
+            o, _ = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, 1, Lk, False, 0.125)
+            x = ops.gemm(o, cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"],
+                                        1e-5, save_stats=False)
+            a = ops.gemm(h, st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
+            x = ops.gemm(a, st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
+                         out_dtype=self.stream)
+        hf, _, _ = ops.layernorm_fwd(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"],
+                                     1e-5, save_stats=False)
+        eo = st.entries["model.decoder.embed_tokens.weight"][0]
+        e_pad = st.S[eo:eo + self.ldv * D].view(self.ldv, D)
+        logits = ops.gemm(hf, e_pad)
+        cache["t"] = t + 1
+        return logits
+
     # ---- backward --------------------------------------------------------------------------------------------------
     def _bias_grad(self, name):
         return self.st.g[name] if self.st.is_trainable(name) else None

@@ -276,9 +276,13 @@ class WhisperForConditionalGeneration(nn.Module):
         return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc)
 
     @torch.no_grad()
-    def generate(self, input_features, max_new_tokens=32, decoder_start_ids=None, eos_token_id=None, **kwargs):
-        """Greedy decoding on the engine (prefix re-decode; the KV-cache step kernel is the next row of the scope
-        table)."""
+    def generate(self, input_features, max_new_tokens=32, decoder_start_ids=None, eos_token_id=None, use_cache=True,
+                 **kwargs):
+        """Greedy decoding (run_distillation.py:1524-1528 `generate_step`, run_eval.py:739) on the engine.  With
+        use_cache the decoder runs one token per step against a KV cache (static cross-attention K/V computed once,
+        self-attention K/V appended in place); use_cache=False re-decodes the whole prefix every step and exists as
+        the cross-check.  Beam search, timestamps rules and the long-form fallback logic of
+        TF:generation_whisper.py are outside this round's scope."""
         self._sync_shadow()
         eng, d = self.engine, self.dims
         B = input_features.shape[0]
@@ -286,10 +290,20 @@ class WhisperForConditionalGeneration(nn.Module):
         ids = torch.full((B, 1), d.decoder_start_token_id, dtype=torch.long, device=input_features.device) \
             if decoder_start_ids is None else decoder_start_ids.clone()
         done = torch.zeros(B, dtype=torch.bool, device=ids.device)
+        total = ids.shape[1] + max_new_tokens
+        if total > d.max_tgt:
+            raise ValueError(f"prompt + max_new_tokens = {total} exceeds max_target_positions = {d.max_tgt}")
+        cache = eng.decode_init(enc, B, total) if use_cache else None
+        if use_cache:
+            for j in range(ids.shape[1] - 1):          # feed the prompt (all but its last token) through the cache
+                eng.decode_step(ids[:, j:j + 1], cache)
         for _ in range(max_new_tokens):
             T = ids.shape[1]
-            logits, _ = eng.decode(ids.contiguous(), enc, save=False)
-            nxt = logits[: B * T, : d.vocab].view(B, T, -1)[:, -1].float().argmax(-1)
+            if use_cache:
+                nxt = eng.decode_step(ids[:, -1:], cache)[:, : d.vocab].float().argmax(-1)
+            else:
+                logits, _ = eng.decode(ids.contiguous(), enc, save=False)
+                nxt = logits[: B * T, : d.vocab].view(B, T, -1)[:, -1].float().argmax(-1)
             if eos_token_id is not None:
                 nxt = torch.where(done, torch.full_like(nxt, eos_token_id), nxt)
                 done |= nxt == eos_token_id

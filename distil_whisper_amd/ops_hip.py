@@ -40,6 +40,7 @@ _SIGS = {
     "dw_layernorm_bwd": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_attn_fwd": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
+    "dw_attn_fwd_ex": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 6 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_bwd": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_distill_loss": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float,
                          C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -283,15 +284,17 @@ class HipOps:
                                             self._stream()), "layernorm_bwd")
         return dres
 
-    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None):
+    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None, kv_batch_rows=None):
+        """kv_batch_rows: rows between consecutive batches of k/v in memory (a padded KV cache), default Lk."""
         for t in (q, k, v):
             assert t.dtype == torch.bfloat16 and t.stride(1) == 1
         o = self.empty((B * Lq, H * 64), torch.bfloat16) if out is None else out
         assert o.dtype == torch.bfloat16 and o.stride(1) == 1 and o.shape == (B * Lq, H * 64)
         lse = self.empty((B, H, Lq), torch.float32)
         e0 = self._t0()
-        self._chk(self.lib.dw_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Lq, Lk, q.stride(0), k.stride(0),
-                                       v.stride(0), o.stride(0), int(causal), float(scale), self._stream()), "attn_fwd")
+        self._chk(self.lib.dw_attn_fwd_ex(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Lq, Lk, q.stride(0), k.stride(0),
+                                          v.stride(0), o.stride(0), Lq, Lk if kv_batch_rows is None else kv_batch_rows,
+                                          int(causal), float(scale), self._stream()), "attn_fwd")
         self._t1(e0, "attn_fwd", 4.0 * B * H * Lq * Lk * 64)
         return o, lse
 

@@ -101,6 +101,11 @@ int dw_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const floa
  * bit-identical to scale=0.125 here (power of two). */
 int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int causal, float scale, void* stream);
+/* Same kernel with explicit batch pitches (rows between consecutive batches of q/o and of k/v): reads a padded KV
+ * cache in place during greedy decoding (TF:modeling_whisper.py:312-335 EncoderDecoderCache).  lse may be NULL. */
+int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
+                   int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_batch_rows, int64_t kv_batch_rows,
+                   int causal, float scale, void* stream);
 /* delta f32 [B][H][Lq] scratch.  dq/dk/dv bf16 with row strides lddq/lddk/lddv. */
 int dw_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                 float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int64_t ldq, int64_t ldk,

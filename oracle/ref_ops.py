@@ -123,7 +123,10 @@ class RefOps:
     def _heads(t, B, L, H):
         return t.reshape(B, L, H, 64).permute(0, 2, 1, 3).float()
 
-    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None):
+    def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None, kv_batch_rows=None):
+        if kv_batch_rows is not None and kv_batch_rows != Lk:  # padded KV cache: batch b starts at row b*kv_batch_rows
+            k = k.reshape(B, kv_batch_rows, -1)[:, :Lk].reshape(B * Lk, -1)
+            v = v.reshape(B, kv_batch_rows, -1)[:, :Lk].reshape(B * Lk, -1)
         qh, kh, vh = self._heads(q, B, Lq, H), self._heads(k, B, Lk, H), self._heads(v, B, Lk, H)
         s = (qh @ kh.transpose(-1, -2)) * scale
         if causal:

@@ -153,8 +153,9 @@ def test_drop_in_module_and_feature_extractor_on_gpu(ops):
     for n in ("model.decoder.layers.0.fc1.weight", "model.encoder.layers.1.self_attn.v_proj.weight",
               "model.decoder.embed_tokens.weight", "model.encoder.conv2.weight"):
         assert relerr(model.get_parameter(n).grad, params[n].grad) < 0.1, n
-    ids = model.generate(feats.cuda(), max_new_tokens=3)
-    assert ids.shape == (2, 4)
+    ids = model.generate(feats.cuda(), max_new_tokens=8, use_cache=True)
+    ids2 = model.generate(feats.cuda(), max_new_tokens=8, use_cache=False)
+    assert ids.shape == (2, 9) and torch.equal(ids, ids2)  # KV-cache decode == prefix re-decode
 
 
 def test_large_v3_loss_matches_cpu_oracle(ops):

@@ -91,10 +91,27 @@ def test_error_behaviour_mirrors_reference():
         model(input_features=feats, labels=torch.zeros(2, 449, dtype=torch.long))
 
 
-def test_greedy_generate_runs():
+def test_greedy_generate_kv_cache_equals_prefix_redecode():
     cfg_s, s_sd, model, feats, ids, labels = build()
-    out = model.generate(feats, max_new_tokens=4)
-    assert out.shape == (2, 5) and int(out[0, 0]) == cfg_s.decoder_start_token_id
+    a = model.generate(feats, max_new_tokens=6, use_cache=True)
+    b = model.generate(feats, max_new_tokens=6, use_cache=False)
+    assert a.shape == (2, 7) and int(a[0, 0]) == cfg_s.decoder_start_token_id
+    assert torch.equal(a, b)
+    # with a prompt
+    prompt = torch.tensor([[cfg_s.decoder_start_token_id, 5, 9], [cfg_s.decoder_start_token_id, 7, 3]])
+    c = model.generate(feats, max_new_tokens=3, decoder_start_ids=prompt, use_cache=True)
+    e = model.generate(feats, max_new_tokens=3, decoder_start_ids=prompt, use_cache=False)
+    assert torch.equal(c, e) and torch.equal(c[:, :3], prompt)
+    # and the cached logits equal the teacher-forced forward logits at the same positions
+    eng = model.engine
+    enc, _ = eng.encode(feats, save=False)
+    full, _ = eng.decode(c[:, :-1].contiguous(), enc, save=False)
+    cache = eng.decode_init(enc, 2, c.shape[1])
+    T = c.shape[1] - 1
+    for t in range(T):
+        step = eng.decode_step(c[:, t:t + 1], cache)[:, : cfg_s.vocab]
+        ref = full[: 2 * T, : cfg_s.vocab].view(2, T, -1)[:, t]
+        assert relerr(step, ref) < 1e-5
 
 
 def test_collator_matches_oracle_and_lr_schedule():
