@@ -77,7 +77,8 @@ class GradReducer:
 class DistillationTrainer:
     def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
-                 share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None):
+                 share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None,
+                 overlap_teacher=True):
         self.ops = ops
         self.sdims, self.tdims = WhisperDims.from_any(student_dims), WhisperDims.from_any(teacher_dims)
         frozen = []
@@ -100,6 +101,10 @@ class DistillationTrainer:
         self.reducer = GradReducer(st.G, process_group) if st.G is not None else None
         self.world = self.reducer.world if self.reducer else 1
         self.mel_filters = mel_filters
+        # the frozen teacher forward is independent of the student forward until the loss: run it on a second HIP
+        # stream so that its kernels fill the tails (partially filled last rounds of workgroups) of the student's
+        self.overlap_teacher = overlap_teacher and self.student_store.P.is_cuda
+        self._tstream = torch.cuda.Stream(device=self.student_store.P.device) if self.overlap_teacher else None
         self._sumsq = ops.zeros((1,), torch.float32)
         self.segments = st.adam_segments(weight_decay)
 
@@ -117,9 +122,22 @@ class DistillationTrainer:
         input_features = input_features.to(torch.float32).contiguous()
         decoder_input_ids = decoder_input_ids.contiguous()
         labels_flat = labels.reshape(-1).contiguous()
+        side = self._tstream if (self.overlap_teacher and not self.share_encoder) else None
+        if side is not None:
+            main = torch.cuda.current_stream(input_features.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                enc_t, _ = T.encode(input_features, save=False)
+                logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False)
+                del enc_t
+            for t_ in (input_features, decoder_input_ids):
+                t_.record_stream(side)
         enc_s, ectx = S.encode(input_features, save=not self.freeze_encoder)
         logits_s, dctx = S.decode(decoder_input_ids, enc_s, save=True)
-        if self.share_encoder:
+        if side is not None:
+            main.wait_stream(side)
+            logits_t.record_stream(main)
+        elif self.share_encoder:
             t_ids = shift_tokens_right(labels, self.tdims.pad_token_id, self.tdims.decoder_start_token_id)
             logits_t, _ = T.decode(t_ids, enc_s, save=False)
         else:

@@ -1,0 +1,33 @@
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distil_whisper_amd.ops_hip import HipOps
+from distil_whisper_amd.distill import DistillationTrainer
+from distil_whisper_amd import student_init as si
+dev = "cuda:0"
+ops = HipOps(dev)
+tdims = si.PRESETS["large-v3"]
+t_sd = si.random_state_dict(tdims, 0, dev)
+s_sd, sdims = si.student_from_teacher(t_sd, tdims, 32, 2)
+filt = torch.tensor(si.mel_filter_bank(128), dtype=torch.float32, device=dev).contiguous()
+tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, mel_filters=filt)
+del t_sd, s_sd
+B, T = 32, 447
+audio = 0.1 * torch.randn(B, 480000, device=dev)
+ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
+dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
+def step():
+    return tr.train_step(tr.features(audio), dec_in, labels)
+step(); torch.cuda.synchronize()
+res = {True: [], False: []}
+for r in range(4):
+    for ov in (False, True):
+        tr.overlap_teacher = ov
+        l = step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): l = step()
+        torch.cuda.synchronize()
+        res[ov].append((time.perf_counter() - t0) / 3 * 1e3)
+    print(r, "loss", float(l[2]), flush=True)
+for ov in (False, True):
+    print("overlap", ov, " ".join(f"{x:.1f}" for x in res[ov]))
+print("max mem GiB", torch.cuda.max_memory_allocated() / 2**30)
