@@ -8,6 +8,13 @@ def rnd(shape, s=1.0): return (torch.randn(shape, device="cuda") * s).bfloat16()
 shapes = [("fwd N=1280 K=1280", B*1500, 1280, 1280, False, False), ("fwd N=5120 K=1280", B*1500, 5120, 1280, False, False),
           ("fwd N=1280 K=5120", B*1500, 1280, 5120, False, False), ("dX N=5120 K=1280", B*1500, 5120, 1280, False, True),
           ("dW 5120x1280 K=48000", 5120, 1280, B*1500, True, True)]
+if os.environ.get("DW_MORE"):
+    shapes = [("qkv fwd", B*1500, 3840, 1280, False, False), ("conv2 fwd K=3840", B*1500, 1280, 3840, False, False),
+              ("dX qkv K=3840", B*1500, 1280, 3840, False, True), ("dX out K=1280 N=1280", B*1500, 1280, 1280, False, True),
+              ("dX fc1 K=5120 N=1280", B*1500, 1280, 5120, False, True),
+              ("dec qkv M=14304", B*447, 3840, 1280, False, False), ("dec fc1 M=14304", B*447, 5120, 1280, False, False),
+              ("lm head", B*447, 51904, 1280, False, False), ("lm head dX", B*447, 1280, 51904, False, True),
+              ("dW qkv 3840x1280", 3840, 1280, B*1500, True, True), ("dW out 1280x1280", 1280, 1280, B*1500, True, True)]
 variants = [int(v) for v in os.environ.get("DW_VARIANTS", "0,1,2,3").split(",")]
 KEY = int(os.environ.get("DW_KEY", "0"))
 for name, M, N, K, ta, tb in shapes:
