@@ -135,3 +135,31 @@ def test_gradient_accumulation_equals_mean_of_microbatch_gradients():
     d2 = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
     d2.train_step_accumulated([(f[:1], d[:1], l[:1]), (f[1:], d[1:], l[1:])])
     assert relerr(d2.student_store.P, ref.student_store.P) < 1e-6
+
+
+def test_freeze_embed_positions_and_recipe_layout():
+    """--freeze_embed_positions (run_distillation.py:1034-1040) + --freeze_encoder: frozen tensors leave the trainable
+    range, everything else still matches autograd."""
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(seed=4)
+    params = {}
+    for k, v in s_sd.items():
+        frozen = k.startswith("model.encoder.") or k == "model.decoder.embed_positions.weight"
+        params[k] = v.clone().requires_grad_(not frozen)
+    loss, metrics, *_ = wo.train_step(params, cfg_s, t_sd, cfg_t, batch, 2.0, 1.0, True)
+    loss.backward()
+    tr = DistillationTrainer(RefOps("cpu", lowp=torch.float32), s_sd, cfg_s, t_sd, cfg_t, freeze_encoder=True,
+                             share_encoder=True, freeze_embed_positions=True)
+    tr.teacher_store.load_state_dict(t_sd, round_bf16=False)
+    losses = tr.forward_backward(batch["input_features"], batch["decoder_input_ids"], batch["labels"])
+    assert abs(losses[2].item() - loss.item()) < 2e-5 * abs(loss.item())
+    st = tr.student_store
+    assert not st.is_trainable("model.decoder.embed_positions.weight")
+    assert st.dec_start == st.train_start  # only decoder-side tensors are trainable
+    for name, p in params.items():
+        if p.grad is None:
+            assert not st.is_trainable(name), name
+        else:
+            assert relerr(st.g[name], p.grad) < 2e-4, name
+    tr.optimizer_step()  # frozen range untouched
+    assert torch.equal(st.p["model.decoder.embed_positions.weight"], s_sd["model.decoder.embed_positions.weight"])
+    assert torch.equal(st.p["model.encoder.layers.0.fc1.weight"], s_sd["model.encoder.layers.0.fc1.weight"])
