@@ -141,17 +141,11 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        # per-launch HIP events need the kernels one after the other on one stream: the instrumented step runs without
-        # the two-stream teacher/student overlap (the timed region above keeps it)
-        saved_overlap, tr.overlap_teacher = tr.overlap_teacher, False
-        one_step()
-        torch.cuda.synchronize()
         ops.profile = {}
         one_step()
         torch.cuda.synchronize()
         prof = ops.collect_profile()
         ops.profile = None
-        tr.overlap_teacher = saved_overlap
         log("per-kernel-class ms (instrumented step): " + json.dumps(
             {k: {"n": v["n"], "ms": round(v["ms"], 2), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}))

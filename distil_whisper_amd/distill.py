@@ -78,7 +78,7 @@ class DistillationTrainer:
     def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
                  share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None,
-                 overlap_teacher=True):
+                 overlap_teacher=False):
         self.ops = ops
         self.sdims, self.tdims = WhisperDims.from_any(student_dims), WhisperDims.from_any(teacher_dims)
         frozen = []
@@ -101,8 +101,9 @@ class DistillationTrainer:
         self.reducer = GradReducer(st.G, process_group) if st.G is not None else None
         self.world = self.reducer.world if self.reducer else 1
         self.mel_filters = mel_filters
-        # the frozen teacher forward is independent of the student forward until the loss: run it on a second HIP
-        # stream so that its kernels fill the tails (partially filled last rounds of workgroups) of the student's
+        # optional: the frozen teacher forward is independent of the student forward until the loss and can run on a
+        # second HIP stream so that its kernels fill the tails of the student's (measured +0.6 % on 1 GPU; off by default
+        # so that per-kernel profiles of the step stay one-kernel-at-a-time)
         self.overlap_teacher = overlap_teacher and self.student_store.P.is_cuda
         self._tstream = torch.cuda.Stream(device=self.student_store.P.device) if self.overlap_teacher else None
         self._sumsq = ops.zeros((1,), torch.float32)
