@@ -55,7 +55,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     constexpr int PLD = TN + 4;                    // patch row stride in floats (TN = 64 -> 68: 8 rows x 4 banks)
     constexpr int LPR = TN / 4;                    // lanes per row in the row-major walk
     constexpr int RPI = 64 / LPR;                  // rows per instruction
-    __syncthreads();                               // every wave is done reading the operand tiles
+    constexpr int NIT = 32 / RPI;                  // row groups of a 32-row slab
     float* patch = (float*)smem + wave * (32 * PLD);
     const int hi = lane >> 5, ln = lane & 31;
     const bool plain = !p.bias && !p.z_out && p.act == 0 && !p.zgrad && !p.r;
@@ -64,6 +64,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     const int n = n0 + wn0 + pc;
     const bool n_in = n < p.n;
     const bool full = p.vec && n + 3 < p.n;
+    // Side inputs of the epilogue (z for GELU', residual r) come from HBM.  They are fetched into registers one
+    // 32-row slab ahead (the group consumed at (slab i, row group it) is re-issued for slab i+1 right away), with
+    // clamped addresses and no data-dependent branch around the loads: otherwise every row group is a serial
+    // load -> use -> store chain (the loads cannot be hoisted above the previous group's stores) and the whole
+    // memory latency is exposed 32 times per tile with the matrix pipe idle.
+    const bool pf_z = p.vec && p.n >= 4 && p.zgrad != nullptr, pf_r = p.vec && p.n >= 4 && p.r != nullptr;
+    const int npf = full ? n : 0;
+    bf16x4 zq[NIT];
+    f32x4 rq[NIT];                                 // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
+    auto side_load = [&](int i, auto itc) {
+        constexpr int it = decltype(itc)::value;
+        const int mm = min(m0 + wm0 + i * 32 + it * RPI + pr, p.m - 1);
+        if (pf_z) zq[it] = *(const bf16x4*)(p.zgrad + (long)mm * p.ldzg + npf);
+        if (pf_r) {
+            const int rr = p.r_row_mod > 0 ? (mm % p.r_row_mod) : mm;
+            if (p.r_dtype == DW_F32) rq[it] = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + npf);
+            else {
+                const f32x2 t = *(const f32x2*)((const bf16*)p.r + (long)rr * p.ldr + npf);
+                rq[it][0] = t[0]; rq[it][1] = t[1];
+            }
+        }
+    };
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && n_in) {
         if (full) b4 = *(const f32x4*)(p.bias + n);
@@ -72,6 +94,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             for (int e = 0; e < 4; ++e) if (n + e < p.n) b4[e] = p.bias[n + e];
         }
     }
+    // Two copies of the slab walk, with and without side inputs (block-uniform choice): the copy without them does
+    // not carry the prefetch registers through the GELU arithmetic.
+    auto walk = [&](auto side_c) {
+    constexpr bool SIDE = decltype(side_c)::value;
+    if constexpr (SIDE) static_for<0, NIT>([&](auto itc) { side_load(0, itc); });
+    __syncthreads();                               // every wave is done reading the operand tiles
     static_for<0, FM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         static_for<0, FN>([&](auto jc) {
@@ -85,20 +113,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             });
         });
         // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads below)
-#pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {  // fully unrolled: all loads of a 32-row slab are in flight at once
+        static_for<0, NIT>([&](auto itc) {
+            constexpr int it = decltype(itc)::value;
             const int rl = it * RPI + pr;
             const int m = m0 + wm0 + i * 32 + rl;
             const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
-            if (m >= p.m || !n_in) continue;
+            bf16x4 zs;
+            f32x4 rs;
+            if constexpr (SIDE) {
+                zs = zq[it]; rs = rq[it];
+                if constexpr (i + 1 < FM) side_load(i + 1, itc);
+            }
+            if (m >= p.m || !n_in) return;
             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
             if (p.atomic) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (n + e < p.n) atomicAdd(cf + (long)m * p.ldc + n + e, v[e]);
-                continue;
+                return;
             }
-            const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
             if (full) {
                 if (!plain) {
 #pragma unroll
@@ -117,11 +150,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                             v[e] = g2[0]; v[e + 1] = g2[1];
                         }
                     }
+                    if constexpr (SIDE) {
                     if (p.zgrad) {
-                        const bf16x4 z4 = *(const bf16x4*)(p.zgrad + (long)m * p.ldzg + n);
 #pragma unroll
                         for (int e = 0; e < 4; e += 2) {
-                            f32x2 x2; x2[0] = bf2f(z4[e]); x2[1] = bf2f(z4[e + 1]);
+                            f32x2 x2; x2[0] = bf2f(zs[e]); x2[1] = bf2f(zs[e + 1]);
                             const f32x2 g2 = gelu_grad_fast2(x2);
                             v[e] *= g2[0]; v[e + 1] *= g2[1];
                         }
@@ -129,16 +162,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                     if (p.r) {
                         float rv[4];
                         if (p.r_dtype == DW_F32) {
-                            const f32x4 r4 = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + n);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) rv[e] = r4[e];
+                            for (int e = 0; e < 4; ++e) rv[e] = rs[e];
                         } else {
-                            const bf16x4 r4 = *(const bf16x4*)((const bf16*)p.r + (long)rr * p.ldr + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) rv[e] = bf2f(r4[e]);
+                            const unsigned u0 = __float_as_uint(rs[0]), u1 = __float_as_uint(rs[1]);
+                            rv[0] = __uint_as_float(u0 << 16); rv[1] = __uint_as_float(u0 & 0xffff0000u);
+                            rv[2] = __uint_as_float(u1 << 16); rv[3] = __uint_as_float(u1 & 0xffff0000u);
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
+                    }
                     }
                 }
                 if (p.c_dtype == DW_F32) {
@@ -154,6 +187,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                 }
             } else {
                 // ragged / unaligned columns: scalar path
+                const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int nn = n + e;
@@ -174,6 +208,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                     else ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x);
                 }
             }
-        }
+        });
     });
+    };
+    if (pf_z || pf_r) walk(std::true_type{});
+    else walk(std::false_type{});
 }

@@ -111,6 +111,7 @@ class HipOps:
         self._window = torch.hann_window(400, periodic=True, dtype=torch.float64).to(torch.float32).to(self.device)
         self.profile = None       # set to {} to bracket every launch with HIP events on the launch stream
         self._prof_events = []
+        self.profile_detail = False   # keys of the GEMM entries carry shape + epilogue flavour (tools/step_breakdown.py)
 
     # ------------------------------------------------------------------------------------------------------------
     def _stream(self):
@@ -253,7 +254,14 @@ class HipOps:
         if ws is not None:
             self._chk(self.lib.dw_reduce_slices(ws.data_ptr(), M * N, g.split_k, out.data_ptr(), M * N, 1,
                                                 self._stream()), "reduce_slices")
-        self._t1(e0, f"gemm_t{g.tile}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}", 2.0 * M * N * K)
+        key = f"gemm_t{g.tile}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}"
+        if self.profile_detail:
+            key += (f" m{M} n{N} k{K} c{'f32' if out.dtype == torch.float32 else 'bf16'}"
+                    f"{' bias' if bias is not None else ''}{' act%d' % act if act else ''}{' z' if want_z else ''}"
+                    f"{' zg' if zgrad is not None else ''}"
+                    f"{' r' + ('f32' if residual.dtype == torch.float32 else 'bf16') if residual is not None else ''}"
+                    f"{' sk%d' % g.split_k if g.split_k else ''}")
+        self._t1(e0, key, 2.0 * M * N * K)
         return (out, z) if want_z else out
 
     def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):

@@ -1,0 +1,40 @@
+"""Per-shape / per-epilogue breakdown of the GEMM launches of one full distillation step (HIP events per launch).
+Writes a markdown table: which GEMM flavours of the step run furthest below the kernel's best rate."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distil_whisper_amd.ops_hip import HipOps
+from distil_whisper_amd.distill import DistillationTrainer
+from distil_whisper_amd import student_init as si
+dev = "cuda:0"
+ops = HipOps(dev)
+tdims = si.PRESETS["large-v3"]
+t_sd = si.random_state_dict(tdims, 0, dev)
+s_sd, sdims = si.student_from_teacher(t_sd, tdims, 32, 2)
+filt = torch.tensor(si.mel_filter_bank(128), dtype=torch.float32, device=dev).contiguous()
+tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, mel_filters=filt)
+del t_sd, s_sd
+B, T = int(os.environ.get("B", 32)), 447
+audio = 0.1 * torch.randn(B, 480000, device=dev)
+ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
+dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
+def step():
+    return tr.train_step(tr.features(audio), dec_in, labels)
+for _ in range(2): step()
+torch.cuda.synchronize()
+ops.profile_detail = True
+acc = {}
+for _ in range(2):
+    ops.profile = {}
+    step()
+    for k, d in ops.collect_profile().items():
+        a = acc.setdefault(k, {"n": 0, "ms": 0.0, "flops": 0.0})
+        a["n"] += d["n"]; a["ms"] += d["ms"]; a["flops"] += d["flops"]
+ops.profile = None
+rows = sorted(acc.items(), key=lambda kv: -kv[1]["ms"])
+tot = sum(d["ms"] for _, d in rows) / 2
+print(f"# per-flavour launch times of one step (B={B}); instrumented step = {tot:.1f} ms\n")
+print("| launch | calls/step | ms/step | avg us | TFLOP/s |\n|---|---|---|---|---|")
+for k, d in rows:
+    tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
+    print(f"| {k} | {d['n'] // 2} | {d['ms'] / 2:.2f} | {d['ms'] / d['n'] * 1e3:.1f} | {tf:.0f} |" if tf else
+          f"| {k} | {d['n'] // 2} | {d['ms'] / 2:.2f} | {d['ms'] / d['n'] * 1e3:.1f} | |")
