@@ -255,6 +255,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
   }  // job loop
 }
 
+bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b);   // gemm_skinny.hip
+int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
+
 static int g_gemm_persistent = 1;
 static int g_gemm_variant = 1;  // 1 = register double-buffered fragments with pinned MFMA/LDS interleave
 static int g_gemm_strip = 0;
@@ -355,11 +358,14 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         p.vec = v ? 1 : 0;
     }
     int tile = g->tile;
+    hipStream_t s = (hipStream_t)stream;
+    // decode regime (M = batch rows): weight-streaming kernel; tile = 16 requests it explicitly
+    if (tile == 16 && !dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return DW_EINVAL;
+    if ((tile == 0 || tile == 16) && dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return dw_gemm_skinny_launch(p, s);
     if (tile != 128 && tile != 256) {
         const long t256 = (long)((g->m + 255) / 256) * ((g->n + 255) / 256);
         tile = t256 >= 512 ? 256 : 128;
     }
-    hipStream_t s = (hipStream_t)stream;
     if (tile == 256) {
         if (g_gemm_variant == 0) return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
         return launch_tile<256, 256, 2, 4, 1>(p, g->trans_a, g->trans_b, s);

@@ -1,0 +1,137 @@
+// Skinny-M bf16 GEMM for the KV-cache decode step: C[M,N] = A[M,K] . W[N,K]^T with M = decode batch (<= 64 rows).
+//
+// Replaces the nn.Linear calls of one `generate` token step (TF:modeling_whisper.py:279-282, 444-445, 970 on the
+// cache branch 312-335; run_eval.py:739): q/k/v, out_proj, fc1, fc2 and the tied LM head with M = batch.
+//
+// This regime is pure weight streaming (every W byte is used M <= 64 times), so the kernel is laid out for
+// memory-level parallelism instead of tile reuse:
+//   * one workgroup per 16 output columns (W rows), its waves split K; a wave requests its WHOLE K slice of the
+//     16 weight rows up front as 16-byte loads straight in v_mfma_f32_16x16x32_bf16 operand layout (lane = row,
+//     8 consecutive k per lane; a 16-row x 64-byte footprint per load instruction, the workgroup's weights are one
+//     contiguous 16*K*2-byte range of HBM), so all of W is in flight at once across the grid;
+//   * the activations (M x K, L2 resident) are fetched in the same layout and fed as the other MFMA operand; the
+//     accumulators come out transposed (lane = activation row m, 4 consecutive n per lane) so the epilogue stores
+//     are 4-wide along N;
+//   * the per-wave partial sums meet in LDS; the fused epilogue (bias, exact GELU, residual, fp32/bf16 store) is the
+//     same arithmetic as the tile kernel's (gemm_common.h).
+#include "gemm_common.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int SK_MAXS = 10;   // 32-deep k steps a wave keeps in registers (10 x 16 B of W + as much of A per lane)
+constexpr int SK_MAXW = 16;   // waves per workgroup
+
+template <int MB>
+__global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p, int nw, int steps_total) {
+    extern __shared__ float red[];  // [nw][MB][64][4]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16;
+    const int r16 = lane & 15, g = lane >> 4;
+    // this wave's k steps: [s0, s0 + ns)
+    const int base = steps_total / nw, rem = steps_total - base * nw;
+    const int s0 = wave * base + (wave < rem ? wave : rem);
+    const int ns = base + (wave < rem ? 1 : 0);
+
+    int wrow = n0 + r16;
+    wrow = wrow < p.n ? wrow : p.n - 1;
+    const bf16* wp = p.b + (long)wrow * p.ldb + (long)s0 * 32 + g * 8;
+    bf16x8 wf[SK_MAXS];
+#pragma unroll
+    for (int s = 0; s < SK_MAXS; ++s)
+        if (s < ns) wf[s] = *(const bf16x8*)(wp + s * 32);
+
+    f32x4_t acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    static_for<0, MB>([&](auto mc) {
+        constexpr int mb = decltype(mc)::value;
+        int arow = mb * 16 + r16;
+        arow = arow < p.m ? arow : p.m - 1;
+        const bf16* ap = p.a + (long)arow * p.lda + (long)s0 * 32 + g * 8;
+        bf16x8 af[SK_MAXS];
+#pragma unroll
+        for (int s = 0; s < SK_MAXS; ++s)
+            if (s < ns) af[s] = *(const bf16x8*)(ap + s * 32);
+#pragma unroll
+        for (int s = 0; s < SK_MAXS; ++s)
+            if (s < ns) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[s], acc[mb], 0, 0, 0);
+    });
+    // acc[mb][r] = partial C[m = mb*16 + (lane & 15)][n = n0 + 4*(lane >> 4) + r]
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) *(f32x4_t*)(red + ((wave * MB + mb) * 64 + lane) * 4) = acc[mb];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MB * 64; idx += blockDim.x) {
+        const int mb = idx >> 6, l = idx & 63;
+        f32x4_t v4 = {0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < nw; ++w) {
+            const f32x4_t t = *(const f32x4_t*)(red + ((w * MB + mb) * 64 + l) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] += t[e];
+        }
+        const int m = mb * 16 + (l & 15);
+        const int n = n0 + 4 * (l >> 4);
+        if (m >= p.m || n >= p.n) continue;      // (n is a multiple of 4 and p.n of 16: all four columns are valid)
+        float v[4] = {v4[0], v4[1], v4[2], v4[3]};
+        if (p.bias) {
+            const f32x4_t b4 = *(const f32x4_t*)(p.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
+                const f32x2 g2 = gelu_fast2(x2);
+                v[e] = g2[0]; v[e + 1] = g2[1];
+            }
+        }
+        if (p.r) {
+            float rv[4];
+            if (p.r_dtype == DW_F32) {
+                const f32x4_t r4 = *(const f32x4_t*)((const float*)p.r + (long)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = r4[e];
+            } else {
+                const bf16x4 r4 = *(const bf16x4*)((const bf16*)p.r + (long)m * p.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rv[e] = bf2f(r4[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
+        }
+        if (p.c_dtype == DW_F32) {
+            f32x4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e];
+            *(f32x4_t*)((float*)p.c + (long)m * p.ldc + n) = o;
+        } else {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
+        }
+    }
+}
+
+// true when the problem fits this kernel (the caller falls back to the tile kernel otherwise)
+bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b) {
+    if (trans_a || trans_b || p.m > 64 || p.split_k > 1 || p.atomic || p.z_out || p.zgrad || p.r_row_mod > 0) return false;
+    if (!p.vec || (p.n & 15) || (p.k & 31) || p.k > SK_MAXS * SK_MAXW * 32) return false;
+    return true;
+}
+
+int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s) {
+    const int steps = p.k >> 5;
+    int nw = (steps + 9) / 10;                    // ~10 steps (640 B of each weight row) per wave
+    if (nw > SK_MAXW) nw = SK_MAXW;
+    if ((steps + nw - 1) / nw > SK_MAXS) return DW_EINVAL;
+    const int mb = (p.m + 15) / 16;
+    dim3 grid(p.n / 16), block(64 * nw);
+    const size_t lds = (size_t)nw * (mb == 3 ? 4 : mb) * 64 * 4 * sizeof(float);
+    if (mb == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, lds, s, p, nw, steps);
+    else if (mb == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, lds, s, p, nw, steps);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, block, lds, s, p, nw, steps);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}

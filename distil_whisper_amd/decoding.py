@@ -1,0 +1,108 @@
+"""Batched greedy KV-cache decoding on the engine, with the per-token launch sequence captured in HIP graphs.
+
+Reference behaviour: `model.generate(...)` as called by run_distillation.py:1524-1528 (`generate_step`) and
+run_eval.py:739 / 806-844 (`benchmark_gen`: fixed number of new tokens on random encoder input) with greedy search
+(`num_beams=1`, `top_k=0`): TF:generation_whisper.py:383 + the cache branches of TF:modeling_whisper.py:312-335, with
+the `SuppressTokensLogitsProcessor` / `SuppressTokensAtBeginLogitsProcessor` steps (TF:generation_whisper.py:1774-1812).
+
+One decoding step of the 2-layer student is ~30 kernel launches of a few microseconds each with M = batch rows, i.e.
+launch-latency bound when driven from Python.  Every token position t has fixed shapes (cache length t+1, position
+embedding row t), so the step for position t is captured once into a HIP graph and replayed for every later batch of
+chunks; all tensors the graphs touch (current ids, token matrix, done flags, K/V caches) are allocated once.
+"""
+import torch
+
+
+class GreedyDecoder:
+    def __init__(self, engine, batch, max_len, eos_token_id=None, suppress_tokens=None, begin_suppress_tokens=None,
+                 use_graphs=None, check_every=16):
+        self.eng, self.B, self.max_len = engine, int(batch), int(max_len)
+        d = engine.dims
+        if self.max_len > d.max_tgt:
+            raise ValueError(f"max_len = {max_len} exceeds max_target_positions = {d.max_tgt}")
+        dev = engine.ops.device
+        self.dev = dev
+        self.eos = eos_token_id
+        self.use_graphs = (torch.device(dev).type == "cuda") if use_graphs is None else bool(use_graphs)
+        self.check_every = int(check_every)
+        self.tokens = torch.zeros((self.B, self.max_len), dtype=torch.long, device=dev)
+        self.cur = torch.zeros((self.B, 1), dtype=torch.long, device=dev)
+        self.done = torch.zeros((self.B,), dtype=torch.bool, device=dev)
+        self.eos_fill = None if eos_token_id is None else torch.full((self.B,), eos_token_id, dtype=torch.long, device=dev)
+
+        def mask(ids):
+            if ids is None or len(ids) == 0:
+                return None
+            m = torch.zeros((d.vocab,), dtype=torch.float32, device=dev)
+            m[torch.as_tensor(list(ids), dtype=torch.long, device=dev)] = float("-inf")
+            return m
+        self.suppress = mask(suppress_tokens)
+        self.begin_suppress = mask(begin_suppress_tokens)
+        self.cache = None
+        self.graphs = {}
+        self.pool = None
+        self._warm = False
+
+    # mode 0: position t+1 is still inside the prompt (teacher forcing); 1: first generated token; 2: later tokens
+    def _step(self, t, mode):
+        eng, d = self.eng, self.eng.dims
+        self.cache["t"] = t
+        logits = eng.decode_step(self.cur, self.cache)
+        if mode == 0:
+            nxt = self.tokens[:, t + 1]
+        else:
+            sc = logits[:, : d.vocab].float()
+            if self.suppress is not None:
+                sc = sc + self.suppress
+            if mode == 1 and self.begin_suppress is not None:
+                sc = sc + self.begin_suppress
+            nxt = sc.argmax(-1)
+            if self.eos is not None:
+                nxt = torch.where(self.done, self.eos_fill, nxt)
+                self.done.logical_or_(nxt == self.eos)
+            self.tokens[:, t + 1].copy_(nxt)
+        self.cur.copy_(nxt.view(self.B, 1))
+
+    def _run_step(self, t, mode):
+        if not self.use_graphs:
+            self._step(t, mode)
+            return
+        g = self.graphs.get((t, mode))
+        if g is None:
+            if not self._warm:
+                # one eager step first: lazy initialisation inside torch must not happen under stream capture
+                keep = (self.cur.clone(), self.tokens.clone(), self.done.clone())
+                self._step(t, mode)
+                self.cur.copy_(keep[0]); self.tokens.copy_(keep[1]); self.done.copy_(keep[2])
+                torch.cuda.synchronize(self.dev)
+                self.pool = torch.cuda.graph_pool_handle()
+                self._warm = True
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool):
+                self._step(t, mode)
+            self.graphs[(t, mode)] = g
+        g.replay()
+
+    def run(self, enc_out, prompt_ids, max_new_tokens):
+        """enc_out: encoder output of `batch` chunks (engine layout, rows = batch * max_source_positions);
+        prompt_ids: int64 [batch, P] forced decoder prefix (P >= 1; position 0 = <|startoftranscript|>).
+        Returns int64 [batch, P + n] with n <= max_new_tokens (stops early once every row has produced EOS)."""
+        B, P = prompt_ids.shape
+        if B != self.B:
+            raise ValueError(f"decoder built for batch {self.B}, got {B}")
+        total = P + int(max_new_tokens)
+        if total > self.max_len:
+            raise ValueError(f"prompt + max_new_tokens = {total} exceeds the decoder's max_len = {self.max_len}")
+        self.cache = self.eng.decode_init(enc_out, B, self.max_len, cache=self.cache)
+        self.tokens.zero_()
+        self.tokens[:, :P].copy_(prompt_ids)
+        self.done.zero_()
+        self.cur.copy_(self.tokens[:, 0:1])
+        n = P
+        for t in range(total - 1):
+            mode = 0 if t + 1 < P else (1 if t + 1 == P else 2)
+            self._run_step(t, mode)
+            n = t + 2
+            if self.eos is not None and mode and (t + 2 - P) % self.check_every == 0 and bool(self.done.all()):
+                break
+        return self.tokens[:, :n].clone()

@@ -374,18 +374,21 @@ class WhisperEngine:
         return logits, ctx
 
     # ---- incremental decoding with a KV cache (TF:modeling_whisper.py:312-335, EncoderDecoderCache) -----------------
-    def decode_init(self, enc_out, B, max_len):
+    def decode_init(self, enc_out, B, max_len, cache=None):
         """Per decoder layer: the static cross-attention K/V projected once from the encoder output, and an empty
         self-attention K/V cache laid out [B][max_len][2D] that the attention kernel reads in place (batch pitch =
-        max_len rows)."""
+        max_len rows).  Passing a `cache` made by an earlier call with the same (B, max_len) refills its buffers in
+        place (their addresses are baked into captured HIP graphs, see decoding.GreedyDecoder)."""
         ops, st, d = self.ops, self.st, self.dims
         D, Re = d.d_model, B * d.max_src
-        cache = {"B": B, "max_len": max_len, "t": 0, "cross": [], "self": []}
+        if cache is None:
+            cache = {"B": B, "max_len": max_len, "t": 0, "cross": [None] * d.dec_layers,
+                     "self": [ops.zeros((B * max_len, 2 * D), self.lowp) for _ in range(d.dec_layers)]}
+        assert cache["B"] == B and cache["max_len"] == max_len
+        cache["t"] = 0
         for i in range(d.dec_layers):
             cv = st.attn_views(f"model.decoder.layers.{i}.encoder_attn")
-            kv = ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:])
-            cache["cross"].append(kv)
-            cache["self"].append(ops.zeros((B * max_len, 2 * D), self.lowp))
+            cache["cross"][i] = ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=cache["cross"][i])
         return cache
 
     def decode_step(self, ids_t, cache):

@@ -215,6 +215,7 @@ class WhisperForConditionalGeneration(nn.Module):
         sd = state_dict if state_dict is not None else random_state_dict(self.dims, seed, device=self.ops.device)
         self.store = ParamStore(self.ops, self.dims, sd, trainable=True, frozen_prefixes=tuple(frozen_prefixes))
         self.engine = WhisperEngine(self.ops, self.store, torch.float32)
+        self._decoders = {}
         self.model = _Model(self.dims)
         self.proj_out = nn.Linear(self.dims.d_model, self.dims.vocab, bias=False, device="meta")
         # re-point every parameter of the (meta) module tree at its view in the flat master buffer
@@ -276,34 +277,61 @@ class WhisperForConditionalGeneration(nn.Module):
         return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc)
 
     @torch.no_grad()
-    def generate(self, input_features, max_new_tokens=32, decoder_start_ids=None, eos_token_id=None, use_cache=True,
-                 **kwargs):
+    def generate(self, input_features=None, max_new_tokens=32, decoder_start_ids=None, eos_token_id=None,
+                 use_cache=True, use_graphs=False, suppress_tokens=None, begin_suppress_tokens=None,
+                 encoder_outputs=None, **kwargs):
         """Greedy decoding (run_distillation.py:1524-1528 `generate_step`, run_eval.py:739) on the engine.  With
         use_cache the decoder runs one token per step against a KV cache (static cross-attention K/V computed once,
-        self-attention K/V appended in place); use_cache=False re-decodes the whole prefix every step and exists as
-        the cross-check.  Beam search, timestamps rules and the long-form fallback logic of
-        TF:generation_whisper.py are outside this round's scope."""
+        self-attention K/V appended in place; decoding.GreedyDecoder), optionally with the per-position launch
+        sequence replayed from HIP graphs (use_graphs); use_cache=False re-decodes the whole prefix every step and
+        exists as the cross-check.  `encoder_outputs` (engine layout or [B, 1500, D]) skips the encoder, as
+        run_eval.py's benchmark_gen does (806-844).  Beam search, timestamp rules and the temperature-fallback logic
+        of TF:generation_whisper.py are outside this round's scope."""
         self._sync_shadow()
         eng, d = self.engine, self.dims
-        B = input_features.shape[0]
-        enc, _ = eng.encode(input_features.to(torch.float32).contiguous(), save=False)
-        ids = torch.full((B, 1), d.decoder_start_token_id, dtype=torch.long, device=input_features.device) \
+        if encoder_outputs is not None:
+            enc = encoder_outputs.last_hidden_state if hasattr(encoder_outputs, "last_hidden_state") else encoder_outputs
+            B = enc.shape[0] if enc.dim() == 3 else enc.shape[0] // d.max_src
+            enc = enc.reshape(-1, d.d_model).to(eng.stream).contiguous()
+            dev = enc.device
+        else:
+            B = input_features.shape[0]
+            dev = input_features.device
+            enc, _ = eng.encode(input_features.to(torch.float32).contiguous(), save=False)
+        ids = torch.full((B, 1), d.decoder_start_token_id, dtype=torch.long, device=dev) \
             if decoder_start_ids is None else decoder_start_ids.clone()
-        done = torch.zeros(B, dtype=torch.bool, device=ids.device)
         total = ids.shape[1] + max_new_tokens
         if total > d.max_tgt:
             raise ValueError(f"prompt + max_new_tokens = {total} exceeds max_target_positions = {d.max_tgt}")
-        cache = eng.decode_init(enc, B, total) if use_cache else None
         if use_cache:
-            for j in range(ids.shape[1] - 1):          # feed the prompt (all but its last token) through the cache
-                eng.decode_step(ids[:, j:j + 1], cache)
-        for _ in range(max_new_tokens):
+            from .decoding import GreedyDecoder
+            key = (B, total, eos_token_id, bool(use_graphs), tuple(suppress_tokens or ()),
+                   tuple(begin_suppress_tokens or ()))
+            dec = self._decoders.get(key)
+            if dec is None:
+                dec = GreedyDecoder(eng, B, total, eos_token_id=eos_token_id, suppress_tokens=suppress_tokens,
+                                    begin_suppress_tokens=begin_suppress_tokens, use_graphs=use_graphs,
+                                    check_every=16 if use_graphs else 1)
+                self._decoders = {key: dec}        # one live decoder (its graphs pin the K/V cache buffers)
+            return dec.run(enc, ids, max_new_tokens)
+        done = torch.zeros(B, dtype=torch.bool, device=ids.device)
+        sup = None
+        if suppress_tokens:
+            sup = torch.zeros(d.vocab, device=dev)
+            sup[torch.as_tensor(list(suppress_tokens), device=dev)] = float("-inf")
+        bsup = None
+        if begin_suppress_tokens:
+            bsup = torch.zeros(d.vocab, device=dev)
+            bsup[torch.as_tensor(list(begin_suppress_tokens), device=dev)] = float("-inf")
+        for step in range(max_new_tokens):
             T = ids.shape[1]
-            if use_cache:
-                nxt = eng.decode_step(ids[:, -1:], cache)[:, : d.vocab].float().argmax(-1)
-            else:
-                logits, _ = eng.decode(ids.contiguous(), enc, save=False)
-                nxt = logits[: B * T, : d.vocab].view(B, T, -1)[:, -1].float().argmax(-1)
+            logits, _ = eng.decode(ids.contiguous(), enc, save=False)
+            sc = logits[: B * T, : d.vocab].view(B, T, -1)[:, -1].float()
+            if sup is not None:
+                sc = sc + sup
+            if step == 0 and bsup is not None:
+                sc = sc + bsup
+            nxt = sc.argmax(-1)
             if eos_token_id is not None:
                 nxt = torch.where(done, torch.full_like(nxt, eos_token_id), nxt)
                 done |= nxt == eos_token_id

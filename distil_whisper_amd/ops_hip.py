@@ -205,7 +205,7 @@ class HipOps:
         g.trans_a, g.trans_b = int(trans_a), int(trans_b)
         g.act = int(act)
         g.c_dtype = _dt(out)
-        g.tile = int(tile) if tile else self.pick_tile(M, N)
+        g.tile = int(tile) if tile else (0 if M <= 64 else self.pick_tile(M, N))  # 0: library's choice (skinny-M)
         ws = None
         if atomic_acc:
             # out (fp32, contiguous) += A^T.B : weight-gradient form.  Few output tiles and a very long K: cut K into

@@ -72,7 +72,7 @@ typedef struct DwGemm {
     int32_t r_dtype;    /* DW_F32 / DW_BF16 */
     int32_t r_row_mod;  /* 0: R row = m; >0: R row = m %% r_row_mod (positional table broadcast) */
     int32_t round_res;  /* 1: round v to bf16 before adding R (autocast semantics) */
-    int32_t tile;       /* 0 auto, 128 or 256: force the block tile */
+    int32_t tile;       /* 0 auto, 128 or 256: force the block tile; 16: the skinny-M (m <= 64) weight-streaming kernel */
     int32_t split_k;    /* > 1: the K range is cut into that many slices, combined either by atomic_acc or by
                            storing fp32 partials at c + slice * slice_stride (then call dw_reduce_slices) */
     int32_t atomic_acc; /* 1: C (f32, plain epilogue) += result with float atomics (gradient accumulation) */

@@ -175,3 +175,50 @@ def test_large_v3_loss_matches_cpu_oracle(ops):
     assert abs(losses[0].item() - metrics["ce_loss"].item()) < 1e-3 * abs(metrics["ce_loss"].item()), losses
     assert abs(losses[2].item() - loss.item()) < 1e-3 * abs(loss.item()), (losses.tolist(), loss.item())
     assert torch.isfinite(tr.student_store.G).all()
+
+
+def test_graph_replayed_greedy_decode_and_longform_scheduler(ops):
+    """decoding.GreedyDecoder with HIP-graph replay of the token steps == the eager cached decode == prefix re-decode,
+    across two batches through the same graphs; the long-form scheduler on top of it == per-window generate +
+    stitching (run_eval.py:566-576 pipeline path)."""
+    from distil_whisper_amd.longform import LongFormTranscriber, chunk_spans, merge_sequences
+    from distil_whisper_amd.modeling import WhisperFeatureExtractor, WhisperForConditionalGeneration
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 71)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    model = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+    g = torch.Generator().manual_seed(4)
+    kw = dict(max_new_tokens=12, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6])
+    for rep in range(2):                       # second round replays the graphs captured in the first
+        feats = (torch.randn(4, cfg_s.n_mels, 3000, generator=g) * 0.5).cuda()
+        a = model.generate(feats, use_cache=True, use_graphs=True, **kw)
+        b = model.generate(feats, use_cache=True, use_graphs=False, **kw)
+        c = model.generate(feats, use_cache=False, **kw)
+        assert a.shape == (4, 13) and torch.equal(a, b) and torch.equal(a, c), rep
+    eos = int(a[0, 5])
+    a = model.generate(feats, use_cache=True, use_graphs=True, eos_token_id=eos, **kw)
+    c = model.generate(feats, use_cache=False, eos_token_id=eos, **kw)
+    n = min(a.shape[1], c.shape[1])
+    assert torch.equal(a[:, :n], c[:, :n]) and bool((a[:, n:] == eos).all())
+
+    fe = WhisperFeatureExtractor(feature_size=cfg_s.n_mels, ops=ops)
+    rng = np.random.default_rng(6)
+    audios = [0.1 * rng.standard_normal(n).astype(np.float32) for n in (1_300_000, 200_000)]
+    first_special = cfg_s.vocab - 8
+    got = {}
+    for graphs in (True, False):
+        tr = LongFormTranscriber(model, fe, batch_size=3, max_new_tokens=10, first_special_id=first_special,
+                                 use_graphs=graphs)
+        got[graphs] = tr(audios)
+    assert got[True] == got[False]
+    want = []
+    for a in audios:
+        seqs = []
+        for start, length, _, _, _ in chunk_spans(len(a), 480000, 80000, 80000):
+            f = fe(a[start:start + length], sampling_rate=16000, return_tensors="pt").input_features
+            ids = model.generate(f, max_new_tokens=10, use_cache=False)[0, 1:].tolist()
+            text = [t for t in ids if t < first_special]
+            if text:
+                seqs.append(text)
+        want.append(merge_sequences(seqs))
+    assert got[True] == want

@@ -105,6 +105,28 @@ def test_gemm_epilogues(ops, ref, tile):
     assert relerr(c, rc) < 6e-3
 
 
+@pytest.mark.parametrize("M", [1, 16, 17, 40, 64])
+@pytest.mark.parametrize("N,K", [(1280, 1280), (5120, 1280), (1280, 5120), (48, 64), (51904, 1280)])
+def test_gemm_skinny_decode_shapes(ops, ref, M, N, K):
+    """The weight-streaming kernel of the decode step (M = batch rows <= 64) against the restatement and against the
+    tile kernel, with every epilogue the decode step uses."""
+    a, w = rnd((M, K), 1.0, seed=30), rnd((N, K), 0.03, seed=31)
+    bias = rnd((N,), 1.0, torch.float32, seed=32)
+    c = ops.gemm(a, w, out_dtype=torch.float32, tile=16)
+    assert relerr(c, ref.gemm(a, w, out_dtype=torch.float32)) < 1e-5
+    assert relerr(c, ops.gemm(a, w, out_dtype=torch.float32, tile=128)) < 1e-5
+    c = ops.gemm(a, w, bias=bias, act=1, tile=16)
+    assert relerr(c, ref.gemm(a, w, bias=bias, act=1)) < 4e-3
+    for rdt in (torch.float32, torch.bfloat16):
+        res = rnd((M, N), 1.0, rdt, seed=33)
+        c = ops.gemm(a, w, bias=bias, residual=res, round_res=True, out_dtype=rdt)      # auto dispatch (M <= 64)
+        assert relerr(c, ref.gemm(a, w, bias=bias, residual=res, round_res=True, out_dtype=rdt)) < 4e-3
+    # strided activations / weights (views into larger buffers, as the fused QKV weight and the KV cache rows are)
+    big_a, big_w = rnd((M, K + 64), 1.0, seed=34), rnd((N + 16, K), 0.03, seed=35)
+    c = ops.gemm(big_a[:, 64:], big_w[16:], out_dtype=torch.float32, tile=16)
+    assert relerr(c, ref.gemm(big_a[:, 64:], big_w[16:], out_dtype=torch.float32)) < 1e-5
+
+
 @pytest.mark.parametrize("tile,split_k", [(128, 1), (128, 5), (256, 3), (0, 0)])
 def test_gemm_atomic_split_k(ops, ref, tile, split_k):
     """Weight-gradient form: out (fp32) += A^T . B over a long token dimension, K range split across workgroups."""

@@ -1,0 +1,119 @@
+"""Long-form scheduler (distil_whisper_amd/longform.py) and the graph-capable greedy decoder (decoding.py), CPU side:
+chunk windows and token stitching against known answers produced by the `transformers` functions the reference's
+pipeline path runs (tests/golden/longform.json, made by oracle/gen_golden_longform.py), and against those functions
+directly when `transformers` is importable; the transcriber end to end against per-window generate + stitching."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from distil_whisper_amd.longform import LongFormTranscriber, chunk_spans, merge_sequences
+from distil_whisper_amd.decoding import GreedyDecoder
+from distil_whisper_amd.modeling import WhisperFeatureExtractor, WhisperForConditionalGeneration
+from oracle import whisper_oracle as wo
+from oracle.ref_ops import RefOps
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "longform.json")))
+
+
+def test_chunk_spans_match_reference_chunk_iter():
+    for case in GOLD["chunks"]:
+        got = [list(s) for s in chunk_spans(*case["args"])]
+        assert got == case["spans"], case["args"]
+    # 5-minute clip, 30 s windows, 5 s strides: 15 windows per clip
+    assert len(chunk_spans(4800000, 480000, 80000, 80000)) == 15
+    with pytest.raises(ValueError, match="superior to stride"):
+        chunk_spans(1000, 100, 50, 50)
+
+
+def test_merge_sequences_match_reference_stitching():
+    for case in GOLD["merges"]:
+        assert merge_sequences(case["sequences"]) == case["merged"]
+    assert merge_sequences([]) == []
+
+
+def test_against_transformers_functions_directly():
+    tw = pytest.importorskip("transformers.models.whisper.tokenization_whisper")
+    asr = pytest.importorskip("transformers.pipelines.automatic_speech_recognition")
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        n_seq = int(rng.integers(1, 6))
+        base = rng.integers(0, 30, size=400).tolist()
+        seqs, pos = [], 0
+        for _ in range(n_seq):
+            w = int(rng.integers(1, 50))
+            seqs.append(base[max(0, pos - int(rng.integers(0, 12))): pos + w])
+            pos += w
+        assert merge_sequences(seqs) == list(tw._find_longest_common_sequence(seqs))
+
+    class FE:
+        sampling_rate = 16000
+
+        def __call__(self, chunk, **kw):
+            return {"n": len(chunk)}
+    for _ in range(40):
+        c = int(rng.integers(10, 300))
+        sl, sr = int(rng.integers(0, c // 3)), int(rng.integers(0, c // 3))
+        n = int(rng.integers(1, 2000))
+        ref = [(o["stride"], o["is_last"], o["n"]) for o in asr.chunk_iter(np.zeros(n, np.float32), FE(), c, sl, sr)]
+        got = [((length, l, r), last, length) for _, length, l, r, last in chunk_spans(n, c, sl, sr)]
+        assert got == ref, (n, c, sl, sr)
+
+
+def _model(seed=4):
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, seed)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    ops = RefOps("cpu", lowp=torch.float32)
+    model = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+    fe = WhisperFeatureExtractor(feature_size=cfg_s.n_mels, ops=ops)
+    return cfg_s, model, fe
+
+
+def test_greedy_decoder_matches_prefix_redecode_with_suppression_and_eos():
+    cfg, model, fe = _model()
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(3, cfg.n_mels, 3000, generator=g) * 0.5
+    ref = model.generate(feats, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6])
+    eos = int(ref[0, 3])              # a token the model really emits -> exercises the EOS fill
+    ref = model.generate(feats, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6],
+                         eos_token_id=eos)
+    enc, _ = model.engine.encode(feats, save=False)
+    dec = GreedyDecoder(model.engine, 3, 8, eos_token_id=eos, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6],
+                        use_graphs=False, check_every=1)
+    prompt = torch.full((3, 1), cfg.decoder_start_token_id, dtype=torch.long)
+    out = dec.run(enc, prompt, 7)
+    assert torch.equal(out, ref)
+    assert not bool(((out[:, 1:] >= 3) & (out[:, 1:] <= 5)).any()) and not bool((out[:, 1] == 6).any())
+    # the decoder is reusable: second batch through the same buffers
+    feats2 = torch.randn(3, cfg.n_mels, 3000, generator=g) * 0.5
+    enc2, _ = model.engine.encode(feats2, save=False)
+    ref2 = model.generate(feats2, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5],
+                          begin_suppress_tokens=[6], eos_token_id=eos)
+    assert torch.equal(dec.run(enc2, prompt, 7), ref2)
+    with pytest.raises(ValueError, match="exceeds the decoder's max_len"):
+        dec.run(enc, prompt, 9)
+
+
+def test_transcriber_equals_per_window_generate_plus_stitching():
+    cfg, model, fe = _model()
+    rng = np.random.default_rng(5)
+    audios = [0.1 * rng.standard_normal(n).astype(np.float32) for n in (1_000_000, 300_000, 480_000)]
+    first_special = cfg.vocab - 8
+    tr = LongFormTranscriber(model, fe, batch_size=2, chunk_length_s=30.0, max_new_tokens=6,
+                             first_special_id=first_special, use_graphs=False)
+    assert (tr.chunk_len, tr.stride_left, tr.stride_right) == (480000, 80000, 80000)
+    got = tr(audios)
+    want = []
+    for a in audios:
+        seqs = []
+        for start, length, _, _, _ in chunk_spans(len(a), 480000, 80000, 80000):
+            f = fe(a[start:start + length], sampling_rate=16000, return_tensors="pt").input_features
+            ids = model.generate(f, max_new_tokens=6, use_cache=False)[0, 1:].tolist()
+            text = [t for t in ids if t < first_special]
+            if text:
+                seqs.append(text)
+        want.append(merge_sequences(seqs))
+    assert got == want and len(got) == 3 and all(len(x) > 0 for x in got)
