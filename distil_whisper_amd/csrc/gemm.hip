@@ -17,14 +17,15 @@
 #include "gemm_common.h"
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, int VAR>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(64 * WM * WN, (BM == 128 ? 2 : 1) * WM * WN / 4) void gemm_kernel(const GemmP p) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int CA = (BM / 8) / NW;  // 1 KiB chunks per wave per stage (A)
     constexpr int CB = (BN / 8) / NW;
     constexpr int STAGE = (BM + BN) * 128;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    constexpr int PATCH = NW * 32 * (TN + 4) * 4;   // epilogue transposition patches (alias the operand buffers)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE > PATCH ? 2 * STAGE : PATCH];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmP p) {
         if (t + 1 < nt) stage(buf ^ 1);
         compute(buf);
     }
-    gemm_epilogue<FM, FN, TN>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
+    gemm_epilogue<FM, FN, TN, ((BM == 128 ? 2 : 1) * NW >= 16 ? 2 : 0)>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
     __syncthreads();  // the LDS patches are reused as operand buffers by the next job
   }  // job loop
 }
@@ -259,7 +260,7 @@ bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b);   // gemm_skin
 int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
 
 static int g_gemm_persistent = 1;
-static int g_gemm_variant = 1;  // 1 = register double-buffered fragments with pinned MFMA/LDS interleave
+static int g_gemm_variant = 3;  // 0/1: 8-wave 256 tile (1 = register double-buffered fragments); 2: 16-wave 256 tile; 3: + 8-wave 128 tile
 static int g_gemm_strip = 0;
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
@@ -368,7 +369,9 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     }
     if (tile == 256) {
         if (g_gemm_variant == 0) return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
+        if (g_gemm_variant >= 2) return launch_tile<256, 256, 4, 4, 0>(p, g->trans_a, g->trans_b, s);
         return launch_tile<256, 256, 2, 4, 1>(p, g->trans_a, g->trans_b, s);
     }
+    if (g_gemm_variant == 3) return launch_tile<128, 128, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
     return launch_tile<128, 128, 2, 2, 0>(p, g->trans_a, g->trans_b, s);
 }

@@ -42,7 +42,7 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, i
 }
 
 
-template <int FM, int FN, int TN>
+template <int FM, int FN, int TN, int PFDIST = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
                                               int m0, int wm0, int n0, int wn0, int ks) {
     // ---- epilogue ----
@@ -64,25 +64,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     const int n = n0 + wn0 + pc;
     const bool n_in = n < p.n;
     const bool full = p.vec && n + 3 < p.n;
-    // Side inputs of the epilogue (z for GELU', residual r) come from HBM.  They are fetched into registers one
-    // 32-row slab ahead (the group consumed at (slab i, row group it) is re-issued for slab i+1 right away), with
+    // Side inputs of the epilogue (z for GELU', residual r) come from HBM.  They are fetched into registers PFD row
+    // groups ahead (the slot consumed at a row group is re-issued right away for the group PFD further on), with
     // clamped addresses and no data-dependent branch around the loads: otherwise every row group is a serial
     // load -> use -> store chain (the loads cannot be hoisted above the previous group's stores) and the whole
     // memory latency is exposed 32 times per tile with the matrix pipe idle.
     const bool pf_z = p.vec && p.n >= 4 && p.zgrad != nullptr, pf_r = p.vec && p.n >= 4 && p.r != nullptr;
     const int npf = full ? n : 0;
-    bf16x4 zq[NIT];
-    f32x4 rq[NIT];                                 // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
-    auto side_load = [&](int i, auto itc) {
-        constexpr int it = decltype(itc)::value;
-        const int mm = min(m0 + wm0 + i * 32 + it * RPI + pr, p.m - 1);
-        if (pf_z) zq[it] = *(const bf16x4*)(p.zgrad + (long)mm * p.ldzg + npf);
+    // prefetch distance in row groups: a whole slab by default (2 waves per SIMD); the caller shortens it when four
+    // waves share a SIMD (128 registers per lane, and the other waves cover more of the latency)
+    constexpr int PFD = PFDIST > 0 ? (PFDIST < NIT ? PFDIST : NIT) : NIT;
+    bf16x4 zq[PFD];
+    f32x4 rq[PFD];                                 // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
+    auto side_load = [&](auto gc) {                // gc: linear row-group index = slab * NIT + group
+        constexpr int gi = decltype(gc)::value;
+        constexpr int slot = gi % PFD;
+        const int mm = min(m0 + wm0 + (gi / NIT) * 32 + (gi % NIT) * RPI + pr, p.m - 1);
+        if (pf_z) zq[slot] = *(const bf16x4*)(p.zgrad + (long)mm * p.ldzg + npf);
         if (pf_r) {
             const int rr = p.r_row_mod > 0 ? (mm % p.r_row_mod) : mm;
-            if (p.r_dtype == DW_F32) rq[it] = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + npf);
+            if (p.r_dtype == DW_F32) rq[slot] = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + npf);
             else {
                 const f32x2 t = *(const f32x2*)((const bf16*)p.r + (long)rr * p.ldr + npf);
-                rq[it][0] = t[0]; rq[it][1] = t[1];
+                rq[slot][0] = t[0]; rq[slot][1] = t[1];
             }
         }
     };
@@ -98,7 +102,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     // not carry the prefetch registers through the GELU arithmetic.
     auto walk = [&](auto side_c) {
     constexpr bool SIDE = decltype(side_c)::value;
-    if constexpr (SIDE) static_for<0, NIT>([&](auto itc) { side_load(0, itc); });
+    if constexpr (SIDE) static_for<0, PFD>([&](auto gc) { side_load(gc); });
     __syncthreads();                               // every wave is done reading the operand tiles
     static_for<0, FM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -121,8 +125,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             bf16x4 zs;
             f32x4 rs;
             if constexpr (SIDE) {
-                zs = zq[it]; rs = rq[it];
-                if constexpr (i + 1 < FM) side_load(i + 1, itc);
+                constexpr int gi = i * NIT + it;
+                zs = zq[gi % PFD]; rs = rq[gi % PFD];
+                if constexpr (gi + PFD < FM * NIT) side_load(std::integral_constant<int, gi + PFD>{});
             }
             if (m >= p.m || !n_in) return;
             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
