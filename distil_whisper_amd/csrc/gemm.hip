@@ -6,7 +6,9 @@
 //
 // Structure (CDNA4-first, not a warp-shaped port):
 //   * block tile BM x BN x 64, waves laid out WM x WN, every wave owns (BM/WM) x (BN/WN) made of 32x32 accumulators
-//     fed by v_mfma_f32_32x32x16_bf16 (64-lane wavefront, 16 fp32 accumulators per lane per 32x32 tile);
+//     fed by v_mfma_f32_32x32x16_bf16 (64-lane wavefront, 16 fp32 accumulators per lane per 32x32 tile); the default
+//     256x256 tile runs 16 waves (4x4, 64x64 per wave, <= 128 VGPRs): four resident waves per SIMD hide each
+//     other's barrier / vmcnt / LDS latency better than the 8-wave layout with software-pipelined fragments did;
 //   * operands go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered, one barrier per
 //     K-step; the LDS image is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address
 //     and undone on the fragment read (same involution on both sides);
