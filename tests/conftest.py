@@ -21,3 +21,24 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def _usable_cores():
+    """Cores this process may actually use (affinity mask and cgroup quota): the GPU box shows 256 logical cores
+    under a 16-core quota, and torch's default of one thread per visible core makes the CPU oracle crawl there."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_threads():
+    import torch
+
+    torch.set_num_threads(max(1, min(16, _usable_cores())))
+    yield

@@ -167,7 +167,6 @@ def test_large_v3_loss_matches_cpu_oracle(ops):
     b = wo.synthetic_batch(cfg_t, 1, seed=62, with_audio=False)
     feats = torch.randn(1, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(3)) * 0.5
     batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
     with torch.no_grad():
         loss, metrics, *_ = wo.train_step(s_sd, cfg_s, t_sd, cfg_t, batch)
     tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
