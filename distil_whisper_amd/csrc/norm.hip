@@ -189,10 +189,13 @@ extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, cons
     DW_CLEAR_ERR();
     if (!dy || !x || !mean || !rstd || !gamma || !dres || !dgamma || !dbeta) return DW_EINVAL;
     if (rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
-    int nb = (rows + 3) / 4;
-    if (nb > 1024) nb = 1024;
     hipStream_t s = (hipStream_t)stream;
     const int nv = ((cols >> 2) + 63) / 64;
+    // grid = exactly the workgroups that are resident at once (registers: 4 / 3 / 1 per CU for <=3 / 5 / 8 vectors
+    // per lane): a grid-stride loop over rows on a grid of 1.33 rounds left a third of the chip idle in the tail
+    int nb = (rows + 3) / 4;
+    const int resident = 256 * (nv <= 3 ? 4 : nv <= 5 ? 3 : 1);
+    if (nb > resident) nb = resident;
 #define LN_BWD(NVV)                                                                                                   \
     do {                                                                                                              \
         if (x_dtype == DW_BF16)                                                                                       \
