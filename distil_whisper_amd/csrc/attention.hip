@@ -57,7 +57,7 @@ __device__ __forceinline__ void store_t(bf16* base, long ld, long row, bool ok, 
 // forward: block = 4 waves x 32 queries; key/value tiles of 64 rows double-buffered in LDS
 // ---------------------------------------------------------------------------------------------------------------
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const AttnP p) {
+__global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const AttnP p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];  // [buf][K tile 8K | V tile 8K]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
