@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
 // backward dQ: stationary = 32 queries per wave (Q, dO fragments + lse, delta in registers); stream K, V tiles
 //   S^T = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T[d][q] += K^T . dS^T
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+template <bool CAUSAL, bool FS>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];
     const int lane = threadIdx.x & 63;
@@ -227,15 +227,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 
-    stage_tile64<4>(K, p.ldk, 0, p.Lk, smem, wave, lane);
-    stage_tile64<4>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
+    stage_tile64<4, FS>(K, p.ldk, 0, p.Lk, smem, wave, lane);
+    stage_tile64<4, FS>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         wait_vm0();
         __syncthreads();
         if (kt + 1 < nkt) {
-            stage_tile64<4>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
-            stage_tile64<4>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
+            stage_tile64<4, FS>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
+            stage_tile64<4, FS>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
         }
         const char* tK = smem + buf * 16384;
         const char* tV = tK + 8192;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
 //   S = Q.K^T, dP = dO.V^T  (rows = queries in registers, column = key = lane&31)
 //   dV^T[d][key] += dO^T . P,   dK^T[d][key] += Q^T . dS
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
+template <bool CAUSAL, bool FS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     // [buf][Q tile 8K | dO tile 8K | lse 64 f32 | delta 64 f32]
     constexpr int STG = 16384 + 512;
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
 
     auto stage = [&](int qt, int buf) {
         char* base = smem + buf * 17408;
-        stage_tile64<4>(Q, p.ldq, qt * 64, p.Lq, base, wave, lane);
-        stage_tile64<4>(DO, p.lddo, qt * 64, p.Lq, base + 8192, wave, lane);
+        stage_tile64<4, FS>(Q, p.ldq, qt * 64, p.Lq, base, wave, lane);
+        stage_tile64<4, FS>(DO, p.lddo, qt * 64, p.Lq, base + 8192, wave, lane);
         if (threadIdx.x < 128) {  // waves 0,1: 64 lse + 64 delta values through the same async path (4 B per lane)
             const int i = threadIdx.x & 63;
             int qi = qt * 64 + i;
@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     store_t(DV, p.lddv, key, k_ok, 1, hi, av[1], 1.0f);
 }
 
+int g_attn_bwd_stage = 1;  // bit 0: dq kernel, bit 1: dkv kernel use the 32-bit-offset tile staging (dw_debug_set key 3)
 static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
 
 extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
@@ -409,6 +410,7 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     DW_CLEAR_ERR();
     if (!q || !k || !v || !o || B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
     if (q_batch_rows < Lq || kv_batch_rows < Lk) return DW_EINVAL;
+    if ((int64_t)Lk * ldk >= (1LL << 31) || (int64_t)Lk * ldv >= (1LL << 31)) return DW_EINVAL;  // 32-bit tile offsets
     if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || (ldo & 3)) return DW_EINVAL;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7)) return DW_EINVAL;
     AttnP p = {};
@@ -433,6 +435,9 @@ extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const vo
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
     if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || check_ld(ldo) || check_ld(lddo)) return DW_EINVAL;
     if ((lddq & 3) || (lddk & 3) || (lddv & 3)) return DW_EINVAL;
+    if ((int64_t)Lk * ldk >= (1LL << 31) || (int64_t)Lk * ldv >= (1LL << 31) || (int64_t)Lq * ldq >= (1LL << 31) ||
+        (int64_t)Lq * lddo >= (1LL << 31))
+        return DW_EINVAL;  // 32-bit tile offsets
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 15) ||
         ((uintptr_t)d_o & 15) || ((uintptr_t)dq & 7) || ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7))
         return DW_EINVAL;
@@ -446,12 +451,15 @@ extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const vo
     hipLaunchKernelGGL(attn_delta_kernel, dim3((rows * 8 + 255) / 256), dim3(256), 0, s, p);
     DW_CHECK_LAUNCH();
     dim3 gq((Lq + 127) / 128, H, B), gk((Lk + 127) / 128, H, B), block(256);
+    const int fs = g_attn_bwd_stage;
     if (causal) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, block, 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, block, 0, s, p);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, block, 0, s, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), gk, block, 0, s, p);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, block, 0, s, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, block, 0, s, p);
+        if (fs & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, block, 0, s, p);
+        if (fs & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), gk, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), gk, block, 0, s, p);
     }
     DW_CHECK_LAUNCH();
     return DW_OK;

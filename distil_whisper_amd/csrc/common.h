@@ -127,16 +127,31 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int cb, int rowbase0
 
 // Stage a [64 rows][64 bf16] tile (8 KiB) with NW waves: 8 chunks of 1 KiB (= 8 rows each).
 // Rows past nrows are clamped to the last valid row (callers mask the results).
-template <int NW>
+// Full tiles take the cheap path: a 32-bit per-lane element offset (its lane part is loop invariant, its row0 part
+// is scalar) on top of the uniform base -- the generic 64-bit row * stride product cost ~10 VALU instructions per
+// load in kernels whose VALU is the bottleneck (attention).  Callers guarantee nrows * row_stride < 2^31.
+template <int NW, bool FAST = true>
 __device__ __forceinline__ void stage_tile64(const bf16* base, long row_stride, int row0, int nrows, char* lds,
                                              int wave, int lane) {
+    const int ld = (int)row_stride;
+    if (FAST && row0 + 64 <= nrows) {
+        const int off0 = __builtin_amdgcn_readfirstlane(row0 * ld);
 #pragma unroll
-    for (int c = wave; c < 8; c += NW) {
-        const int row = c * 8 + (lane >> 3);
-        const int ls = (lane & 7) ^ swz7(row);
-        int grow = row0 + row;
-        grow = grow < nrows ? grow : nrows - 1;
-        glds16(base + (long)grow * row_stride + ls * 8, lds + c * 1024);
+        for (int c = wave; c < 8; c += NW) {
+            const int row = c * 8 + (lane >> 3);
+            const int ls = (lane & 7) ^ swz7(row);
+            const unsigned off = (unsigned)(off0 + (row * ld + ls * 8));
+            glds16(base + off, lds + c * 1024);
+        }
+    } else {
+#pragma unroll
+        for (int c = wave; c < 8; c += NW) {
+            const int row = c * 8 + (lane >> 3);
+            const int ls = (lane & 7) ^ swz7(row);
+            int grow = row0 + row;
+            grow = grow < nrows ? grow : nrows - 1;
+            glds16(base + (unsigned)(grow * ld + ls * 8), lds + c * 1024);
+        }
     }
 }
 

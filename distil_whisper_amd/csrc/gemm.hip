@@ -261,6 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 ? 2 : 1) * WM * WN / 4) vo
 bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b);   // gemm_skinny.hip
 int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
 
+extern int g_attn_bwd_stage;  // attention.hip
 static int g_gemm_persistent = 1;
 static int g_gemm_variant = 3;  // 0/1: 8-wave 256 tile (1 = register double-buffered fragments); 2: 16-wave 256 tile; 3: + 8-wave 128 tile
 static int g_gemm_strip = 0;
@@ -268,6 +269,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
     if (key == 1) { g_gemm_strip = value; return DW_OK; }
     if (key == 2) { g_gemm_persistent = value; return DW_OK; }
+    if (key == 3) { g_attn_bwd_stage = value; return DW_OK; }
     return DW_EINVAL;
 }
 
