@@ -106,3 +106,54 @@ class GreedyDecoder:
             if self.eos is not None and mode and (t + 2 - P) % self.check_every == 0 and bool(self.done.all()):
                 break
         return self.tokens[:, :n].clone()
+
+
+def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_ids, max_new_tokens,
+                           num_assistant_tokens=5, eos_token_id=None):
+    """Speculative (assisted) greedy decoding: the small `assistant` engine drafts `num_assistant_tokens` tokens, the
+    `target` engine scores prefix + draft in ONE decoder pass and keeps the longest draft prefix that equals its own
+    greedy choices plus its next token -- the output is token-for-token what target-only greedy decoding produces.
+
+    Reference: run_eval.py:578-599, 706-707 (`assistant_model` of `generate`; the distilled student drafts for the
+    teacher and shares its encoder output) and flax/run_speculative_decoding.py:76-107.  target / assistant:
+    WhisperEngine; enc_*: their encoder outputs in engine layout (the same tensor when the encoders are shared);
+    prompt_ids int64 [B, P].  With a batch the accepted length is the minimum over the rows that are still running
+    (every emitted token is still each row's own greedy token).  Returns (ids [B, P + n], drafted, accepted)."""
+    dt, da = target.dims, assistant.dims
+    B = prompt_ids.shape[0]
+    ids = prompt_ids.clone()
+    total = prompt_ids.shape[1] + int(max_new_tokens)
+    if total > min(dt.max_tgt, da.max_tgt):
+        raise ValueError(f"prompt + max_new_tokens = {total} exceeds max_target_positions")
+    done = torch.zeros(B, dtype=torch.bool, device=ids.device)
+    drafted = accepted = 0
+
+    def greedy_rows(eng, d, seq, enc, first):
+        """argmax tokens of `eng` for positions first .. len(seq)-1 of seq (each predicts the next token): [B, n]"""
+        T = seq.shape[1]
+        logits, _ = eng.decode(seq.contiguous(), enc, save=False)
+        return logits[: B * T, : d.vocab].view(B, T, -1)[:, first:].float().argmax(-1)
+
+    while ids.shape[1] < total and not (eos_token_id is not None and bool(done.all())):
+        k = min(int(num_assistant_tokens), total - ids.shape[1] - 1)
+        draft = ids
+        for _ in range(k):                                   # the assistant drafts k tokens greedily
+            nxt = greedy_rows(assistant, da, draft, enc_assistant, draft.shape[1] - 1)[:, -1]
+            draft = torch.cat([draft, nxt[:, None]], 1)
+        P = ids.shape[1]
+        own = greedy_rows(target, dt, draft, enc_target, P - 1)  # [B, k + 1]: target's choice after each prefix
+        if k > 0:
+            agree = (own[:, :k] == draft[:, P:]) | done[:, None]
+            n_ok = int(agree.long().cumprod(1).sum(1).min().item())
+        else:
+            n_ok = 0
+        drafted += k
+        accepted += n_ok
+        new = own[:, : n_ok + 1]                             # accepted draft tokens (== own) + the target's next token
+        if eos_token_id is not None:
+            for j in range(new.shape[1]):
+                col = torch.where(done, torch.full_like(new[:, j], eos_token_id), new[:, j])
+                new[:, j] = col
+                done = done | (col == eos_token_id)
+        ids = torch.cat([ids, new], 1)
+    return ids, drafted, accepted

@@ -279,7 +279,7 @@ class WhisperForConditionalGeneration(nn.Module):
     @torch.no_grad()
     def generate(self, input_features=None, max_new_tokens=32, decoder_start_ids=None, eos_token_id=None,
                  use_cache=True, use_graphs=False, suppress_tokens=None, begin_suppress_tokens=None,
-                 encoder_outputs=None, **kwargs):
+                 encoder_outputs=None, assistant_model=None, num_assistant_tokens=5, **kwargs):
         """Greedy decoding (run_distillation.py:1524-1528 `generate_step`, run_eval.py:739) on the engine.  With
         use_cache the decoder runs one token per step against a KV cache (static cross-attention K/V computed once,
         self-attention K/V appended in place; decoding.GreedyDecoder), optionally with the per-position launch
@@ -303,6 +303,25 @@ class WhisperForConditionalGeneration(nn.Module):
         total = ids.shape[1] + max_new_tokens
         if total > d.max_tgt:
             raise ValueError(f"prompt + max_new_tokens = {total} exceeds max_target_positions = {d.max_tgt}")
+        if assistant_model is not None:
+            # speculative decoding (run_eval.py:578-599, 706-707): the assistant drafts, this model verifies; an
+            # assistant with this model's encoder dimensions re-uses the encoder output (the distilled student
+            # keeps a frozen copy of the teacher's encoder), otherwise it encodes the features itself
+            from .decoding import assisted_greedy_decode
+            if suppress_tokens or begin_suppress_tokens:
+                raise ValueError("assisted decoding does not take suppress_tokens / begin_suppress_tokens here")
+            assistant_model._sync_shadow()
+            ad = assistant_model.dims
+            if getattr(assistant_model, "share_encoder_output", None) or \
+                    (input_features is None and ad.d_model == d.d_model):
+                enc_a = enc.to(assistant_model.engine.stream)
+            else:
+                if input_features is None:
+                    raise ValueError("the assistant needs input_features (its encoder differs from this model's)")
+                enc_a, _ = assistant_model.engine.encode(input_features.to(torch.float32).contiguous(), save=False)
+            out, self.last_drafted, self.last_accepted = assisted_greedy_decode(
+                eng, assistant_model.engine, enc, enc_a, ids, max_new_tokens, num_assistant_tokens, eos_token_id)
+            return out
         if use_cache:
             from .decoding import GreedyDecoder
             key = (B, total, eos_token_id, bool(use_graphs), tuple(suppress_tokens or ()),

@@ -117,3 +117,29 @@ def test_transcriber_equals_per_window_generate_plus_stitching():
                 seqs.append(text)
         want.append(merge_sequences(seqs))
     assert got == want and len(got) == 3 and all(len(x) > 0 for x in got)
+
+
+def test_assisted_greedy_decoding_equals_target_greedy():
+    """Speculative decoding (run_eval.py:578-599): student drafts, teacher verifies -> exactly the teacher's greedy
+    output, for a good assistant (the teacher itself: everything accepted) and a poor one (unrelated weights)."""
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 11)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    ops = RefOps("cpu", lowp=torch.float32)
+    teacher = WhisperForConditionalGeneration(cfg_t, ops=ops, state_dict=t_sd)
+    student = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+    other = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=wo.student_from_teacher(
+        wo.init_state_dict(cfg_t, 12), cfg_t, 2, 1)[0])
+    feats = torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(2)) * 0.5
+    ref = teacher.generate(feats, max_new_tokens=9, use_cache=False)
+    for assistant, k in ((student, 4), (other, 3), (teacher, 5)):
+        out = teacher.generate(feats, max_new_tokens=9, assistant_model=assistant, num_assistant_tokens=k)
+        assert torch.equal(out, ref)
+        assert teacher.last_accepted <= teacher.last_drafted
+    assert teacher.last_accepted == teacher.last_drafted        # the teacher as its own assistant: all drafts accepted
+    eos = int(ref[0, 4])
+    ref_e = teacher.generate(feats, max_new_tokens=9, use_cache=False, eos_token_id=eos)
+    out_e = teacher.generate(feats, max_new_tokens=9, assistant_model=student, num_assistant_tokens=4, eos_token_id=eos)
+    n = min(ref_e.shape[1], out_e.shape[1])
+    assert torch.equal(out_e[:, :n], ref_e[:, :n])
+    assert bool((out_e[:, n:] == eos).all()) and bool((ref_e[:, n:] == eos).all())
