@@ -13,9 +13,49 @@ chunks; all tensors the graphs touch (current ids, token matrix, done flags, K/V
 import torch
 
 
+def apply_timestamp_rules(scores, tokens, n, begin_index, no_timestamps_token_id, eos_token_id,
+                          max_initial_timestamp_index=None):
+    """The decoding rules of `WhisperTimeStampLogitsProcessor` (TF:generation/logits_process.py; installed by
+    TF:generation_whisper.py:1774-1812 when `return_timestamps=True`, run_eval.py:690-739) on a whole batch without
+    host round trips: scores f32 [B, V] (modified copy returned), tokens int64 [B, >= n] of which the first n are
+    the sequence so far (prompt included), begin_index = length of the forced prefix.
+      * <|notimestamps|> is never sampled;
+      * timestamps come in pairs: after text+timestamp only a timestamp or EOS may follow, after two timestamps only
+        text; a timestamp may not be smaller than the last one emitted (nor repeat it when it closed a pair);
+      * the first sampled token must be a timestamp, at most `max_initial_timestamp_index` steps in;
+      * if the timestamps together are more probable than the most probable text token, a timestamp is sampled."""
+    sc = scores.clone()
+    B, V = sc.shape
+    tb = no_timestamps_token_id + 1
+    neg = float("-inf")
+    col = torch.arange(V, device=sc.device)[None, :]
+    sc[:, no_timestamps_token_id] = neg
+    L = n - begin_index
+    if L >= 1:
+        last_ts = tokens[:, n - 1] >= tb
+        pen_ts = tokens[:, n - 2] >= tb if L >= 2 else torch.ones_like(last_ts)
+        sc = sc.masked_fill((last_ts & pen_ts)[:, None] & (col >= tb), neg)
+        sc = sc.masked_fill((last_ts & ~pen_ts)[:, None] & (col < eos_token_id), neg)
+        seq = tokens[:, begin_index:n]
+        is_ts = seq >= tb
+        any_ts = is_ts.any(1)
+        pos = (is_ts.long() * torch.arange(1, L + 1, device=sc.device)[None, :]).max(1).values   # 1-based, 0 = none
+        last_val = seq.gather(1, (pos - 1).clamp(min=0)[:, None])[:, 0]
+        ts_last = torch.where(last_ts & ~pen_ts, last_val, last_val + 1)
+        sc = sc.masked_fill(any_ts[:, None] & (col >= tb) & (col < ts_last[:, None]), neg)
+    if L == 0:
+        sc = sc.masked_fill(col < tb, neg)
+        if max_initial_timestamp_index is not None:
+            sc = sc.masked_fill(col > tb + max_initial_timestamp_index, neg)
+    lp = torch.log_softmax(sc.float(), dim=-1)
+    ts_lp = lp[:, tb:].logsumexp(-1)
+    text_max = lp[:, :tb].max(-1).values
+    return sc.masked_fill((ts_lp > text_max)[:, None] & (col < tb), neg)
+
+
 class GreedyDecoder:
     def __init__(self, engine, batch, max_len, eos_token_id=None, suppress_tokens=None, begin_suppress_tokens=None,
-                 use_graphs=None, check_every=16):
+                 use_graphs=None, check_every=16, timestamp_rules=None):
         self.eng, self.B, self.max_len = engine, int(batch), int(max_len)
         d = engine.dims
         if self.max_len > d.max_tgt:
@@ -38,6 +78,10 @@ class GreedyDecoder:
             return m
         self.suppress = mask(suppress_tokens)
         self.begin_suppress = mask(begin_suppress_tokens)
+        # dict(begin_index=, no_timestamps_token_id=, max_initial_timestamp_index=) -> apply_timestamp_rules each step
+        self.timestamp_rules = timestamp_rules
+        if timestamp_rules is not None and eos_token_id is None:
+            raise ValueError("timestamp rules need eos_token_id")
         self.cache = None
         self.graphs = {}
         self.pool = None
@@ -56,6 +100,10 @@ class GreedyDecoder:
                 sc = sc + self.suppress
             if mode == 1 and self.begin_suppress is not None:
                 sc = sc + self.begin_suppress
+            if self.timestamp_rules is not None:
+                r = self.timestamp_rules
+                sc = apply_timestamp_rules(sc, self.tokens, t + 1, r["begin_index"], r["no_timestamps_token_id"],
+                                           self.eos, r.get("max_initial_timestamp_index"))
             nxt = sc.argmax(-1)
             if self.eos is not None:
                 nxt = torch.where(self.done, self.eos_fill, nxt)

@@ -279,7 +279,8 @@ class WhisperForConditionalGeneration(nn.Module):
     @torch.no_grad()
     def generate(self, input_features=None, max_new_tokens=32, decoder_start_ids=None, eos_token_id=None,
                  use_cache=True, use_graphs=False, suppress_tokens=None, begin_suppress_tokens=None,
-                 encoder_outputs=None, assistant_model=None, num_assistant_tokens=5, **kwargs):
+                 encoder_outputs=None, assistant_model=None, num_assistant_tokens=5, return_timestamps=False,
+                 no_timestamps_token_id=None, max_initial_timestamp_index=None, **kwargs):
         """Greedy decoding (run_distillation.py:1524-1528 `generate_step`, run_eval.py:739) on the engine.  With
         use_cache the decoder runs one token per step against a KV cache (static cross-attention K/V computed once,
         self-attention K/V appended in place; decoding.GreedyDecoder), optionally with the per-position launch
@@ -322,15 +323,25 @@ class WhisperForConditionalGeneration(nn.Module):
             out, self.last_drafted, self.last_accepted = assisted_greedy_decode(
                 eng, assistant_model.engine, enc, enc_a, ids, max_new_tokens, num_assistant_tokens, eos_token_id)
             return out
+        ts_rules = None
+        if return_timestamps:
+            # WhisperTimeStampLogitsProcessor (TF:generation_whisper.py:1774-1812); needs the vocabulary landmarks
+            if no_timestamps_token_id is None or eos_token_id is None:
+                raise ValueError("return_timestamps=True needs no_timestamps_token_id and eos_token_id")
+            if not use_cache:
+                raise ValueError("return_timestamps=True runs on the KV-cache decoder (use_cache=True)")
+            ts_rules = dict(begin_index=ids.shape[1], no_timestamps_token_id=int(no_timestamps_token_id),
+                            max_initial_timestamp_index=max_initial_timestamp_index)
+            use_graphs = False            # the rule kernels have not been exercised under stream capture yet
         if use_cache:
             from .decoding import GreedyDecoder
             key = (B, total, eos_token_id, bool(use_graphs), tuple(suppress_tokens or ()),
-                   tuple(begin_suppress_tokens or ()))
+                   tuple(begin_suppress_tokens or ()), None if ts_rules is None else tuple(sorted(ts_rules.items())))
             dec = self._decoders.get(key)
             if dec is None:
                 dec = GreedyDecoder(eng, B, total, eos_token_id=eos_token_id, suppress_tokens=suppress_tokens,
                                     begin_suppress_tokens=begin_suppress_tokens, use_graphs=use_graphs,
-                                    check_every=16 if use_graphs else 1)
+                                    check_every=16 if use_graphs else 1, timestamp_rules=ts_rules)
                 self._decoders = {key: dec}        # one live decoder (its graphs pin the K/V cache buffers)
             return dec.run(enc, ids, max_new_tokens)
         done = torch.zeros(B, dtype=torch.bool, device=ids.device)

@@ -143,3 +143,55 @@ def test_assisted_greedy_decoding_equals_target_greedy():
     n = min(ref_e.shape[1], out_e.shape[1])
     assert torch.equal(out_e[:, :n], ref_e[:, :n])
     assert bool((out_e[:, n:] == eos).all()) and bool((ref_e[:, n:] == eos).all())
+
+
+def test_timestamp_rules_match_transformers_processor():
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    import types
+    from distil_whisper_amd.decoding import apply_timestamp_rules
+    V, no_ts, eos, begin = 120, 60, 50, 3
+    tb = no_ts + 1
+    cfg = types.SimpleNamespace(no_timestamps_token_id=no_ts, eos_token_id=eos, bos_token_id=eos,
+                                max_initial_timestamp_index=7, _detect_timestamp_from_logprob=True)
+    proc = lp.WhisperTimeStampLogitsProcessor(cfg, begin_index=begin)
+    g = torch.Generator().manual_seed(0)
+    for trial in range(200):
+        B = 5
+        n = begin + int(torch.randint(0, 9, (1,), generator=g))
+        ids = torch.randint(0, eos, (B, n), generator=g)
+        # sprinkle timestamps (in non-decreasing order, as the rules themselves would produce) and some pairs
+        for b in range(B):
+            cur = tb
+            for j in range(begin, n):
+                u = float(torch.rand(1, generator=g))
+                if u < 0.45:
+                    cur = min(V - 1, cur + int(torch.randint(0, 4, (1,), generator=g)))
+                    ids[b, j] = cur
+        scores = torch.randn(B, V, generator=g) * (3.0 if trial % 2 else 0.3)
+        if trial % 3 == 0:
+            scores[:, tb:] += 2.0                 # makes the "timestamps more probable than text" branch fire
+        want = proc(ids, scores)
+        buf = torch.zeros(B, n + 4, dtype=torch.long)
+        buf[:, :n] = ids
+        got = apply_timestamp_rules(scores, buf, n, begin, no_ts, eos, 7)
+        assert torch.equal(torch.isinf(got), torch.isinf(want)), trial
+        assert torch.equal(got[~torch.isinf(got)], want[~torch.isinf(want)])
+
+
+def test_greedy_decoder_with_timestamp_rules_follows_them():
+    cfg, model, fe = _model()
+    V = cfg.vocab
+    no_ts, eos = V - 40, V - 60          # toy layout: text < eos < specials < <|notimestamps|> < timestamps
+    feats = torch.randn(2, cfg.n_mels, 3000, generator=torch.Generator().manual_seed(8)) * 0.5
+    enc, _ = model.engine.encode(feats, save=False)
+    prompt = torch.tensor([[cfg.decoder_start_token_id, 7]] * 2)
+    dec = GreedyDecoder(model.engine, 2, 14, eos_token_id=eos, use_graphs=False, check_every=1,
+                        timestamp_rules=dict(begin_index=2, no_timestamps_token_id=no_ts, max_initial_timestamp_index=5))
+    out = dec.run(enc, prompt, 12)
+    gen = out[:, 2:]
+    tb = no_ts + 1
+    assert bool((gen[:, 0] >= tb).all()) and bool((gen[:, 0] <= tb + 5).all())      # starts with a timestamp
+    assert not bool((gen == no_ts).any())
+    for row in gen.tolist():
+        ts = [t for t in row if t >= tb]
+        assert ts == sorted(ts)                                                    # never decreasing
