@@ -1,0 +1,90 @@
+"""Pseudo-labelling throughput path: teacher-only batched generate over 30 s packs.
+
+Reference: run_pseudo_labelling.py:632-673 (`concatenate_dataset`: consecutive samples of one speaker are appended
+until the next one would exceed `max_input_length` = 30 s; `condition_on_prev` marks a pack that continues the
+previous pack's speaker) and 861-996 (the teacher's `generate` over the packed batches under data parallelism, one
+process per GPU, each on its own shard).  Here the packs are gathered on the GPU straight into the log-mel kernel's
+[B, 480000] buffer and decoded by decoding.GreedyDecoder; sharding across ranks is by pack index (no collective).
+"""
+import numpy as np
+import torch
+
+from .decoding import GreedyDecoder
+
+
+def pack_plan(lengths, speaker_ids=None, max_input_length=480000):
+    """Greedy packing rule of `concatenate_dataset`: returns (packs, condition_on_prev) where packs[i] is the list of
+    sample indices concatenated into pack i.  A sample joins the current pack iff it has the pack's speaker and the
+    summed length stays <= max_input_length; otherwise it opens a new pack, flagged 1 when the speaker continues."""
+    n = len(lengths)
+    if n == 0:
+        return [], []
+    spk = [None] * n if speaker_ids is None else list(speaker_ids)
+    packs, cond = [[0]], [0]
+    cur_len, cur_spk = int(lengths[0]), spk[0]
+    for i in range(1, n):
+        same = spk[i] == cur_spk
+        if same and int(lengths[i]) + cur_len <= max_input_length:
+            packs[-1].append(i)
+            cur_len += int(lengths[i])
+        else:
+            packs.append([i])
+            cond.append(1 if same else 0)
+            cur_len, cur_spk = int(lengths[i]), spk[i]
+    return packs, cond
+
+
+def shard(items, rank, world):
+    """Contiguous per-rank shard of the pack list (what `accelerator.prepare(dataloader)` does for the reference)."""
+    per = (len(items) + world - 1) // world
+    return items[rank * per:(rank + 1) * per]
+
+
+class PseudoLabeller:
+    """audios (list of 1-D 16 kHz waveforms, each <= 30 s) -> (token id lists per pack, packs, condition_on_prev)."""
+
+    def __init__(self, model, feature_extractor, batch_size=16, max_new_tokens=255, prompt_ids=None, eos_token_id=None,
+                 timestamp_rules=None, use_graphs=None, rank=0, world=1):
+        self.model, self.fe = model, feature_extractor
+        self.B, self.max_new = int(batch_size), int(max_new_tokens)
+        self.rank, self.world = rank, world
+        d = model.dims
+        dev = model.ops.device
+        self.dev = dev
+        self.prompt = torch.as_tensor([d.decoder_start_token_id] if prompt_ids is None else list(prompt_ids),
+                                      dtype=torch.long, device=dev)
+        if timestamp_rules is not None:
+            timestamp_rules = dict(timestamp_rules, begin_index=len(self.prompt))
+            use_graphs = False
+        self.eos = eos_token_id
+        self.decoder = GreedyDecoder(model.engine, self.B, len(self.prompt) + self.max_new, eos_token_id=eos_token_id,
+                                     use_graphs=use_graphs, timestamp_rules=timestamp_rules)
+        self._wave = torch.zeros((self.B, feature_extractor.n_samples), dtype=torch.float32, device=dev)
+
+    def __call__(self, audios, speaker_ids=None):
+        model = self.model
+        model._sync_shadow()
+        audios = [torch.as_tensor(np.asarray(a, dtype=np.float32) if not torch.is_tensor(a) else a,
+                                  dtype=torch.float32).reshape(-1).to(self.dev) for a in audios]
+        packs, cond = pack_plan([a.numel() for a in audios], speaker_ids, self.fe.n_samples)
+        mine = shard(list(range(len(packs))), self.rank, self.world)
+        prompt = self.prompt[None, :].expand(self.B, -1).contiguous()
+        out = {}
+        for b0 in range(0, len(mine), self.B):
+            batch = mine[b0:b0 + self.B]
+            self._wave.zero_()
+            for r, pi in enumerate(batch):
+                pos = 0
+                for si in packs[pi]:
+                    n = audios[si].numel()
+                    self._wave[r, pos:pos + n].copy_(audios[si])
+                    pos += n
+            feats = model.ops.logmel(self._wave, self.fe._filt)
+            enc, _ = model.engine.encode(feats, save=False)
+            ids = self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
+            for r, pi in enumerate(batch):
+                row = ids[r, self.prompt.numel():].tolist()
+                if self.eos is not None and self.eos in row:
+                    row = row[:row.index(self.eos)]
+                out[pi] = [int(x) for x in row]
+        return [out.get(i) for i in range(len(packs))], packs, cond

@@ -195,3 +195,48 @@ def test_greedy_decoder_with_timestamp_rules_follows_them():
     for row in gen.tolist():
         ts = [t for t in row if t >= tb]
         assert ts == sorted(ts)                                                    # never decreasing
+
+
+def test_pack_plan_follows_reference_concatenation_rule():
+    from distil_whisper_amd.pseudo_label import pack_plan, shard
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        n = int(rng.integers(1, 40))
+        lengths = rng.integers(1, 300, size=n).tolist()
+        spk = sorted(rng.integers(0, 4, size=n).tolist()) if rng.random() < 0.7 else None
+        packs, cond = pack_plan(lengths, spk, 480)
+        # straight restatement of run_pseudo_labelling.py:649-663 on lists of lengths
+        cat_len, cat_spk, cat_idx, cprev = [lengths[0]], [spk[0] if spk else None], [[0]], [0]
+        for i in range(1, n):
+            s = spk[i] if spk else None
+            same = s == cat_spk[-1]
+            if same and lengths[i] + cat_len[-1] <= 480:
+                cat_len[-1] += lengths[i]; cat_idx[-1].append(i)
+            else:
+                cat_len.append(lengths[i]); cat_spk.append(s); cat_idx.append([i]); cprev.append(1 if same else 0)
+        assert packs == cat_idx and cond == cprev
+        assert sorted(sum(packs, [])) == list(range(n)) and all(sum(lengths[i] for i in p) <= 480 or len(p) == 1 for p in packs)
+    assert pack_plan([], None) == ([], [])
+    assert [shard(list(range(10)), r, 4) for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]
+
+
+def test_pseudo_labeller_equals_generate_on_packed_audio():
+    from distil_whisper_amd.pseudo_label import PseudoLabeller
+    cfg, model, fe = _model()
+    rng = np.random.default_rng(10)
+    audios = [0.1 * rng.standard_normal(n).astype(np.float32) for n in (200_000, 150_000, 300_000, 100_000)]
+    spk = [0, 0, 0, 1]
+    eos = cfg.vocab - 3
+    pl = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=6, eos_token_id=eos, use_graphs=False)
+    toks, packs, cond = pl(audios, spk)
+    assert packs == [[0, 1], [2], [3]] and cond == [0, 1, 0]
+    for p, t in zip(packs, toks):
+        wave = np.concatenate([audios[i] for i in p])
+        f = fe(wave, sampling_rate=16000, return_tensors="pt").input_features
+        ref = model.generate(f, max_new_tokens=6, use_cache=False, eos_token_id=eos)[0, 1:].tolist()
+        ref = ref[:ref.index(eos)] if eos in ref else ref
+        assert t == ref
+    # two ranks cover the packs disjointly
+    a = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=6, eos_token_id=eos, use_graphs=False, rank=0, world=2)(audios, spk)[0]
+    b = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=6, eos_token_id=eos, use_graphs=False, rank=1, world=2)(audios, spk)[0]
+    assert [x if x is not None else y for x, y in zip(a, b)] == toks and a[2] is None and b[0] is None
