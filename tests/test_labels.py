@@ -73,3 +73,36 @@ def test_matches_golden_known_answers():
                                    decoder_prev_token_id=PREV, timestamp_probability=case["tp"],
                                    condition_on_prev_probability=case["cp"], max_label_length=MAXLEN)
         assert got == case["labels"]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="reference tree not present (GPU box)")
+def test_weight_decay_grouping_matches_reference_get_parameter_names():
+    """run_distillation.py:760-778 + 1386-1391 exec'd on the drop-in module: the decay set the reference would build
+    equals the oracle's name rule and the flat store's per-range weight-decay classification."""
+    import torch
+    import torch.nn as nn
+    from distil_whisper_amd.modeling import WhisperForConditionalGeneration
+    from oracle import whisper_oracle as wo
+    from oracle.ref_ops import RefOps
+    src = open(REF).read()
+    a = src.index("def get_parameter_names(model, forbidden_layer_types, forbidden_module=None):")
+    b = src.index("\n\n\n", a)
+    ns = {}
+    exec(src[a:b], ns)
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 3)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    model = WhisperForConditionalGeneration(cfg_s, ops=RefOps("cpu", lowp=torch.float32), state_dict=s_sd)
+    decay = ns["get_parameter_names"](model, [nn.LayerNorm], forbidden_module=None)
+    decay = {n for n in decay if "bias" not in n}                     # run_distillation.py:1391
+    named = {n for n, _ in model.named_parameters()}                  # (tied proj_out.weight is listed once by torch)
+    ref_decay = {n for n in named if n in decay}
+    assert ref_decay == set(wo.decay_parameter_names({n: None for n in named}))
+    # the flat store: every trainable entry's range carries weight decay iff the reference puts it in the decay group
+    st = model.store
+    segs = st.adam_segments(0.1)
+    for name, (o, shape, kind) in st.entries.items():
+        if o < st.train_start or name not in named:
+            continue
+        wd = next(w for lo, hi, w in segs if lo <= o < hi)
+        assert (wd > 0) == (name in ref_decay), name
