@@ -162,7 +162,9 @@ int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, in
 /* ---- self tests (diagnostics for bring-up; not on the hot path) --------------------------------------------------
  * Runs ds_read_b64_tr_b16 on a known LDS image: out int32 [64][4] = element ids received by each lane. */
 int dw_selftest_tr16(int32_t* out, void* stream);
-/* Tuning knob for kernel A/B experiments (key 0 = GEMM main-loop variant); not part of the hot path. */
+/* Tuning knobs for kernel A/B experiments; not part of the hot path.  key 0: GEMM layout (0/1 = 8-wave 256x256 tile,
+ * 2 = 16-wave, 3 = 16-wave + 8-wave 128x128 tile [default]); key 1: strip width override (0 = rule); key 2: persistent
+ * workgroups on/off; key 3: attention backward tile-staging variant (bit 0 dQ, bit 1 dK/dV; default 1). */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus

@@ -18,7 +18,7 @@ ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
 dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
 def step():
     return tr.train_step(tr.features(audio), dec_in, labels)
-configs = eval(os.environ.get("DW_AB", "[(0,1000),(1,1000),(0,0),(1,0)]"))  # (variant, strip) ; strip 0 = auto rule
+configs = eval(os.environ.get("DW_AB", "[(1,0),(3,0)]"))  # (variant, strip); variant 1 = 8-wave, 3 = 16-wave default; strip 0 = auto rule
 step(); torch.cuda.synchronize()
 res = {c: [] for c in configs}
 for r in range(4):

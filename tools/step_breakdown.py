@@ -19,7 +19,7 @@ ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
 dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
 def step():
     return tr.train_step(tr.features(audio), dec_in, labels)
-ops.lib.dw_debug_set(0, int(os.environ.get('DW_VARIANT', 1)))
+ops.lib.dw_debug_set(0, int(os.environ.get('DW_VARIANT', 3)))  # 3 = the library default layouts
 for _ in range(2): step()
 torch.cuda.synchronize()
 ops.profile_detail = True
