@@ -13,7 +13,9 @@ random (no checkpoints exist offline), data is synthetic.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel class (the bf16 MFMA GEMM): its launches are
 bracketed by HIP events on the launch stream during one extra instrumented step after the timed region.
-`cpu_baseline` times the CPU oracle (a port of the reference path, oracle/whisper_oracle.py) on a bounded sample.
+`cpu_baseline` times the reference path itself (the `transformers` classes under the reference's train_step,
+oracle/reference_cpu_step.py) on a bounded sample on the host cores.  With N > 1 every rank checks after the timed
+steps that its parameters are bit-identical to rank 0's (data-parallel replicas must not diverge).
 """
 import argparse
 import json
@@ -129,6 +131,17 @@ def main():
         dt = tmax.item()
     ms_per_step = dt / args.steps * 1e3
     log(f"{ms_per_step:.1f} ms/step")
+    if world > 1:
+        # replicas must stay bit-identical: compare every rank's master weights with rank 0's (outside the timed region)
+        P = tr.student_store.P
+        ref = P.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1 if torch.equal(ref, P) else 0], device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        del ref
+        if int(same.item()) != 1:
+            raise RuntimeError("data-parallel replicas diverged: parameters differ between ranks after the timed steps")
+        log("replica check: parameters bit-identical on all ranks")
     value = world * B * 30.0 * args.steps / dt
     loss_val = float(losses[2].item())
 
@@ -164,7 +177,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        log("cpu baseline leg (subprocess, bounded to 300 s) ...")
+        log("cpu baseline leg (subprocess, bounded to 420 s) ...")
         cpu_baseline = run_cpu_baseline(args.model, args.mode)
 
     if rank == 0:
@@ -202,7 +215,7 @@ def usable_cores():
     return n
 
 
-def run_cpu_baseline(model, mode, limit_s=300):
+def run_cpu_baseline(model, mode, limit_s=420):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", model, "--mode", mode]
     try:
@@ -218,22 +231,35 @@ def run_cpu_baseline(model, mode, limit_s=300):
 
 
 def cpu_baseline_leg(model, le, ld, recipe):
-    """The CPU oracle (port of the reference train_step + clip + AdamW, fp32) on a bounded sample: ONE step at
-    batch 1 of the same model configuration on the host cores of this box."""
+    """The reference path on the host cores of this box: the `transformers` Whisper classes +
+    feature extractor driven by the reference's train_step / AdamW groups / clip (oracle/reference_cpu_step.py), fp32,
+    batch 1 x 30 s of the same model configuration, log-mel included, 1 warm-up + up to 3 timed steps within a time
+    budget.  Falls back to the oracle port (kind "port") only if `transformers` cannot be imported."""
     from oracle import whisper_oracle as wo
     cfg_t = wo.CONFIGS[model]
     ncores = usable_cores()
     torch.set_num_threads(ncores)
+    try:
+        from oracle.reference_cpu_step import timed_reference_steps
+        r = timed_reference_steps(cfg_t, le, ld, batch=1, recipe=recipe, warmup=1, steps=3, budget_s=200.0,
+                                  threads=ncores)
+        return {"value": 30.0 * r["batch"] / r["seconds_per_step"], "unit": "audio-s/s", "cores": ncores,
+                "kind": "reference",
+                "sample": f"transformers WhisperForConditionalGeneration + WhisperFeatureExtractor, reference "
+                          f"train_step + clip + AdamW, {model} dims, fp32, batch {r['batch']} x 30 s, log-mel included, "
+                          f"{r['warmup']} warm-up + {r['steps']} timed steps ({r['seconds_per_step']:.1f} s/step)"}
+    except ImportError as e:
+        note = f"transformers unavailable ({e}); oracle port instead"
     t_sd = wo.init_state_dict(cfg_t, 0)
     s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, le, ld)
-    b = wo.synthetic_batch(cfg_t, 1, seed=1234, with_audio=False)
-    feats = torch.randn(1, cfg_t.n_mels, 3000) * 0.5
-    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
+    b = wo.synthetic_batch(cfg_t, 1, seed=1234, with_audio=True)
     params = {}
     for k, v in s_sd.items():
         rg = k != "model.encoder.embed_positions.weight" and not (recipe and k.startswith("model.encoder."))
         params[k] = v.requires_grad_(rg)
     t0 = time.perf_counter()
+    feats = torch.tensor(wo.logmel(b["audio"], cfg_t.n_mels))
+    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
     loss, *_ = wo.train_step(params, cfg_s, t_sd, cfg_t, batch, 2.0, 1.0, recipe)
     loss.backward()
     grads = {k: p.grad for k, p in params.items() if p.grad is not None}
@@ -241,7 +267,7 @@ def cpu_baseline_leg(model, le, ld, recipe):
         wo.clip_and_adamw({k: p.detach() for k, p in params.items()}, grads, {}, step=1)
     dt = time.perf_counter() - t0
     return {"value": 30.0 / dt, "unit": "audio-s/s", "cores": ncores, "kind": "port",
-            "sample": f"1 step, batch 1 x 30 s, {model} dims, fp32 torch CPU ({dt:.1f} s; log-mel excluded)"}
+            "sample": f"{note}: 1 step, batch 1 x 30 s, {model} dims, fp32 torch CPU ({dt:.1f} s; log-mel included)"}
 
 
 if __name__ == "__main__":

@@ -125,8 +125,11 @@ __global__ __launch_bounds__(LOSS_NT) void loss_final_kernel(const float* row_ce
     a = block_sum<LOSS_NT>(a, red);
     b = block_sum<LOSS_NT>(b, red);
     if (threadIdx.x == 0) {
-        const float ce = a / (float)max(counts[0], 1);
-        const float kl = b / (float)max(counts[1], 1) * T * T;
+        // no valid label in the batch: the reference's means are 0/0 = NaN (CrossEntropyLoss over zero tokens,
+        // kl.sum() / padding_mask.sum()); report NaN as well so that the empty batch is visible (the gradient written
+        // by the row kernel is zero in that case, i.e. the step is a no-op instead of poisoning the weights)
+        const float ce = a / (float)counts[0];
+        const float kl = b / (float)counts[1] * T * T;
         losses[0] = ce;
         losses[1] = kl;
         losses[2] = ce_w * ce + kl_w * kl;

@@ -4,7 +4,11 @@
 #include "common.h"
 #include "../../include/dwamd.h"
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* out) {
+// Two deterministic stages (no float atomics): every block stores its partial sum, one block adds the partials in a
+// fixed order.  The clip coefficient derived from this norm is baked into every parameter update, so data-parallel
+// replicas (which see bit-identical all-reduced gradients) must compute bit-identical norms -- an atomicAdd over up to
+// 2048 blocks would make the summation order, and with it the replicas' parameters, run dependent.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* partials) {
     __shared__ float red[4];
     float acc = 0.f;
     const long stride = (long)gridDim.x * 256 * 4;
@@ -17,7 +21,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, floa
         }
     }
     acc = block_sum<256>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partials, int nb, float* out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partials[i];
+    acc = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) out[0] += acc;
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, long n,
@@ -66,13 +78,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 
-extern "C" int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream) {
+extern "C" int dw_sumsq_f32(const float* g, int64_t n, float* out, float* partials, void* stream) {
     DW_CLEAR_ERR();
-    if (!g || !out || n <= 0 || ((uintptr_t)g & 15)) return DW_EINVAL;
+    if (!g || !out || !partials || n <= 0 || ((uintptr_t)g & 15)) return DW_EINVAL;
     long nb = (n / 4 + 255) / 256;
-    if (nb > 2048) nb = 2048;
+    if (nb > DW_SUMSQ_PARTIALS) nb = DW_SUMSQ_PARTIALS;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, out);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, (long)n, partials);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)nb, out);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

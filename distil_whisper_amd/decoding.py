@@ -55,7 +55,7 @@ def apply_timestamp_rules(scores, tokens, n, begin_index, no_timestamps_token_id
 
 class GreedyDecoder:
     def __init__(self, engine, batch, max_len, eos_token_id=None, suppress_tokens=None, begin_suppress_tokens=None,
-                 use_graphs=None, check_every=16, timestamp_rules=None):
+                 use_graphs=None, check_every=16, timestamp_rules=None, pad_token_id=None):
         self.eng, self.B, self.max_len = engine, int(batch), int(max_len)
         d = engine.dims
         if self.max_len > d.max_tgt:
@@ -68,7 +68,14 @@ class GreedyDecoder:
         self.tokens = torch.zeros((self.B, self.max_len), dtype=torch.long, device=dev)
         self.cur = torch.zeros((self.B, 1), dtype=torch.long, device=dev)
         self.done = torch.zeros((self.B,), dtype=torch.bool, device=dev)
-        self.eos_fill = None if eos_token_id is None else torch.full((self.B,), eos_token_id, dtype=torch.long, device=dev)
+        # finished rows are filled with pad_token_id (GenerationMixin: next = next * unfinished + pad * (1 - unfinished));
+        # Whisper checkpoints have pad == eos
+        fill = eos_token_id if pad_token_id is None else pad_token_id
+        self.eos_fill = None if eos_token_id is None else torch.full((self.B,), fill, dtype=torch.long, device=dev)
+        self.eos_mask = None
+        if eos_token_id is not None:   # MinNewTokensLengthLogitsProcessor: EOS cannot be sampled before min_new_tokens
+            self.eos_mask = torch.zeros((d.vocab,), dtype=torch.float32, device=dev)
+            self.eos_mask[eos_token_id] = float("-inf")
 
         def mask(ids):
             if ids is None or len(ids) == 0:
@@ -88,18 +95,21 @@ class GreedyDecoder:
         self._warm = False
 
     # mode 0: position t+1 is still inside the prompt (teacher forcing); 1: first generated token; 2: later tokens
-    def _step(self, t, mode):
+    def _step(self, t, mode, no_eos=False):
         eng, d = self.eng, self.eng.dims
         self.cache["t"] = t
         logits = eng.decode_step(self.cur, self.cache)
         if mode == 0:
             nxt = self.tokens[:, t + 1]
         else:
+            # processor order of the reference: min-new-tokens, begin-suppress, suppress, timestamp rules
             sc = logits[:, : d.vocab].float()
-            if self.suppress is not None:
-                sc = sc + self.suppress
+            if no_eos and self.eos_mask is not None:
+                sc = sc + self.eos_mask
             if mode == 1 and self.begin_suppress is not None:
                 sc = sc + self.begin_suppress
+            if self.suppress is not None:
+                sc = sc + self.suppress
             if self.timestamp_rules is not None:
                 r = self.timestamp_rules
                 sc = apply_timestamp_rules(sc, self.tokens, t + 1, r["begin_index"], r["no_timestamps_token_id"],
@@ -111,27 +121,27 @@ class GreedyDecoder:
             self.tokens[:, t + 1].copy_(nxt)
         self.cur.copy_(nxt.view(self.B, 1))
 
-    def _run_step(self, t, mode):
+    def _run_step(self, t, mode, no_eos=False):
         if not self.use_graphs:
-            self._step(t, mode)
+            self._step(t, mode, no_eos)
             return
-        g = self.graphs.get((t, mode))
+        g = self.graphs.get((t, mode, no_eos))
         if g is None:
             if not self._warm:
                 # one eager step first: lazy initialisation inside torch must not happen under stream capture
                 keep = (self.cur.clone(), self.tokens.clone(), self.done.clone())
-                self._step(t, mode)
+                self._step(t, mode, no_eos)
                 self.cur.copy_(keep[0]); self.tokens.copy_(keep[1]); self.done.copy_(keep[2])
                 torch.cuda.synchronize(self.dev)
                 self.pool = torch.cuda.graph_pool_handle()
                 self._warm = True
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.pool):
-                self._step(t, mode)
-            self.graphs[(t, mode)] = g
+                self._step(t, mode, no_eos)
+            self.graphs[(t, mode, no_eos)] = g
         g.replay()
 
-    def run(self, enc_out, prompt_ids, max_new_tokens):
+    def run(self, enc_out, prompt_ids, max_new_tokens, min_new_tokens=0):
         """enc_out: encoder output of `batch` chunks (engine layout, rows = batch * max_source_positions);
         prompt_ids: int64 [batch, P] forced decoder prefix (P >= 1; position 0 = <|startoftranscript|>).
         Returns int64 [batch, P + n] with n <= max_new_tokens (stops early once every row has produced EOS)."""
@@ -149,7 +159,7 @@ class GreedyDecoder:
         n = P
         for t in range(total - 1):
             mode = 0 if t + 1 < P else (1 if t + 1 == P else 2)
-            self._run_step(t, mode)
+            self._run_step(t, mode, bool(mode) and (t + 1 - P) < int(min_new_tokens))
             n = t + 2
             if self.eos is not None and mode and (t + 2 - P) % self.check_every == 0 and bool(self.done.all()):
                 break
@@ -157,7 +167,8 @@ class GreedyDecoder:
 
 
 def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_ids, max_new_tokens,
-                           num_assistant_tokens=5, eos_token_id=None):
+                           num_assistant_tokens=5, eos_token_id=None, suppress_tokens=None, min_new_tokens=0,
+                           pad_token_id=None):
     """Speculative (assisted) greedy decoding: the small `assistant` engine drafts `num_assistant_tokens` tokens, the
     `target` engine scores prefix + draft in ONE decoder pass and keeps the longest draft prefix that equals its own
     greedy choices plus its next token -- the output is token-for-token what target-only greedy decoding produces.
@@ -166,21 +177,44 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
     teacher and shares its encoder output) and flax/run_speculative_decoding.py:76-107.  target / assistant:
     WhisperEngine; enc_*: their encoder outputs in engine layout (the same tensor when the encoders are shared);
     prompt_ids int64 [B, P].  With a batch the accepted length is the minimum over the rows that are still running
-    (every emitted token is still each row's own greedy token).  Returns (ids [B, P + n], drafted, accepted)."""
+    (every emitted token is still each row's own greedy token).  suppress_tokens / min_new_tokens are the target's
+    logits rules (SuppressTokensLogitsProcessor, MinNewTokensLengthLogitsProcessor); finished rows are filled with
+    pad_token_id.  Returns (ids [B, P + n], drafted, accepted)."""
     dt, da = target.dims, assistant.dims
-    B = prompt_ids.shape[0]
+    B, P0 = prompt_ids.shape
     ids = prompt_ids.clone()
-    total = prompt_ids.shape[1] + int(max_new_tokens)
+    dev = ids.device
+    total = P0 + int(max_new_tokens)
     if total > min(dt.max_tgt, da.max_tgt):
         raise ValueError(f"prompt + max_new_tokens = {total} exceeds max_target_positions")
-    done = torch.zeros(B, dtype=torch.bool, device=ids.device)
+    done = torch.zeros(B, dtype=torch.bool, device=dev)
     drafted = accepted = 0
+    fill = eos_token_id if pad_token_id is None else pad_token_id
+    sup = {}
+
+    def sup_mask(V):
+        if not suppress_tokens:
+            return None
+        if V not in sup:
+            m = torch.zeros((V,), dtype=torch.float32, device=dev)
+            m[torch.as_tensor([t for t in suppress_tokens if t < V], dtype=torch.long, device=dev)] = float("-inf")
+            sup[V] = m
+        return sup[V]
 
     def greedy_rows(eng, d, seq, enc, first):
         """argmax tokens of `eng` for positions first .. len(seq)-1 of seq (each predicts the next token): [B, n]"""
         T = seq.shape[1]
         logits, _ = eng.decode(seq.contiguous(), enc, save=False)
-        return logits[: B * T, : d.vocab].view(B, T, -1)[:, first:].float().argmax(-1)
+        sc = logits[: B * T, : d.vocab].view(B, T, -1)[:, first:].float()
+        m = sup_mask(d.vocab)
+        if m is not None:
+            sc = sc + m
+        if eos_token_id is not None and min_new_tokens > 0 and eos_token_id < d.vocab:
+            gen_idx = torch.arange(first + 1 - P0, T + 1 - P0, device=dev)       # index of the token being predicted
+            sc = sc.clone()
+            sc[:, :, eos_token_id] = torch.where((gen_idx < min_new_tokens)[None, :], float("-inf"),
+                                                 sc[:, :, eos_token_id])
+        return sc.argmax(-1)
 
     while ids.shape[1] < total and not (eos_token_id is not None and bool(done.all())):
         k = min(int(num_assistant_tokens), total - ids.shape[1] - 1)
@@ -200,7 +234,7 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
         new = own[:, : n_ok + 1]                             # accepted draft tokens (== own) + the target's next token
         if eos_token_id is not None:
             for j in range(new.shape[1]):
-                col = torch.where(done, torch.full_like(new[:, j], eos_token_id), new[:, j])
+                col = torch.where(done, torch.full_like(new[:, j], fill), new[:, j])
                 new[:, j] = col
                 done = done | (col == eos_token_id)
         ids = torch.cat([ids, new], 1)

@@ -28,15 +28,18 @@ class GradReducer:
     """Bucketed all-reduce (sum) of ranges of the flat gradient buffer, issued on a communication stream as soon as a
     range is final.  With world_size 1 (or no process group) it is a no-op."""
 
-    def __init__(self, flat, group=None, bucket_bytes=256 << 20):
+    def __init__(self, flat, group=None, bucket_bytes=256 << 20, always_reduce=False):
         import torch.distributed as dist
         self.flat, self.group, self.dist = flat, group, dist
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.initialized = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.initialized else 1
+        # always_reduce: issue the collectives even with one rank (exercises the stream hand-off on a single GPU)
+        self.active = self.world > 1 or (always_reduce and self.initialized)
         self.bucket_elems = bucket_bytes // 4
         self.pending_lo = self.pending_hi = None
         self.handles = []
         self.cuda = flat.is_cuda
-        self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.world > 1) else None
+        self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.active) else None
 
     def _launch(self, lo, hi):
         view = self.flat[lo:hi]
@@ -50,7 +53,7 @@ class GradReducer:
 
     def ready(self, lo, hi):
         """Gradients in [lo, hi) are final.  Ranges must arrive adjacent and descending (backward order)."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         if self.pending_lo is not None and hi == self.pending_lo:
             self.pending_lo = lo
@@ -78,7 +81,7 @@ class DistillationTrainer:
     def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
                  share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None,
-                 overlap_teacher=False):
+                 overlap_teacher=False, bucket_bytes=256 << 20, always_reduce=False):
         self.ops = ops
         self.sdims, self.tdims = WhisperDims.from_any(student_dims), WhisperDims.from_any(teacher_dims)
         frozen = []
@@ -98,7 +101,7 @@ class DistillationTrainer:
             raise ValueError("share_encoder requires freeze_encoder (run_distillation.py:1046-1049)")
         self.step_count = 0
         st = self.student_store
-        self.reducer = GradReducer(st.G, process_group) if st.G is not None else None
+        self.reducer = GradReducer(st.G, process_group, bucket_bytes, always_reduce) if st.G is not None else None
         self.world = self.reducer.world if self.reducer else 1
         self.mel_filters = mel_filters
         # optional: the frozen teacher forward is independent of the student forward until the loss and can run on a
@@ -107,6 +110,8 @@ class DistillationTrainer:
         self.overlap_teacher = overlap_teacher and self.student_store.P.is_cuda
         self._tstream = torch.cuda.Stream(device=self.student_store.P.device) if self.overlap_teacher else None
         self._sumsq = ops.zeros((1,), torch.float32)
+        self._accum = 1            # micro-batches summed in the gradient buffer of the current optimizer step
+        self._last_gm = 1.0        # gradient multiplier the last optimizer step applied (1 / (world * accum))
         self.segments = st.adam_segments(weight_decay)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -152,7 +157,7 @@ class DistillationTrainer:
         if zero_grad:
             S.zero_small_grads()
         st = self.student_store
-        dp = self.reducer is not None and self.world > 1 and sync_grads
+        dp = self.reducer is not None and self.reducer.active and sync_grads
         denc = S.backward_decoder(dctx, logits_s, want_denc=not self.freeze_encoder)
         del logits_s, dctx
         if dp:
@@ -169,7 +174,8 @@ class DistillationTrainer:
             self.reducer.wait()
         self.step_count += 1
         lo, hi = st.train_start, st.train_end
-        gm = 1.0 / (self.world * getattr(self, "_accum", 1))
+        gm = 1.0 / (self.world * self._accum)
+        self._last_gm = gm
         self._sumsq.zero_()
         ops.sumsq(st.G[lo:hi], self._sumsq)
         for a, b, wd in self.segments:
@@ -189,12 +195,48 @@ class DistillationTrainer:
         AdamW, like accelerate's `accumulate` context (loss / gradient_accumulation_steps)."""
         n = len(micro_batches)
         out = []
-        for i, (f, d, l) in enumerate(micro_batches):
-            out.append(self.forward_backward(f, d, l, zero_grad=(i == 0), sync_grads=(i == n - 1)))
         self._accum = n
-        self.optimizer_step(lr)
-        self._accum = 1
+        try:
+            for i, (f, d, l) in enumerate(micro_batches):
+                out.append(self.forward_backward(f, d, l, zero_grad=(i == 0), sync_grads=(i == n - 1)))
+            self.optimizer_step(lr)
+        finally:
+            self._accum = 1
         return torch.stack(out).mean(0)
 
     def grad_norm(self):
-        return torch.sqrt(self._sumsq[0]) / self.world
+        """Global gradient norm the last optimizer step clipped (what `accelerator.clip_grad_norm_` returns,
+        run_distillation.py:1611): norm of the rank- and micro-batch-averaged gradient."""
+        return torch.sqrt(self._sumsq[0]) * self._last_gm
+
+    # ---- checkpoint / resume (the reference: accelerator.save_state / load_state, run_distillation.py:1638-1650) ----
+    def state_dict(self):
+        """Everything a resumed run needs to continue bit-exactly: fp32 master weights, Adam moments (HF parameter
+        names), step count and hyper-parameters."""
+        st = self.student_store
+        names = [n for n in st.real_names() if st.is_trainable(n)]
+
+        def view(buf, name):
+            o, shape, _ = st.entries[name]
+            n = 1
+            for d in shape:
+                n *= d
+            return buf[o:o + n].view(shape).detach().clone()
+        return {"model": st.state_dict(), "exp_avg": {n: view(st.M, n) for n in names},
+                "exp_avg_sq": {n: view(st.V, n) for n in names}, "step": self.step_count,
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                          "max_grad_norm": self.max_grad_norm, "temperature": self.temperature,
+                          "kl_weight": self.kl_weight}}
+
+    def load_state_dict(self, state):
+        st = self.student_store
+        st.load_state_dict(state["model"])
+        for key, buf in (("exp_avg", st.M), ("exp_avg_sq", st.V)):
+            for n, t in state[key].items():
+                o, shape, _ = st.entries[n]
+                buf[o:o + t.numel()].view(shape).copy_(t.to(buf.device))
+        self.step_count = int(state["step"])
+        h = state.get("hyper", {})
+        self.lr, self.eps = h.get("lr", self.lr), h.get("eps", self.eps)
+        self.betas = tuple(h.get("betas", self.betas))
+        self.temperature, self.kl_weight = h.get("temperature", self.temperature), h.get("kl_weight", self.kl_weight)

@@ -105,6 +105,87 @@ class WhisperFeatureExtractor:
         return out
 
 
+    def pad(self, processed_features, padding=True, max_length=None, truncation=False, pad_to_multiple_of=None,
+            return_attention_mask=None, return_tensors=None):
+        """`SequenceFeatureExtractor.pad` as the reference's collator calls it (run_distillation.py:447-451:
+        `pad({"input_features": [M x 3000 arrays]}, padding="max_length", return_tensors="pt")`).  The base class
+        pads along the FIRST axis of every item (the mel-bin axis for Whisper features, which is equal for all items),
+        so the call (`padding="longest"` at run_distillation.py:1421) amounts to stacking the already fixed-length features into one float32 batch; items whose first
+        axes differ are padded with `padding_value` up to the longest (or `max_length`)."""
+        if isinstance(processed_features, (list, tuple)):
+            processed_features = {k: [f[k] for f in processed_features] for k in processed_features[0]}
+        if "input_features" not in processed_features:
+            raise ValueError("You should supply an instance of `BatchFeature` or list of `BatchFeature` to this "
+                             f"method that includes input_features, but you provided {list(processed_features.keys())}")
+        items = [torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(torch.float32)
+                 for x in processed_features["input_features"]]
+        out = BatchFeature()
+        if len(items) == 0:
+            out["input_features"] = []
+            return out
+        do_pad = padding not in (False, "do_not_pad")
+        if padding == "max_length" and max_length is None:
+            raise ValueError("When setting ``padding=max_length``, make sure that max_length is defined")
+        n0 = max(x.shape[0] for x in items)
+        if do_pad and padding == "max_length" and max_length is not None:
+            n0 = max_length
+        if do_pad and pad_to_multiple_of:
+            n0 = -(-n0 // pad_to_multiple_of) * pad_to_multiple_of
+        rows, masks = [], []
+        for x in items:
+            if truncation and max_length is not None and x.shape[0] > max_length:
+                x = x[:max_length]
+            m = torch.ones(x.shape[0], dtype=torch.int32)
+            if do_pad and x.shape[0] < n0:
+                fill = torch.full((n0 - x.shape[0],) + tuple(x.shape[1:]), float(self.padding_value))
+                x = torch.cat([x, fill], 0)
+                m = torch.cat([m, torch.zeros(n0 - m.numel(), dtype=torch.int32)])
+            rows.append(x)
+            masks.append(m)
+        if return_tensors in ("pt", "np"):
+            if any(r.shape != rows[0].shape for r in rows):
+                raise ValueError("Unable to convert output 'input_features' to tensor: the items have different "
+                                 "shapes. Use padding=True to ensure all outputs have the same length.")
+            batch = torch.stack(rows)
+            out["input_features"] = batch if return_tensors == "pt" else batch.numpy()
+            if return_attention_mask:
+                am = torch.stack(masks)
+                out["attention_mask"] = am if return_tensors == "pt" else am.numpy()
+        elif return_tensors is None:
+            out["input_features"] = [r.numpy() for r in rows]
+            if return_attention_mask:
+                out["attention_mask"] = [m.numpy() for m in masks]
+        else:
+            raise ValueError(f"unsupported return_tensors={return_tensors}")
+        return out
+
+    # -- checkpoint directory round trip (run_distillation.py:966, 1071, 1641) ------------------------------------------
+    def to_dict(self):
+        return {"feature_extractor_type": "WhisperFeatureExtractor", "feature_size": self.feature_size,
+                "sampling_rate": self.sampling_rate, "hop_length": self.hop_length, "chunk_length": self.chunk_length,
+                "n_fft": self.n_fft, "padding_value": self.padding_value, "n_samples": self.n_samples,
+                "nb_max_frames": self.nb_max_frames, "padding_side": "right", "return_attention_mask": False}
+
+    def save_pretrained(self, save_directory, **kwargs):
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "preprocessor_config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, ops=None, device="cuda:0", **kwargs):
+        import json
+        import os
+        path = os.path.join(str(pretrained_model_name_or_path), "preprocessor_config.json")
+        if not os.path.exists(path):
+            raise OSError(f"{path} not found (no hub access in this environment: pass a local checkpoint directory)")
+        with open(path) as f:
+            d = json.load(f)
+        keys = ("feature_size", "sampling_rate", "hop_length", "chunk_length", "n_fft", "padding_value")
+        return cls(**{k: d[k] for k in keys if k in d}, ops=ops, device=device)
+
+
 class _EncoderLayer(nn.Module):
     def __init__(self, D, Fd):
         super().__init__()
@@ -162,6 +243,59 @@ class _Model(nn.Module):
         self.decoder = _Decoder(d)
 
 
+class WhisperConfig:
+    """The fields of `transformers.WhisperConfig` this path reads (TF:configuration_whisper.py:127-164), loadable from
+    and writable to a checkpoint directory's config.json.  A `transformers.WhisperConfig` works in its place."""
+
+    model_type = "whisper"
+    _DEFAULTS = dict(vocab_size=51865, num_mel_bins=80, encoder_layers=4, encoder_attention_heads=6, decoder_layers=4,
+                     decoder_attention_heads=6, decoder_ffn_dim=1536, encoder_ffn_dim=1536, d_model=384,
+                     max_source_positions=1500, max_target_positions=448, pad_token_id=50256, bos_token_id=50256,
+                     eos_token_id=50256, decoder_start_token_id=50257, activation_function="gelu", dropout=0.0,
+                     attention_dropout=0.0, activation_dropout=0.0, encoder_layerdrop=0.0, decoder_layerdrop=0.0,
+                     scale_embedding=False, use_cache=True, suppress_tokens=None, begin_suppress_tokens=None,
+                     max_length=448, forced_decoder_ids=None)
+
+    def __init__(self, **kw):
+        for k, v in self._DEFAULTS.items():
+            setattr(self, k, v)
+        for k, v in kw.items():
+            setattr(self, k, v)
+        if self.encoder_attention_heads != self.decoder_attention_heads or self.encoder_ffn_dim != self.decoder_ffn_dim:
+            raise ValueError("the MI355X engine expects equal encoder / decoder head counts and FFN widths")
+        if self.d_model != 64 * self.encoder_attention_heads:
+            raise ValueError("the HIP attention kernel implements head_dim 64 (every Whisper checkpoint)")
+        if self.activation_function != "gelu":
+            raise ValueError("the HIP GEMM epilogue implements Whisper's exact GELU")
+        if any(getattr(self, k) for k in ("dropout", "attention_dropout", "activation_dropout", "encoder_layerdrop",
+                                          "decoder_layerdrop")) or self.scale_embedding:
+            raise ValueError("dropout / layerdrop / scale_embedding are 0 / False in every Whisper config; the MI355X "
+                             "path does not implement them")
+
+    def to_dict(self):
+        d = {k: v for k, v in vars(self).items() if not k.startswith("_")}
+        d["model_type"] = "whisper"
+        d["architectures"] = ["WhisperForConditionalGeneration"]
+        return d
+
+    @classmethod
+    def from_pretrained(cls, path, **_):
+        import json
+        import os
+        with open(os.path.join(path, "config.json")) as f:
+            d = json.load(f)
+        for k in ("model_type", "architectures", "transformers_version", "torch_dtype", "dtype", "_name_or_path"):
+            d.pop(k, None)
+        return cls(**d)
+
+    def save_pretrained(self, path):
+        import json
+        import os
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.to_dict(), f, indent=2, sort_keys=True)
+
+
 class _EngineFn(torch.autograd.Function):
     """forward: engine encode+decode with activations kept; backward: engine backward from d(loss)/d(logits) (and
     optionally d/d(encoder_last_hidden_state)); parameter gradients are returned as views of the flat buffer."""
@@ -170,9 +304,10 @@ class _EngineFn(torch.autograd.Function):
     def forward(ctx, model, input_features, enc_in, decoder_input_ids, *params):
         eng = model.engine
         train = any(ctx.needs_input_grad[4:])  # (grad mode is off inside Function.forward; this is the real signal)
+        enc_train = train and model._encoder_requires_grad()
         ectx = None
         if enc_in is None:
-            enc, ectx = eng.encode(input_features.to(torch.float32).contiguous(), save=train and model._enc_trainable)
+            enc, ectx = eng.encode(input_features.to(torch.float32).contiguous(), save=enc_train)
         else:
             rows = enc_in.shape[0] * enc_in.shape[1]
             enc = eng.act(rows, eng.dims.d_model)
@@ -200,21 +335,34 @@ class _EngineFn(torch.autograd.Function):
         denc = eng.backward_decoder(ctx.dctx, buf, want_denc=ctx.ectx is not None)
         if ctx.ectx is not None:
             eng.backward_encoder(ctx.ectx, denc)
+        # views of the flat gradient buffer: autograd's AccumulateGrad copies them into `.grad` (one copy, not two);
+        # parameters frozen after construction (`requires_grad_(False)`, run_distillation.py:1018-1040) get None
         grads = []
         for name, p in zip(model._param_names, model._param_list):
-            grads.append(st.g[name].clone() if (p.requires_grad and name in st.g) else None)
+            grads.append(st.g[name] if (p.requires_grad and name in st.g) else None)
         return (None, None, None, None, *grads)
 
 
 class WhisperForConditionalGeneration(nn.Module):
-    def __init__(self, config, ops=None, device="cuda:0", state_dict=None, seed=0, frozen_prefixes=()):
+    """dtype=torch.float32 (default): fp32 master weights, bf16 GEMM operands, fp32 residual stream -- the reference's
+    student under `accelerate` bf16 autocast (SURVEY.md section 8a').  dtype=torch.bfloat16: weights rounded to bf16
+    and a bf16 residual stream -- a model loaded with `torch_dtype=torch.bfloat16` (the teacher of
+    run_distillation.py:986-1004, every model of run_eval.py / run_pseudo_labelling.py); inference only."""
+
+    def __init__(self, config, ops=None, device="cuda:0", state_dict=None, seed=0, frozen_prefixes=(),
+                 dtype=torch.float32):
         super().__init__()
         self.config = config
         self.dims = WhisperDims.from_any(config)
         self.ops = ops if ops is not None else _default_ops(device)
+        if dtype not in (torch.float32, torch.bfloat16, None):
+            raise ValueError(f"dtype {dtype}: the MI355X path computes in bf16 with fp32 or bf16 parameters")
+        self.dtype_mode = torch.float32 if dtype is None else dtype
+        pure_bf16 = self.dtype_mode == torch.bfloat16
         sd = state_dict if state_dict is not None else random_state_dict(self.dims, seed, device=self.ops.device)
-        self.store = ParamStore(self.ops, self.dims, sd, trainable=True, frozen_prefixes=tuple(frozen_prefixes))
-        self.engine = WhisperEngine(self.ops, self.store, torch.float32)
+        self.store = ParamStore(self.ops, self.dims, sd, trainable=not pure_bf16,
+                                frozen_prefixes=tuple(frozen_prefixes), round_bf16=pure_bf16)
+        self.engine = WhisperEngine(self.ops, self.store, self.ops.lowp if pure_bf16 else torch.float32)
         self._decoders = {}
         self.model = _Model(self.dims)
         self.proj_out = nn.Linear(self.dims.d_model, self.dims.vocab, bias=False, device="meta")
@@ -227,8 +375,13 @@ class WhisperForConditionalGeneration(nn.Module):
         self.proj_out.weight = self.model.decoder.embed_tokens.weight  # tied (TF:modeling_whisper.py:965)
         self._param_names = self.store.real_names()
         self._param_list = [self.get_parameter(n) for n in self._param_names]
-        self._enc_trainable = self.store.is_trainable("model.encoder.conv1.weight")
+        self._enc_params = [p for n, p in zip(self._param_names, self._param_list) if n.startswith("model.encoder.")]
         self._versions = None
+        from .generation import GenerationConfig
+        self.generation_config = GenerationConfig.from_model_config(config)
+        if self.generation_config.decoder_start_token_id is None:
+            self.generation_config.decoder_start_token_id = self.dims.decoder_start_token_id
+        self.is_gradient_checkpointing = False
 
     # -- reference surface ------------------------------------------------------------------------------------------
     def get_encoder(self):
@@ -237,11 +390,94 @@ class WhisperForConditionalGeneration(nn.Module):
     def get_decoder(self):
         return self.model.decoder
 
+    def _encoder_requires_grad(self):
+        return any(p.requires_grad for p in self._enc_params)
+
     def freeze_encoder(self):
-        """Mirror of `student_model.freeze_encoder()` (run_distillation.py:1018-1021): the flat layout has to be
-        rebuilt with the encoder in the frozen range."""
-        raise RuntimeError("construct the model with frozen_prefixes=('model.encoder.',) instead: the parameter layout "
-                           "of the MI355X engine is fixed at construction")
+        """`student_model.freeze_encoder()` (run_distillation.py:1018-1021; TF:modeling_whisper.py `freeze_encoder` ->
+        `encoder._freeze_parameters()`): gradients of the encoder are disabled.  The engine then neither keeps the
+        encoder's activations nor runs its backward; the same happens for any parameter the caller switches off with
+        `requires_grad_(False)` afterwards (run_distillation.py:1034-1040 `freeze_embed_positions`)."""
+        for p in self._enc_params:
+            p.requires_grad_(False)
+        self.model.encoder._requires_grad = False
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        """run_distillation.py:1014-1015.  The engine keeps every activation it needs in HBM (288 GB: the full
+        distil-large-v3 step at batch 32 peaks at 94 GiB) and never recomputes, so this only records the request."""
+        self.is_gradient_checkpointing = True
+        self.model.encoder.gradient_checkpointing = True
+        self.model.decoder.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.is_gradient_checkpointing = False
+        self.model.encoder.gradient_checkpointing = False
+        self.model.decoder.gradient_checkpointing = False
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, torch_dtype=None, dtype=None,
+                        attn_implementation=None, low_cpu_mem_usage=None, cache_dir=None, revision=None, token=None,
+                        subfolder="", variant=None, use_safetensors=None, local_files_only=None, ops=None,
+                        device="cuda:0", **kwargs):
+        """Load `config.json` + `model.safetensors` (or `pytorch_model.bin`) from a LOCAL checkpoint directory
+        (run_distillation.py:986-1004, run_eval.py:547-563 call this with hub names; there is no network here, so a
+        name that is not a directory raises).  `attn_implementation` is accepted for the CLI whitelist
+        (run_distillation.py:141-148): this class always runs the HIP flash-attention kernel."""
+        import json
+        import os
+        if kwargs:
+            raise TypeError(f"from_pretrained() got unexpected keyword arguments {sorted(kwargs)}")
+        path = os.path.join(str(pretrained_model_name_or_path), subfolder) if subfolder else \
+            str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            raise OSError(f"{path} is not a local checkpoint directory (no hub access in this environment)")
+        if attn_implementation not in (None, "eager", "sdpa", "flash_attention_2", "hip_attention"):
+            raise ValueError(f"unknown attn_implementation {attn_implementation!r}")
+        if config is None:
+            config = WhisperConfig.from_pretrained(path)
+        dt = dtype if dtype is not None else torch_dtype
+        if isinstance(dt, str):
+            dt = {"float32": torch.float32, "bfloat16": torch.bfloat16, "auto": None}.get(dt, dt)
+        st_path = os.path.join(path, "model.safetensors" if not variant else f"model.{variant}.safetensors")
+        bin_path = os.path.join(path, "pytorch_model.bin")
+        if os.path.exists(st_path) and use_safetensors is not False:
+            from safetensors.torch import load_file
+            sd = load_file(st_path)
+        elif os.path.exists(bin_path):
+            sd = torch.load(bin_path, map_location="cpu", weights_only=True)
+        else:
+            raise OSError(f"no model.safetensors / pytorch_model.bin under {path}")
+        if "model.decoder.embed_tokens.weight" not in sd and "proj_out.weight" in sd:
+            sd["model.decoder.embed_tokens.weight"] = sd["proj_out.weight"]
+        model = cls(config, ops=ops, device=device, state_dict=sd, dtype=dt)
+        gpath = os.path.join(path, "generation_config.json")
+        if os.path.exists(gpath):
+            from .generation import GenerationConfig
+            with open(gpath) as f:
+                model.generation_config = GenerationConfig.from_any(json.load(f))
+        return model
+
+    def save_pretrained(self, save_directory, state_dict=None, safe_serialization=True, **kwargs):
+        """run_distillation.py:1765, 1791: config.json, generation_config.json and the weights under their HF names
+        (the tied `proj_out.weight` is not stored, as `transformers` does for tied weights)."""
+        import json
+        import os
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = self.config
+        if hasattr(cfg, "save_pretrained"):
+            cfg.save_pretrained(save_directory)
+        else:
+            WhisperConfig(**{k: getattr(cfg, k) for k in WhisperConfig._DEFAULTS if hasattr(cfg, k)}) \
+                .save_pretrained(save_directory)
+        with open(os.path.join(save_directory, "generation_config.json"), "w") as f:
+            json.dump(self.generation_config.to_dict(), f, indent=2, sort_keys=True)
+        sd = state_dict if state_dict is not None else self.state_dict()
+        sd = {k: v.detach().to("cpu").contiguous() for k, v in sd.items() if k != "proj_out.weight"}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(save_directory, "pytorch_model.bin"))
 
     def _sync_shadow(self):
         v = tuple(p._version for p in self._param_list)
@@ -277,95 +513,233 @@ class WhisperForConditionalGeneration(nn.Module):
         return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc)
 
     @torch.no_grad()
-    def generate(self, input_features=None, max_new_tokens=32, decoder_start_ids=None, eos_token_id=None,
-                 use_cache=True, use_graphs=False, suppress_tokens=None, begin_suppress_tokens=None,
-                 encoder_outputs=None, assistant_model=None, num_assistant_tokens=5, return_timestamps=False,
-                 no_timestamps_token_id=None, max_initial_timestamp_index=None, **kwargs):
-        """Greedy decoding (run_distillation.py:1524-1528 `generate_step`, run_eval.py:739) on the engine.  With
-        use_cache the decoder runs one token per step against a KV cache (static cross-attention K/V computed once,
-        self-attention K/V appended in place; decoding.GreedyDecoder), optionally with the per-position launch
-        sequence replayed from HIP graphs (use_graphs); use_cache=False re-decodes the whole prefix every step and
-        exists as the cross-check.  `encoder_outputs` (engine layout or [B, 1500, D]) skips the encoder, as
-        run_eval.py's benchmark_gen does (806-844).  Beam search, timestamp rules and the temperature-fallback logic
-        of TF:generation_whisper.py are outside this round's scope."""
+    def generate(self, input_features=None, generation_config=None, logits_processor=None, stopping_criteria=None,
+                 prefix_allowed_tokens_fn=None, synced_gpus=False, return_timestamps=None, task=None, language=None,
+                 is_multilingual=None, prompt_ids=None, prompt_condition_type=None, condition_on_prev_tokens=None,
+                 temperature=None, compression_ratio_threshold=None, logprob_threshold=None, no_speech_threshold=None,
+                 num_segment_frames=None, attention_mask=None, time_precision=0.02, time_precision_features=0.01,
+                 return_token_timestamps=None, return_segments=False, return_dict_in_generate=None,
+                 force_unique_generate_call=None, monitor_progress=None, *, use_graphs=None, **kwargs):
+        """`WhisperGenerationMixin.generate` (TF:generation_whisper.py:383-968) on the MI355X engine, with the argument
+        list of the reference (run_distillation.py:1524-1528, run_eval.py:690-739, 806-844): greedy search over one
+        30 s window per row with language / task / timestamp / prompt_ids prefixes, the suppress / begin-suppress /
+        min-new-tokens / timestamp logits rules, `assistant_model` (speculative decoding), `encoder_outputs`.
+        The token loop is decoding.GreedyDecoder (KV cache; `use_graphs` replays the per-position launch sequence from
+        HIP graphs; `use_cache=False` re-decodes the whole prefix every step and exists as a cross-check).
+        Arguments this path does not implement RAISE (nothing is silently ignored): beam search, sampling /
+        temperature fallback, inputs longer than 30 s (sequential long-form; use longform.LongFormTranscriber for the
+        chunked algorithm of run_eval.py:566-576), token-level timestamps, custom logits processors.
+        Returns what the reference returns: the generated tokens only (decoder prompt and EOS stripped, right-padded
+        with pad_token_id), or with `return_dict_in_generate=True` / `force_unique_generate_call=True` the full
+        sequences (prompt + generated, as GenerationMixin emits them)."""
+        from . import generation as G
         self._sync_shadow()
         eng, d = self.engine, self.dims
+        # ---- arguments the engine path does not implement: loud, never ignored
+        for name, val in (("logits_processor", logits_processor), ("stopping_criteria", stopping_criteria),
+                          ("prefix_allowed_tokens_fn", prefix_allowed_tokens_fn), ("monitor_progress", monitor_progress)):
+            if val is not None and (not hasattr(val, "__len__") or len(val) > 0):
+                raise NotImplementedError(f"generate({name}=...) is not implemented on the MI355X engine path")
+        if return_token_timestamps or return_segments:
+            raise NotImplementedError("return_token_timestamps / return_segments are not implemented on the MI355X path")
+        if condition_on_prev_tokens or compression_ratio_threshold is not None or logprob_threshold is not None or \
+                no_speech_threshold is not None:
+            raise NotImplementedError("the sequential long-form options (condition_on_prev_tokens, compression_ratio_"
+                                      "threshold, logprob_threshold, no_speech_threshold) are not implemented on the "
+                                      "MI355X path; use longform.LongFormTranscriber (chunked long-form)")
+        temps = list(temperature) if isinstance(temperature, (list, tuple)) else [temperature]
+        if temps[0] is not None and temps[0] > 0.0:
+            raise NotImplementedError("sampling (temperature > 0) is not implemented on the MI355X path")
+        engine_keys = ("encoder_outputs", "assistant_model", "decoder_input_ids", "use_cache")
+        unknown = [k for k in kwargs if k not in G._CONFIG_KEYS and k not in engine_keys]
+        if unknown:
+            raise ValueError(f"The following `model_kwargs` are not used by the model: {unknown} (note: typos in the "
+                             "generate arguments will also show up in this list)")
+        gc = G.GenerationConfig.from_any(generation_config if generation_config is not None else self.generation_config)
+        for k in G._CONFIG_KEYS:
+            if k in kwargs and kwargs[k] is not None:
+                setattr(gc, k, kwargs[k])
+        if (getattr(gc, "num_beams", 1) or 1) != 1:
+            raise NotImplementedError(f"num_beams={gc.num_beams}: beam search is not implemented on the MI355X path")
+        if getattr(gc, "do_sample", False):
+            raise NotImplementedError("do_sample=True is not implemented on the MI355X path")
+        if (getattr(gc, "num_return_sequences", 1) or 1) != 1:
+            raise NotImplementedError("num_return_sequences > 1 is not implemented on the MI355X path")
+        for k in ("repetition_penalty", "length_penalty"):
+            if getattr(gc, k, None) not in (None, 1.0):
+                raise NotImplementedError(f"{k} is not implemented on the MI355X path")
+        if getattr(gc, "no_repeat_ngram_size", 0):
+            raise NotImplementedError("no_repeat_ngram_size is not implemented on the MI355X path")
+        if gc.decoder_start_token_id is None:
+            gc.decoder_start_token_id = d.decoder_start_token_id
+        # ---- encoder
+        encoder_outputs = kwargs.get("encoder_outputs")
         if encoder_outputs is not None:
-            enc = encoder_outputs.last_hidden_state if hasattr(encoder_outputs, "last_hidden_state") else encoder_outputs
+            enc = encoder_outputs
+            if not torch.is_tensor(enc):
+                enc = enc.last_hidden_state if hasattr(enc, "last_hidden_state") else enc[0]
             B = enc.shape[0] if enc.dim() == 3 else enc.shape[0] // d.max_src
-            enc = enc.reshape(-1, d.d_model).to(eng.stream).contiguous()
+            if enc.numel() != B * d.max_src * d.d_model:
+                raise ValueError(f"encoder_outputs must cover {d.max_src} positions of width {d.d_model} per row")
+            enc = enc.reshape(-1, d.d_model).to(eng.lowp).contiguous()   # the dtype `encode` returns (GEMM operand)
             dev = enc.device
         else:
+            if input_features is None:
+                raise ValueError("input_features or encoder_outputs are required")
+            frames = input_features.shape[-1]
+            if frames > 2 * d.max_src:
+                raise NotImplementedError(
+                    f"{frames} mel frames (> 30 s): sequential long-form generation is not implemented on the MI355X "
+                    "path; use longform.LongFormTranscriber (the chunked algorithm of run_eval.py:566-576)")
+            if frames != 2 * d.max_src:
+                raise ValueError(f"Whisper expects the mel input features to be of length {2 * d.max_src}, but found "
+                                 f"{frames}. Make sure to pad the input mel features to {2 * d.max_src}.")
             B = input_features.shape[0]
             dev = input_features.device
             enc, _ = eng.encode(input_features.to(torch.float32).contiguous(), save=False)
-        ids = torch.full((B, 1), d.decoder_start_token_id, dtype=torch.long, device=dev) \
-            if decoder_start_ids is None else decoder_start_ids.clone()
-        total = ids.shape[1] + max_new_tokens
-        if total > d.max_tgt:
-            raise ValueError(f"prompt + max_new_tokens = {total} exceeds max_target_positions = {d.max_tgt}")
+        # ---- decoder prompt (TF:1384-1608, 1853-1918)
+        if return_timestamps is None:
+            return_timestamps = bool(getattr(gc, "return_timestamps", False))
+        if return_timestamps and not hasattr(gc, "no_timestamps_token_id"):
+            raise ValueError("You are trying to return timestamps, but the generation config is not properly set. Make "
+                             "sure to initialize the generation config with the correct attributes that are needed "
+                             "such as `no_timestamps_token_id`.")
+        gc.return_timestamps = bool(return_timestamps)
+        G.set_language_and_task(gc, language, task, is_multilingual)
+        if prompt_condition_type is not None and prompt_condition_type not in ("first-segment", "all-segments"):
+            raise ValueError("`prompt_condition_type` must be either 'first-segment' or 'all-segments'")
+        if "decoder_input_ids" in kwargs and kwargs["decoder_input_ids"] is not None:
+            ids = kwargs["decoder_input_ids"].to(dev).long().clone()
+        else:
+            def detect():
+                return self._detect_language(enc, B, gc)
+            rows = G.retrieve_init_tokens(gc, B, detect)
+            ids = torch.as_tensor(rows, dtype=torch.long, device=dev)
+            if prompt_ids is not None:
+                pr = torch.as_tensor(prompt_ids, dtype=torch.long, device=dev).reshape(-1)
+                ids = torch.cat([pr[None, :].expand(B, -1), ids], 1)
+        P = ids.shape[1]
+        max_new, min_new = G.resolve_lengths(gc, P, d.max_tgt, "max_length" in kwargs)
+        eos, pad = gc.eos_token_id, gc.pad_token_id
+        if isinstance(eos, (list, tuple)):
+            if len(eos) != 1:
+                raise NotImplementedError("several eos_token_id values are not implemented on the MI355X path")
+            eos = eos[0]
+        if pad is None:
+            pad = eos
+        suppress = list(gc.suppress_tokens) if gc.suppress_tokens else None
+        begin_suppress = list(gc.begin_suppress_tokens) if gc.begin_suppress_tokens else None
+        assistant_model = kwargs.get("assistant_model")
+        use_cache = kwargs.get("use_cache", True)
+        if use_cache is None:
+            use_cache = True
+        if use_graphs is None:
+            use_graphs = False
         if assistant_model is not None:
-            # speculative decoding (run_eval.py:578-599, 706-707): the assistant drafts, this model verifies; an
-            # assistant with this model's encoder dimensions re-uses the encoder output (the distilled student
-            # keeps a frozen copy of the teacher's encoder), otherwise it encodes the features itself
+            # speculative decoding (run_eval.py:578-599, 706-707): the assistant drafts, this model verifies.  An
+            # assistant with this model's encoder dimensions re-uses the encoder output (the distilled student keeps
+            # a frozen copy of the teacher's encoder); otherwise it encodes the features itself.
             from .decoding import assisted_greedy_decode
-            if suppress_tokens or begin_suppress_tokens:
-                raise ValueError("assisted decoding does not take suppress_tokens / begin_suppress_tokens here")
+            if gc.return_timestamps:
+                raise NotImplementedError("assistant_model with return_timestamps is not implemented on the MI355X path")
+            begin_suppress = None          # TF:719-721: the model must be able to return EOS right away
             assistant_model._sync_shadow()
             ad = assistant_model.dims
             if getattr(assistant_model, "share_encoder_output", None) or \
                     (input_features is None and ad.d_model == d.d_model):
-                enc_a = enc.to(assistant_model.engine.stream)
+                enc_a = enc.to(assistant_model.engine.lowp)
             else:
                 if input_features is None:
                     raise ValueError("the assistant needs input_features (its encoder differs from this model's)")
                 enc_a, _ = assistant_model.engine.encode(input_features.to(torch.float32).contiguous(), save=False)
-            out, self.last_drafted, self.last_accepted = assisted_greedy_decode(
-                eng, assistant_model.engine, enc, enc_a, ids, max_new_tokens, num_assistant_tokens, eos_token_id)
-            return out
-        ts_rules = None
-        if return_timestamps:
-            # WhisperTimeStampLogitsProcessor (TF:generation_whisper.py:1774-1812); needs the vocabulary landmarks
-            if no_timestamps_token_id is None or eos_token_id is None:
-                raise ValueError("return_timestamps=True needs no_timestamps_token_id and eos_token_id")
-            if not use_cache:
-                raise ValueError("return_timestamps=True runs on the KV-cache decoder (use_cache=True)")
-            ts_rules = dict(begin_index=ids.shape[1], no_timestamps_token_id=int(no_timestamps_token_id),
-                            max_initial_timestamp_index=max_initial_timestamp_index)
-            use_graphs = False            # the rule kernels have not been exercised under stream capture yet
-        if use_cache:
+            k = getattr(gc, "num_assistant_tokens", None) or \
+                getattr(getattr(assistant_model, "generation_config", None), "num_assistant_tokens", None) or 5
+            seqs, self.last_drafted, self.last_accepted = assisted_greedy_decode(
+                eng, assistant_model.engine, enc, enc_a, ids, max_new, int(k), eos, suppress_tokens=suppress,
+                min_new_tokens=min_new, pad_token_id=pad)
+        elif use_cache:
             from .decoding import GreedyDecoder
-            key = (B, total, eos_token_id, bool(use_graphs), tuple(suppress_tokens or ()),
-                   tuple(begin_suppress_tokens or ()), None if ts_rules is None else tuple(sorted(ts_rules.items())))
+            ts_rules = None
+            if gc.return_timestamps:
+                if eos is None:
+                    raise ValueError("return_timestamps=True needs eos_token_id in the generation config")
+                ts_rules = dict(begin_index=P, no_timestamps_token_id=int(gc.no_timestamps_token_id),
+                                max_initial_timestamp_index=getattr(gc, "max_initial_timestamp_index", None))
+            total = P + max_new
+            key = (B, total, eos, pad, bool(use_graphs), tuple(suppress or ()), tuple(begin_suppress or ()),
+                   None if ts_rules is None else tuple(sorted(ts_rules.items())))
             dec = self._decoders.get(key)
             if dec is None:
-                dec = GreedyDecoder(eng, B, total, eos_token_id=eos_token_id, suppress_tokens=suppress_tokens,
-                                    begin_suppress_tokens=begin_suppress_tokens, use_graphs=use_graphs,
-                                    check_every=16 if use_graphs else 1, timestamp_rules=ts_rules)
+                dec = GreedyDecoder(eng, B, total, eos_token_id=eos, suppress_tokens=suppress,
+                                    begin_suppress_tokens=begin_suppress, use_graphs=use_graphs,
+                                    check_every=16 if use_graphs else 1, timestamp_rules=ts_rules, pad_token_id=pad)
                 self._decoders = {key: dec}        # one live decoder (its graphs pin the K/V cache buffers)
-            return dec.run(enc, ids, max_new_tokens)
-        done = torch.zeros(B, dtype=torch.bool, device=ids.device)
-        sup = None
-        if suppress_tokens:
-            sup = torch.zeros(d.vocab, device=dev)
-            sup[torch.as_tensor(list(suppress_tokens), device=dev)] = float("-inf")
-        bsup = None
-        if begin_suppress_tokens:
-            bsup = torch.zeros(d.vocab, device=dev)
-            bsup[torch.as_tensor(list(begin_suppress_tokens), device=dev)] = float("-inf")
-        for step in range(max_new_tokens):
+            seqs = dec.run(enc, ids, max_new, min_new)
+        else:
+            if gc.return_timestamps:
+                raise ValueError("return_timestamps=True runs on the KV-cache decoder (use_cache=True)")
+            seqs = self._greedy_no_cache(enc, ids, max_new, min_new, eos, pad, suppress, begin_suppress)
+        seqs = self._trim_finished(seqs, P, eos, pad)
+        if return_dict_in_generate or getattr(gc, "return_dict_in_generate", False):
+            return G.GenerateOutput(seqs)
+        if force_unique_generate_call:
+            return seqs
+        return G.strip_and_pad(seqs, P, eos, pad)
+
+    # -- helpers of generate ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _trim_finished(seqs, P, eos, pad):
+        """GenerationMixin stops as soon as every row has emitted EOS: drop the all-padding columns a decoder that
+        checks the stop condition every few steps (HIP-graph replay) may have appended."""
+        if eos is None or seqs.shape[1] <= P:
+            return seqs
+        gen = seqs[:, P:]
+        is_eos = gen == eos
+        n = gen.shape[1]
+        first = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((gen.shape[0],), n, device=gen.device))
+        keep = int(first.max().item())
+        return seqs[:, : P + keep]
+
+    def _detect_language(self, enc, B, gc):
+        """TF:1610-1674 `detect_language`: one decoder step on <|startoftranscript|>, argmax over the language ids."""
+        d = self.dims
+        ids = torch.full((B, 1), gc.decoder_start_token_id, dtype=torch.long, device=enc.device)
+        logits, _ = self.engine.decode(ids, enc, save=False)
+        sc = logits[:B, : d.vocab].float()
+        lang_ids = torch.as_tensor(sorted(gc.lang_to_id.values()), dtype=torch.long, device=enc.device)
+        mask = torch.full((d.vocab,), float("-inf"), device=enc.device)
+        mask[lang_ids] = 0.0
+        return (sc + mask).argmax(-1).tolist()
+
+    def _greedy_no_cache(self, enc, ids, max_new, min_new, eos, pad, suppress, begin_suppress):
+        """Greedy search that re-decodes the whole prefix at every step (no KV cache): the cross-check of the cached
+        decoder."""
+        eng, d = self.engine, self.dims
+        B, dev = ids.shape[0], ids.device
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+
+        def mask(tokens):
+            if not tokens:
+                return None
+            m = torch.zeros(d.vocab, device=dev)
+            m[torch.as_tensor(list(tokens), device=dev)] = float("-inf")
+            return m
+        sup, bsup = mask(suppress), mask(begin_suppress)
+        for step in range(max_new):
             T = ids.shape[1]
             logits, _ = eng.decode(ids.contiguous(), enc, save=False)
             sc = logits[: B * T, : d.vocab].view(B, T, -1)[:, -1].float()
-            if sup is not None:
-                sc = sc + sup
+            if eos is not None and step < min_new:
+                sc[:, eos] = float("-inf")
             if step == 0 and bsup is not None:
                 sc = sc + bsup
+            if sup is not None:
+                sc = sc + sup
             nxt = sc.argmax(-1)
-            if eos_token_id is not None:
-                nxt = torch.where(done, torch.full_like(nxt, eos_token_id), nxt)
-                done |= nxt == eos_token_id
+            if eos is not None:
+                nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+                done |= nxt == eos
             ids = torch.cat([ids, nxt[:, None]], 1)
-            if eos_token_id is not None and bool(done.all()):
+            if eos is not None and bool(done.all()):
                 break
         return ids

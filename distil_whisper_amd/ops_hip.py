@@ -58,7 +58,7 @@ _SIGS = {
     "dw_cast_bf16_f32": ([C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p], C.c_int),
     "dw_colsum_bf16": ([C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "dw_add": ([C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p], C.c_int),
-    "dw_sumsq_f32": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p], C.c_int),
+    "dw_sumsq_f32": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 2 + [C.c_double] * 5 + [C.c_int, C.c_void_p], C.c_int),
     "dw_selftest_tr16": ([C.c_void_p, C.c_void_p], C.c_int),
     "dw_debug_set": ([C.c_int, C.c_int], C.c_int),
@@ -433,7 +433,9 @@ class HipOps:
 
     def sumsq(self, g, out):
         assert g.dtype == torch.float32 and g.is_contiguous()
-        self._chk(self.lib.dw_sumsq_f32(_p(g), g.numel(), _p(out), self._stream()), "sumsq")
+        if getattr(self, "_sumsq_ws", None) is None:
+            self._sumsq_ws = self.empty((2048,), torch.float32)        # DW_SUMSQ_PARTIALS
+        self._chk(self.lib.dw_sumsq_f32(_p(g), g.numel(), _p(out), _p(self._sumsq_ws), self._stream()), "sumsq")
         return out
 
     def adamw(self, p, g, m, v, shadow, sumsq, max_norm, grad_mul, lr, beta1, beta2, eps, weight_decay, step):

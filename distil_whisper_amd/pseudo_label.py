@@ -44,7 +44,8 @@ class PseudoLabeller:
     """audios (list of 1-D 16 kHz waveforms, each <= 30 s) -> (token id lists per pack, packs, condition_on_prev)."""
 
     def __init__(self, model, feature_extractor, batch_size=16, max_new_tokens=255, prompt_ids=None, eos_token_id=None,
-                 timestamp_rules=None, use_graphs=None, rank=0, world=1):
+                 timestamp_rules=None, use_graphs=None, rank=0, world=1, suppress_tokens=None,
+                 begin_suppress_tokens=None):
         self.model, self.fe = model, feature_extractor
         self.B, self.max_new = int(batch_size), int(max_new_tokens)
         self.rank, self.world = rank, world
@@ -58,6 +59,7 @@ class PseudoLabeller:
             use_graphs = False
         self.eos = eos_token_id
         self.decoder = GreedyDecoder(model.engine, self.B, len(self.prompt) + self.max_new, eos_token_id=eos_token_id,
+                                     suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens,
                                      use_graphs=use_graphs, timestamp_rules=timestamp_rules)
         self._wave = torch.zeros((self.B, feature_extractor.n_samples), dtype=torch.float32, device=dev)
 

@@ -68,15 +68,39 @@ def student_layer_map(n_teacher: int, n_student: int):
     return [int(x) for x in m]
 
 
-def student_from_teacher(teacher_sd, tdims: WhisperDims, enc_layers: int, dec_layers: int):
-    sdims = WhisperDims(**{**tdims.__dict__, "enc_layers": enc_layers, "dec_layers": dec_layers})
+def student_from_teacher(teacher_sd, tdims: WhisperDims, enc_layers=None, dec_layers: int = 2,
+                         decoder_layers_numbers=None):
+    """`init_student_model_from_teacher` (create_student_model.py:92-182).  The reference first loads the teacher's
+    state dict non-strictly into the smaller student (so student layer i starts as teacher layer i), then overwrites
+    the mapped layers: decoder layers always (129-144, 169-175), through `{teacher_layer: student_layer}` dictionaries
+    built from `np.linspace` or from the `decoder_layers_numbers` override (136-139; a teacher layer listed twice keeps
+    its LAST student slot); encoder layers only when `encoder_layers` was given (177-182)."""
+    if decoder_layers_numbers is not None and len(decoder_layers_numbers) != dec_layers:
+        raise ValueError(f"Got {len(decoder_layers_numbers)} layers number for {dec_layers} decoder layers.")
+    n_enc = enc_layers if enc_layers is not None else tdims.enc_layers
+    sdims = WhisperDims(**{**tdims.__dict__, "enc_layers": n_enc, "dec_layers": dec_layers})
     sd = {k: v for k, v in teacher_sd.items() if ".layers." not in k and k != "proj_out.weight"}
-    for part, nt, ns, cross in (("encoder", tdims.enc_layers, enc_layers, False),
-                                ("decoder", tdims.dec_layers, dec_layers, True)):
-        for si, ti in enumerate(student_layer_map(nt, ns)):
-            for n, kind in layer_names(f"model.{part}.layers.{ti}", cross):
-                if kind != "zero":
-                    sd[n.replace(f".layers.{ti}.", f".layers.{si}.")] = teacher_sd[n]
+    enc_map = {t: s for s, t in enumerate(student_layer_map(tdims.enc_layers, n_enc))}
+    dec_src = student_layer_map(tdims.dec_layers, dec_layers) if decoder_layers_numbers is None \
+        else [int(x) for x in decoder_layers_numbers]
+    dec_map = {t: s for s, t in enumerate(dec_src)}
+
+    def copy_layer(part, cross, ti, si):
+        for n, kind in layer_names(f"model.{part}.layers.{ti}", cross):
+            if kind != "zero":
+                sd[n.replace(f".layers.{ti}.", f".layers.{si}.")] = teacher_sd[n]
+
+    for part, nt, ns, cross, mp, remap in (("encoder", tdims.enc_layers, n_enc, False, enc_map, enc_layers is not None),
+                                           ("decoder", tdims.dec_layers, dec_layers, True, dec_map, True)):
+        for i in range(min(ns, nt)):                          # non-strict load_state_dict: same-index layers
+            copy_layer(part, cross, i, i)
+        if remap:
+            for ti in range(nt):
+                if ti in mp:
+                    copy_layer(part, cross, ti, mp[ti])
+        missing = [i for i in range(ns) if f"model.{part}.layers.{i}.fc1.weight" not in sd]
+        if missing:
+            raise RuntimeError(f"student {part} layers {missing} have no teacher layer to start from")
     return sd, sdims
 
 

@@ -154,7 +154,11 @@ int dw_add(const void* a, int a_dtype, const void* b, int b_dtype, void* y, int 
  * sumsq: out[0] += sum(g^2) (zero it first).  adamw: clip = min(1, max_norm/(sqrt(sumsq[0])+1e-6)) (max_norm <= 0
  * disables), g' = g*clip*grad_mul; p *= 1-lr*wd; m,v update; p -= lr/bc1 * m/(sqrt(v)/sqrt(bc2)+eps); the bf16
  * shadow copy used by the GEMMs is refreshed in the same pass (shadow may be NULL). */
-int dw_sumsq_f32(const float* g, int64_t n, float* out, void* stream);
+#define DW_SUMSQ_PARTIALS 2048
+/* partials: caller-owned scratch of DW_SUMSQ_PARTIALS floats.  Two deterministic stages (per-block partials, then one
+ * block adds them in a fixed order; no float atomics): data-parallel replicas must derive bit-identical clip
+ * coefficients from their bit-identical all-reduced gradients. */
+int dw_sumsq_f32(const float* g, int64_t n, float* out, float* partials, void* stream);
 int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq,
              float max_norm, float grad_mul, double lr, double beta1, double beta2, double eps, double weight_decay,
              int step, void* stream);

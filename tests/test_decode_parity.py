@@ -1,0 +1,210 @@
+"""Decode family vs the reference: token ids of `generate` (greedy, suppress / begin-suppress rules, language / task /
+language detection prefixes, timestamp rules, prompt_ids, min/max_new_tokens on given encoder outputs, speculative
+decoding), of the chunked long-form scheduler and of the pseudo-labelling packs must be IDENTICAL to what
+`transformers.WhisperForConditionalGeneration.generate` (+ `chunk_iter` / `_find_longest_common_sequence`) produced on
+the same seeded weights and inputs (tests/golden/decode.json, made by oracle/gen_golden_decode.py).
+
+Integer work: the bar is bit-exact.  The GPU path computes in bf16 and the fixtures come from the fp32 reference, so
+the generator only keeps cases whose smallest top-1/top-2 logit margin is far above the bf16 rounding noise (margin
+stored per scenario; `meta.min_margin`).  CPU leg: the same host logic over the torch restatement of the kernels in
+fp32; GPU leg (`-m gpu`): the HIP kernels, with HIP-graph replay on."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gen_golden_decode as gd
+from oracle import whisper_oracle as wo
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decode.json")))
+SC = {s["name"]: s for s in GOLD["scenarios"]}
+
+
+def _ops(kind):
+    if kind == "hip":
+        from distil_whisper_amd.ops_hip import HipOps
+        return HipOps("cuda:0")
+    from oracle.ref_ops import RefOps
+    return RefOps("cpu", lowp=torch.float32)
+
+
+def _model(ops, cfg, sd, fields, dtype=torch.float32):
+    from distil_whisper_amd.generation import GenerationConfig
+    from distil_whisper_amd.modeling import WhisperForConditionalGeneration
+    m = WhisperForConditionalGeneration(cfg, ops=ops, state_dict=sd, dtype=dtype)
+    m.generation_config = GenerationConfig.from_any(fields)
+    return m
+
+
+def _models(ops, seed, fields):
+    sd_t = gd.weights(seed)
+    sd_s, cfg_s = gd.student(sd_t)
+    return _model(ops, gd.CFG_T, sd_t, fields), _model(ops, cfg_s, sd_s, fields)
+
+
+def _check_short(ops, s, graphs):
+    teacher, student = _models(ops, s["seed"], s["generation_config"])
+    model = teacher if s["model"] == "teacher" else student
+    kw = dict(s["gen_kwargs"])
+    if "prompt_ids" in kw:
+        kw["prompt_ids"] = torch.tensor(kw["prompt_ids"], device=ops.device)
+    B = s["B"]
+    if s["use_encoder_outputs"]:
+        from distil_whisper_amd.modeling import BaseModelOutput
+        g = torch.Generator().manual_seed(s["seed"] + 7)
+        enc = torch.randn(B, gd.CFG_T.max_src, gd.CFG_T.d_model, generator=g).to(ops.device)
+        args = ()
+        kw["encoder_outputs"] = BaseModelOutput(last_hidden_state=enc)
+    else:
+        args = (gd.features(s["seed"] + 1, B).to(ops.device),)
+    if s["assistant"]:
+        kw["assistant_model"] = student
+    else:
+        kw["use_graphs"] = graphs
+    seq = model.generate(*args, return_dict_in_generate=True, **kw).sequences
+    assert seq.tolist() == s["sequences"], (s["name"], seq.tolist(), s["sequences"])
+    plain = model.generate(*args, **kw)
+    assert plain.tolist() == s["plain"], (s["name"], "plain return value")
+    if s["assistant"]:
+        assert model.last_accepted >= 0 and model.last_drafted >= model.last_accepted
+
+
+def _check_longform(ops, s, graphs):
+    from distil_whisper_amd.longform import LongFormTranscriber
+    from distil_whisper_amd.modeling import WhisperFeatureExtractor
+    _, student = _models(ops, s["seed"], s["generation_config"])
+    fe = WhisperFeatureExtractor(feature_size=80, ops=ops)
+    audios = [gd.audio(s["seed"] * 10 + i, n) for i, n in enumerate(s["lengths"])]
+    gc = s["generation_config"]
+    tr = LongFormTranscriber(student, fe, batch_size=s["batch"], chunk_length_s=30.0, max_new_tokens=s["max_new_tokens"],
+                             prompt_ids=[gc["decoder_start_token_id"], gc["no_timestamps_token_id"]],
+                             eos_token_id=gc["eos_token_id"], first_special_id=gc["eos_token_id"],
+                             suppress_tokens=gc["suppress_tokens"], use_graphs=graphs)
+    got = tr(audios)
+    assert got == s["merged"], (got, s["merged"])
+
+
+def _check_pseudo_label(ops, s, graphs):
+    from distil_whisper_amd.modeling import WhisperFeatureExtractor
+    from distil_whisper_amd.pseudo_label import PseudoLabeller, pack_plan
+    teacher, _ = _models(ops, s["seed"], s["generation_config"])
+    fe = WhisperFeatureExtractor(feature_size=80, ops=ops)
+    audios = [gd.audio(s["seed"] * 10 + i, n) for i, n in enumerate(s["lengths"])]
+    packs, _ = pack_plan(s["lengths"], s["speakers"], 480000)
+    assert packs == s["packs"]
+    gc = s["generation_config"]
+    prompt = [gc["decoder_start_token_id"], gc["lang_to_id"]["<|en|>"], gc["task_to_id"]["transcribe"]]
+    lab = PseudoLabeller(teacher, fe, batch_size=2, max_new_tokens=s["max_new_tokens"], prompt_ids=prompt,
+                         eos_token_id=gc["eos_token_id"], suppress_tokens=gc["suppress_tokens"],
+                         begin_suppress_tokens=gc["begin_suppress_tokens"],
+                         timestamp_rules=dict(no_timestamps_token_id=gc["no_timestamps_token_id"],
+                                              max_initial_timestamp_index=gc["max_initial_timestamp_index"]),
+                         use_graphs=graphs)
+    ids, packs2, _ = lab(audios, s["speakers"])
+    assert packs2 == s["packs"]
+    for row, ref in zip(ids, s["sequences"]):
+        want = ref[len(prompt):]
+        if gc["eos_token_id"] in want:
+            want = want[: want.index(gc["eos_token_id"])]
+        assert row == want, (row, want)
+
+
+def _run_all(ops, graphs):
+    assert GOLD["meta"]["min_margin"] >= 0.05
+    for s in GOLD["scenarios"]:
+        assert s["margin"] >= GOLD["meta"]["min_margin"] or os.environ.get("DECODE_GOLDEN_DEBUG"), (s["name"], s["margin"])
+        if s["kind"] == "short":
+            _check_short(ops, s, graphs)
+        elif s["kind"] == "longform":
+            _check_longform(ops, s, graphs)
+        else:
+            _check_pseudo_label(ops, s, graphs)
+
+
+def test_decode_family_matches_reference_fixtures_cpu():
+    _run_all(_ops("ref"), graphs=False)
+
+
+@pytest.mark.gpu
+def test_decode_family_matches_reference_fixtures_gpu():
+    _run_all(_ops("hip"), graphs=True)
+
+
+@pytest.mark.gpu
+def test_decode_family_eager_equals_graph_replay_gpu():
+    ops = _ops("hip")
+    for name in ("greedy_suppress_student", "timestamps_single_call"):
+        _check_short(ops, SC[name], graphs=False)
+
+
+def _encoder_outputs_and_shared_assistant(ops):
+    """`generate(encoder_outputs=...)` in every accepted layout (run_eval.py:806-844 `benchmark_gen`) and an assistant
+    that re-uses the target's encoder output (run_eval.py:578-599), on the margin-selected fixture cases: the same
+    reference tokens as the calls that start from input_features."""
+    from distil_whisper_amd.modeling import BaseModelOutput
+    s = SC["language_task_teacher"]
+    teacher, _ = _models(ops, s["seed"], s["generation_config"])
+    feats = gd.features(s["seed"] + 1, s["B"]).to(ops.device)
+    enc, _ = teacher.engine.encode(feats.float().contiguous(), save=False)
+    L, B = gd.CFG_T.max_src, s["B"]
+    for eo in (enc[: B * L].clone(), enc[: B * L].float().view(B, L, -1),
+               BaseModelOutput(last_hidden_state=enc[: B * L].float().view(B, L, -1)), (enc[: B * L].view(B, L, -1),)):
+        got = teacher.generate(encoder_outputs=eo, return_dict_in_generate=True, **s["gen_kwargs"]).sequences
+        assert got.tolist() == s["sequences"]
+    s = SC["assisted_teacher_student"]
+    teacher, student = _models(ops, s["seed"], s["generation_config"])
+    feats = gd.features(s["seed"] + 1, 1).to(ops.device)
+    enc, _ = teacher.engine.encode(feats.float().contiguous(), save=False)
+    student.share_encoder_output = True
+    a = teacher.generate(feats, assistant_model=student, return_dict_in_generate=True, **s["gen_kwargs"]).sequences
+    b = teacher.generate(encoder_outputs=enc[:L].clone(), assistant_model=student, return_dict_in_generate=True,
+                         **s["gen_kwargs"]).sequences
+    assert a.tolist() == s["sequences"] and b.tolist() == s["sequences"]
+
+
+def test_encoder_outputs_layouts_and_shared_encoder_assistant_cpu():
+    _encoder_outputs_and_shared_assistant(_ops("ref"))
+
+
+@pytest.mark.gpu
+def test_encoder_outputs_layouts_and_shared_encoder_assistant_gpu():
+    _encoder_outputs_and_shared_assistant(_ops("hip"))
+
+
+def test_generate_matches_transformers_live_and_rejects_unsupported_arguments():
+    """Direct comparison with the imported reference class on a fresh seed (no margin selection: fp32 both sides), and
+    the loud failures for arguments the engine path does not implement."""
+    pytest.importorskip("transformers")
+    ops = _ops("ref")
+    fields = gd.generation_fields(multilingual=True, suppress=True)
+    seed = 7
+    sd_t = gd.weights(seed)
+    model = _model(ops, gd.CFG_T, sd_t, fields)
+    feats = gd.features(seed + 1, 2)
+    for kw in (dict(max_new_tokens=7, language="hi", task="transcribe"),
+               dict(max_new_tokens=5, language=["en", "de"]),
+               dict(max_length=9, language="<|fr|>", prompt_ids=[gd.STARTOFPREV, 700, 701])):
+        hkw = dict(kw)
+        if "prompt_ids" in hkw:
+            hkw["prompt_ids"] = torch.tensor(hkw["prompt_ids"])
+        ref, ref_plain, _ = gd.hf_generate(gd.CFG_T, sd_t, fields, feats, want_plain=True, **hkw)
+        got = model.generate(feats, return_dict_in_generate=True, **kw).sequences
+        assert got.tolist() == ref.tolist(), kw
+        assert model.generate(feats, **kw).tolist() == ref_plain.tolist(), kw
+    for bad, exc in ((dict(num_beams=4), NotImplementedError), (dict(do_sample=True), NotImplementedError),
+                     (dict(temperature=(0.2, 0.4)), NotImplementedError),
+                     (dict(condition_on_prev_tokens=True), NotImplementedError),
+                     (dict(no_speech_threshold=0.6), NotImplementedError),
+                     (dict(return_token_timestamps=True), NotImplementedError),
+                     (dict(languge="en"), ValueError), (dict(language="klingon"), ValueError),
+                     (dict(task="summarize", language="en"), ValueError),
+                     (dict(max_new_tokens=500), ValueError)):
+        with pytest.raises(exc):
+            model.generate(feats, **bad)
+    with pytest.raises(NotImplementedError, match="long-form"):
+        model.generate(torch.zeros(1, 80, 6000))
+    en = _model(ops, gd.CFG_T, sd_t, gd.generation_fields(multilingual=False))
+    with pytest.raises(ValueError, match="English-only"):
+        en.generate(feats, language="en")

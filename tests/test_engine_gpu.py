@@ -10,6 +10,11 @@ import torch
 
 from oracle import whisper_oracle as wo
 
+
+def _seq(model, *a, **k):
+    """prompt + generated tokens (the `.sequences` of the reference's return_dict_in_generate=True output)"""
+    return model.generate(*a, return_dict_in_generate=True, **k).sequences
+
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -58,7 +63,7 @@ def test_tiny_en_step_matches_reference_fixture(ops):
         ref = torch.tensor(g32[f"grad{i}"])
         got = st.g[n].reshape(-1)
         got = got[:: max(1, got.numel() // 256)][:256].cpu()
-        assert relerr(got, ref) < 0.1, (n, relerr(got, ref))
+        assert relerr(got, ref) < 0.05, (n, relerr(got, ref))   # 256 strided samples of one tensor, bf16 operands
     tr.optimizer_step()
     gn = tr.grad_norm().item()
     assert abs(gn - float(g32["grad_norm"])) < 2e-2 * float(g32["grad_norm"]), gn
@@ -95,7 +100,10 @@ def test_micro_step_matches_cpu_oracle(ops, shared):
             continue
         e = relerr(st.g[name], p.grad)
         worst = max(worst, e)
-        assert e < 0.12, (name, e)
+        a, b_ = st.g[name].float().cpu().reshape(-1), p.grad.float().reshape(-1)
+        cos = (a @ b_ / (a.norm() * b_.norm() + 1e-30)).item()
+        # bf16 restatement of the kernels vs this oracle on CPU: worst relerr 1.0e-2, cosine >= 0.99995; 3x margin
+        assert e < 0.03 and cos > 0.9995, (name, e, cos)
     print("worst grad relerr", worst)
 
 
@@ -115,8 +123,13 @@ def test_hip_engine_equals_torch_restatement_on_gpu(ops):
         tr = DistillationTrainer(o, s_sd, cfg_s, t_sd, cfg_t)
         out[name] = (tr.forward_backward(feats, ids, labels).cpu(), tr.student_store)
     assert relerr(out["hip"][0][:3], out["ref"][0][:3]) < 2e-4, (out["hip"][0], out["ref"][0])
+    worst = 0.0
     for n in out["ref"][1].g:
-        assert relerr(out["hip"][1].g[n], out["ref"][1].g[n]) < 0.03, n
+        e = relerr(out["hip"][1].g[n], out["ref"][1].g[n])
+        worst = max(worst, e)
+        # identical rounding points: what remains is fp32 summation order and the exp2 / rcp based GELU and softmax
+        assert e < 0.01, (n, e)
+    print("hip vs restatement worst grad relerr", worst)
 
 
 def test_drop_in_module_and_feature_extractor_on_gpu(ops):
@@ -153,8 +166,8 @@ def test_drop_in_module_and_feature_extractor_on_gpu(ops):
     for n in ("model.decoder.layers.0.fc1.weight", "model.encoder.layers.1.self_attn.v_proj.weight",
               "model.decoder.embed_tokens.weight", "model.encoder.conv2.weight"):
         assert relerr(model.get_parameter(n).grad, params[n].grad) < 0.1, n
-    ids = model.generate(feats.cuda(), max_new_tokens=8, use_cache=True)
-    ids2 = model.generate(feats.cuda(), max_new_tokens=8, use_cache=False)
+    ids = _seq(model, feats.cuda(), max_new_tokens=8, use_cache=True)
+    ids2 = _seq(model, feats.cuda(), max_new_tokens=8, use_cache=False)
     assert ids.shape == (2, 9) and torch.equal(ids, ids2)  # KV-cache decode == prefix re-decode
 
 
@@ -190,13 +203,13 @@ def test_graph_replayed_greedy_decode_and_longform_scheduler(ops):
     kw = dict(max_new_tokens=12, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6])
     for rep in range(2):                       # second round replays the graphs captured in the first
         feats = (torch.randn(4, cfg_s.n_mels, 3000, generator=g) * 0.5).cuda()
-        a = model.generate(feats, use_cache=True, use_graphs=True, **kw)
-        b = model.generate(feats, use_cache=True, use_graphs=False, **kw)
-        c = model.generate(feats, use_cache=False, **kw)
+        a = _seq(model, feats, use_cache=True, use_graphs=True, **kw)
+        b = _seq(model, feats, use_cache=True, use_graphs=False, **kw)
+        c = _seq(model, feats, use_cache=False, **kw)
         assert a.shape == (4, 13) and torch.equal(a, b) and torch.equal(a, c), rep
     eos = int(a[0, 5])
-    a = model.generate(feats, use_cache=True, use_graphs=True, eos_token_id=eos, **kw)
-    c = model.generate(feats, use_cache=False, eos_token_id=eos, **kw)
+    a = _seq(model, feats, use_cache=True, use_graphs=True, eos_token_id=eos, **kw)
+    c = _seq(model, feats, use_cache=False, eos_token_id=eos, **kw)
     n = min(a.shape[1], c.shape[1])
     assert torch.equal(a[:, :n], c[:, :n]) and bool((a[:, n:] == eos).all())
 
@@ -215,7 +228,7 @@ def test_graph_replayed_greedy_decode_and_longform_scheduler(ops):
         seqs = []
         for start, length, _, _, _ in chunk_spans(len(a), 480000, 80000, 80000):
             f = fe(a[start:start + length], sampling_rate=16000, return_tensors="pt").input_features
-            ids = model.generate(f, max_new_tokens=10, use_cache=False)[0, 1:].tolist()
+            ids = _seq(model, f, max_new_tokens=10, use_cache=False)[0, 1:].tolist()
             text = [t for t in ids if t < first_special]
             if text:
                 seqs.append(text)

@@ -15,6 +15,11 @@ from distil_whisper_amd.modeling import WhisperFeatureExtractor, WhisperForCondi
 from oracle import whisper_oracle as wo
 from oracle.ref_ops import RefOps
 
+
+def _seq(model, *a, **k):
+    """prompt + generated tokens (the `.sequences` of the reference's return_dict_in_generate=True output)"""
+    return model.generate(*a, return_dict_in_generate=True, **k).sequences
+
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "longform.json")))
 
 
@@ -76,9 +81,9 @@ def test_greedy_decoder_matches_prefix_redecode_with_suppression_and_eos():
     cfg, model, fe = _model()
     g = torch.Generator().manual_seed(1)
     feats = torch.randn(3, cfg.n_mels, 3000, generator=g) * 0.5
-    ref = model.generate(feats, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6])
+    ref = _seq(model, feats, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6])
     eos = int(ref[0, 3])              # a token the model really emits -> exercises the EOS fill
-    ref = model.generate(feats, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6],
+    ref = _seq(model, feats, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6],
                          eos_token_id=eos)
     enc, _ = model.engine.encode(feats, save=False)
     dec = GreedyDecoder(model.engine, 3, 8, eos_token_id=eos, suppress_tokens=[3, 4, 5], begin_suppress_tokens=[6],
@@ -90,7 +95,7 @@ def test_greedy_decoder_matches_prefix_redecode_with_suppression_and_eos():
     # the decoder is reusable: second batch through the same buffers
     feats2 = torch.randn(3, cfg.n_mels, 3000, generator=g) * 0.5
     enc2, _ = model.engine.encode(feats2, save=False)
-    ref2 = model.generate(feats2, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5],
+    ref2 = _seq(model, feats2, max_new_tokens=7, use_cache=False, suppress_tokens=[3, 4, 5],
                           begin_suppress_tokens=[6], eos_token_id=eos)
     assert torch.equal(dec.run(enc2, prompt, 7), ref2)
     with pytest.raises(ValueError, match="exceeds the decoder's max_len"):
@@ -111,7 +116,7 @@ def test_transcriber_equals_per_window_generate_plus_stitching():
         seqs = []
         for start, length, _, _, _ in chunk_spans(len(a), 480000, 80000, 80000):
             f = fe(a[start:start + length], sampling_rate=16000, return_tensors="pt").input_features
-            ids = model.generate(f, max_new_tokens=6, use_cache=False)[0, 1:].tolist()
+            ids = _seq(model, f, max_new_tokens=6, use_cache=False)[0, 1:].tolist()
             text = [t for t in ids if t < first_special]
             if text:
                 seqs.append(text)
@@ -131,15 +136,15 @@ def test_assisted_greedy_decoding_equals_target_greedy():
     other = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=wo.student_from_teacher(
         wo.init_state_dict(cfg_t, 12), cfg_t, 2, 1)[0])
     feats = torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(2)) * 0.5
-    ref = teacher.generate(feats, max_new_tokens=9, use_cache=False)
+    ref = _seq(teacher, feats, max_new_tokens=9, use_cache=False)
     for assistant, k in ((student, 4), (other, 3), (teacher, 5)):
-        out = teacher.generate(feats, max_new_tokens=9, assistant_model=assistant, num_assistant_tokens=k)
+        out = _seq(teacher, feats, max_new_tokens=9, assistant_model=assistant, num_assistant_tokens=k)
         assert torch.equal(out, ref)
         assert teacher.last_accepted <= teacher.last_drafted
     assert teacher.last_accepted == teacher.last_drafted        # the teacher as its own assistant: all drafts accepted
     eos = int(ref[0, 4])
-    ref_e = teacher.generate(feats, max_new_tokens=9, use_cache=False, eos_token_id=eos)
-    out_e = teacher.generate(feats, max_new_tokens=9, assistant_model=student, num_assistant_tokens=4, eos_token_id=eos)
+    ref_e = _seq(teacher, feats, max_new_tokens=9, use_cache=False, eos_token_id=eos)
+    out_e = _seq(teacher, feats, max_new_tokens=9, assistant_model=student, num_assistant_tokens=4, eos_token_id=eos)
     n = min(ref_e.shape[1], out_e.shape[1])
     assert torch.equal(out_e[:, :n], ref_e[:, :n])
     assert bool((out_e[:, n:] == eos).all()) and bool((ref_e[:, n:] == eos).all())
@@ -233,7 +238,7 @@ def test_pseudo_labeller_equals_generate_on_packed_audio():
     for p, t in zip(packs, toks):
         wave = np.concatenate([audios[i] for i in p])
         f = fe(wave, sampling_rate=16000, return_tensors="pt").input_features
-        ref = model.generate(f, max_new_tokens=6, use_cache=False, eos_token_id=eos)[0, 1:].tolist()
+        ref = _seq(model, f, max_new_tokens=6, use_cache=False, eos_token_id=eos)[0, 1:].tolist()
         ref = ref[:ref.index(eos)] if eos in ref else ref
         assert t == ref
     # two ranks cover the packs disjointly

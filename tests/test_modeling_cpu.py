@@ -10,6 +10,11 @@ from oracle import whisper_oracle as wo
 from oracle.ref_ops import RefOps
 
 
+
+def _seq(model, *a, **k):
+    """prompt + generated tokens (the `.sequences` of the reference's return_dict_in_generate=True output)"""
+    return model.generate(*a, return_dict_in_generate=True, **k).sequences
+
 def relerr(a, b):
     return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
 
@@ -93,14 +98,14 @@ def test_error_behaviour_mirrors_reference():
 
 def test_greedy_generate_kv_cache_equals_prefix_redecode():
     cfg_s, s_sd, model, feats, ids, labels = build()
-    a = model.generate(feats, max_new_tokens=6, use_cache=True)
-    b = model.generate(feats, max_new_tokens=6, use_cache=False)
+    a = _seq(model, feats, max_new_tokens=6, use_cache=True)
+    b = _seq(model, feats, max_new_tokens=6, use_cache=False)
     assert a.shape == (2, 7) and int(a[0, 0]) == cfg_s.decoder_start_token_id
     assert torch.equal(a, b)
     # with a prompt
     prompt = torch.tensor([[cfg_s.decoder_start_token_id, 5, 9], [cfg_s.decoder_start_token_id, 7, 3]])
-    c = model.generate(feats, max_new_tokens=3, decoder_start_ids=prompt, use_cache=True)
-    e = model.generate(feats, max_new_tokens=3, decoder_start_ids=prompt, use_cache=False)
+    c = _seq(model, feats, max_new_tokens=3, decoder_input_ids=prompt, use_cache=True)
+    e = _seq(model, feats, max_new_tokens=3, decoder_input_ids=prompt, use_cache=False)
     assert torch.equal(c, e) and torch.equal(c[:, :3], prompt)
     # and the cached logits equal the teacher-forced forward logits at the same positions
     eng = model.engine

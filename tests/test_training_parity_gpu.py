@@ -1,0 +1,211 @@
+"""Training-path parity on the MI355X beyond BASELINE config 1 (tests/test_engine_gpu.py): config 2 (small.en 12/12 ->
+12/4) against the CPU oracle including gradients; batch-composition invariance of the full-size distil-large-v3 step
+(a size-independent property: the token-weighted losses and gradients of a batch equal the sum over its halves);
+large-v3 probe gradients at batch 1 against the oracle's autograd; data-parallel plumbing over RCCL with one rank;
+bit-reproducible global norm; save / resume."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as wo
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def cosine(a, b):
+    a, b = a.float().cpu().reshape(-1), b.float().cpu().reshape(-1)
+    return (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from distil_whisper_amd.ops_hip import HipOps
+    return HipOps("cuda:0")
+
+
+def make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, **kw):
+    from distil_whisper_amd.distill import DistillationTrainer
+    filt = torch.tensor(wo.mel_filter_bank(cfg_t.n_mels), dtype=torch.float32).cuda().contiguous()
+    return DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, mel_filters=filt, **kw)
+
+
+def test_small_en_step_matches_cpu_oracle_with_gradients(ops):
+    """BASELINE config 2 model (whisper-small.en-shaped 12/12 teacher -> distil-small.en 12/4 student) at a batch the
+    CPU oracle finishes in seconds: loss within 1e-3 relative (north_star), every parameter gradient within bf16
+    operand rounding of the oracle's autograd (measured with the bf16 restatement on CPU: worst relative error 1.0e-2,
+    cosine >= 0.99995 on the micro config; bounds below are 3x that)."""
+    cfg_t = wo.CONFIGS["small.en"]
+    t_sd = wo.init_state_dict(cfg_t, 81)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 12, 4)
+    assert [k for k in s_sd if k.startswith("model.decoder.layers.3.")]       # layers [0, 3, 7, 11] of the teacher
+    b = wo.synthetic_batch(cfg_t, 2, seed=82, with_audio=False)
+    feats = torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(5)) * 0.5
+    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
+    params = {k: v.clone().requires_grad_(k != "model.encoder.embed_positions.weight") for k, v in s_sd.items()}
+    loss, metrics, *_ = wo.train_step(params, cfg_s, t_sd, cfg_t, batch)
+    loss.backward()
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    losses = tr.forward_backward(feats.cuda(), batch["decoder_input_ids"].cuda(), batch["labels"].cuda()).cpu()
+    assert abs(losses[2].item() - loss.item()) < 1e-3 * abs(loss.item()), (losses.tolist(), loss.item())
+    assert abs(losses[0].item() - metrics["ce_loss"].item()) < 1e-3 * abs(metrics["ce_loss"].item())
+    st = tr.student_store
+    worst, worst_cos = 0.0, 1.0
+    for name, p in params.items():
+        if p.grad is None:
+            continue
+        e, c = relerr(st.g[name], p.grad), cosine(st.g[name], p.grad)
+        worst, worst_cos = max(worst, e), min(worst_cos, c)
+        assert e < 0.04 and c > 0.999, (name, e, c)
+    print("small.en worst grad relerr", worst, "min cosine", worst_cos)
+
+
+def test_large_v3_batch_composition_invariance_at_full_batch(ops):
+    """BASELINE config 3 at its bench size (32/32 teacher -> 32/2 student, B=32 x 30 s): the step over the whole batch
+    equals the token-weighted combination of the steps over its two halves -- CE and KL sums and every parameter
+    gradient (sum-normalised losses are linear in the batch; tile shapes, split-K partitions and rasterisation all
+    change between B=32 and B=16, so a tile-edge or partition error in any GEMM / attention / loss kernel breaks it)."""
+    cfg_t = wo.CONFIGS["large-v3"]
+    t_sd = wo.init_state_dict(cfg_t, 61)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 32, 2)
+    B = 32
+    b = wo.synthetic_batch(cfg_t, B, seed=63, with_audio=False)
+    g = torch.Generator().manual_seed(9)
+    feats = (torch.randn(B, cfg_t.n_mels, 3000, generator=g) * 0.5).cuda()
+    ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    del t_sd, s_sd
+    st = tr.student_store
+    probes = ["model.encoder.layers.0.fc1.weight", "model.encoder.layers.17.self_attn.q_proj.weight",
+              "model.encoder.layers.31.fc2.weight", "model.decoder.layers.1.encoder_attn.k_proj.weight",
+              "model.decoder.embed_tokens.weight", "model.encoder.conv2.weight",
+              "model.decoder.layers.0.self_attn.out_proj.bias", "model.encoder.layers.9.final_layer_norm.weight"]
+
+    def run(lo, hi):
+        l = tr.forward_backward(feats[lo:hi], ids[lo:hi], labels[lo:hi]).cpu()
+        torch.cuda.synchronize()
+        return l, {n: st.g[n].detach().clone() for n in probes}
+    l_all, g_all = run(0, B)
+    l_a, g_a = run(0, B // 2)
+    l_b, g_b = run(B // 2, B)
+    n_all, n_a, n_b = l_all[3].item(), l_a[3].item(), l_b[3].item()
+    assert n_all == n_a + n_b == float((labels != -100).sum().item())
+    for i, name in ((0, "ce"), (1, "kl"), (2, "loss")):
+        want = (l_a[i].item() * n_a + l_b[i].item() * n_b) / n_all
+        assert abs(l_all[i].item() - want) < 2e-5 * abs(want), (name, l_all[i].item(), want)
+    for n in probes:
+        want = (g_a[n] * n_a + g_b[n] * n_b) / n_all
+        e = relerr(g_all[n], want)
+        assert e < 2e-3, (n, e)
+    assert torch.isfinite(st.G).all()
+
+
+def test_large_v3_probe_gradients_match_cpu_oracle_at_batch_1(ops):
+    """distil-large-v3 dimensions, batch 1: probe gradients of the bf16 HIP step against the fp32 oracle's autograd."""
+    cfg_t = wo.CONFIGS["large-v3"]
+    t_sd = wo.init_state_dict(cfg_t, 61)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 32, 2)
+    b = wo.synthetic_batch(cfg_t, 1, seed=62, with_audio=False)
+    feats = torch.randn(1, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(3)) * 0.5
+    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
+    probes = ["model.encoder.layers.31.fc1.weight", "model.encoder.layers.0.self_attn.v_proj.weight",
+              "model.decoder.layers.1.fc2.weight", "model.decoder.layers.0.encoder_attn.q_proj.weight",
+              "model.encoder.conv1.weight", "model.decoder.layer_norm.weight"]
+    params = {k: (v.clone().requires_grad_(True) if k in probes else v) for k, v in s_sd.items()}
+    loss, metrics, *_ = wo.train_step(params, cfg_s, t_sd, cfg_t, batch)
+    loss.backward()
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    losses = tr.forward_backward(feats.cuda(), batch["decoder_input_ids"].cuda(), batch["labels"].cuda()).cpu()
+    assert abs(losses[2].item() - loss.item()) < 1e-3 * abs(loss.item())
+    for n in probes:
+        e, c = relerr(tr.student_store.g[n], params[n].grad), cosine(tr.student_store.g[n], params[n].grad)
+        print(n, "relerr", e, "cos", c)
+        assert e < 0.06 and c > 0.998, (n, e, c)
+
+
+def test_global_norm_is_bit_reproducible(ops):
+    """The clip coefficient is baked into every parameter update, so data-parallel replicas must derive bit-identical
+    norms from their bit-identical all-reduced gradients (two-stage reduction, no float atomics)."""
+    g = torch.randn(7_654_321, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    outs = []
+    for _ in range(8):
+        out = torch.zeros(1, device="cuda")
+        ops.sumsq(g, out)
+        outs.append(out.item())
+    assert len(set(outs)) == 1, outs
+    ref = (g.double() ** 2).sum().item()
+    assert abs(outs[0] - ref) < 1e-5 * ref
+
+
+def test_trainer_over_rccl_with_one_rank_equals_plain_trainer(ops):
+    """`GradReducer`'s side-stream bucketed all-reduce executed on ROCm (backend "nccl" = RCCL) with world_size 1 and
+    small buckets: parameters after two steps equal the run without a process group bit for bit."""
+    import torch.distributed as dist
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 91)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    b = wo.synthetic_batch(cfg_t, 2, seed=92, T=64, with_audio=False)
+    feats = (torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(8)) * 0.5).cuda()
+    ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+
+    def run(tr):
+        for _ in range(2):
+            tr.train_step(feats, ids, labels)
+        torch.cuda.synchronize()
+        return tr.student_store.P.clone(), tr.grad_norm().item()
+    p_plain, gn_plain = run(make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, always_reduce=True, bucket_bytes=64 << 10)
+        assert tr.reducer.stream is not None
+        launched = []
+        orig = tr.reducer._launch
+        tr.reducer._launch = lambda lo, hi: launched.append((lo, hi)) or orig(lo, hi)
+        p_dp, gn_dp = run(tr)
+        assert len(launched) >= 4                                  # several buckets per step went through RCCL
+        lo = min(a for a, _ in launched)
+        hi = max(b_ for _, b_ in launched)
+        assert lo == tr.student_store.train_start and hi == tr.student_store.train_end
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(p_plain, p_dp) and gn_plain == gn_dp
+
+
+def test_trainer_save_and_resume_is_bit_exact(ops):
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 93)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    b = wo.synthetic_batch(cfg_t, 2, seed=94, T=50, with_audio=False)
+    feats = (torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(4)) * 0.5).cuda()
+    ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+    a = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, weight_decay=0.01)
+    for _ in range(2):
+        a.train_step(feats, ids, labels)
+    state = a.state_dict()
+    a.train_step(feats, ids, labels)
+    r = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, weight_decay=0.01)
+    r.load_state_dict(state)
+    r.train_step(feats, ids, labels)
+    torch.cuda.synchronize()
+    assert r.step_count == a.step_count == 3
+    assert torch.equal(a.student_store.P, r.student_store.P) and torch.equal(a.student_store.M, r.student_store.M)
+    assert torch.equal(a.student_store.S, r.student_store.S)
+
+
+def test_empty_batch_reports_nan_like_the_reference(ops):
+    """All labels -100: the reference's CE / KL means are 0/0 = NaN; the HIP loss reports NaN too (visible), with a zero
+    gradient."""
+    s = torch.randn(64, 1024, device="cuda").to(torch.bfloat16)
+    t = torch.randn(64, 1024, device="cuda").to(torch.bfloat16)
+    labels = torch.full((64,), -100, dtype=torch.long, device="cuda")
+    losses = ops.distill_loss(s, t, labels, 1000, 2.0, 0.8, 1.0, 1.0, True)
+    assert torch.isnan(losses[:3]).all() and losses[3].item() == 0
+    assert float(s.float().abs().max()) == 0.0

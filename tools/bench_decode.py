@@ -15,10 +15,10 @@ del t_sd
 model = WhisperForConditionalGeneration(sdims, ops=ops, state_dict=s_sd)
 B, NEW = int(os.environ.get("B", 16)), int(os.environ.get("NEW", 64))
 feats = torch.randn(B, 128, 3000, device=dev) * 0.5
-model.generate(feats, max_new_tokens=4)
+model.generate(feats, max_new_tokens=4, return_dict_in_generate=True)
 torch.cuda.synchronize()
 t0 = time.perf_counter(); enc, _ = model.engine.encode(feats, save=False); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
-t0 = time.perf_counter(); ids = model.generate(feats, max_new_tokens=NEW); torch.cuda.synchronize(); t_all = time.perf_counter() - t0
+t0 = time.perf_counter(); ids = model.generate(feats, max_new_tokens=NEW, return_dict_in_generate=True).sequences; torch.cuda.synchronize(); t_all = time.perf_counter() - t0
 out = {"B": B, "new_tokens": NEW, "encode_ms": t_enc * 1e3, "generate_ms": t_all * 1e3,
        "ms_per_decode_step": (t_all - t_enc) / NEW * 1e3, "tokens_per_s": B * NEW / (t_all - t_enc),
        "rtfx_30s_chunks": B * 30.0 / t_all}
