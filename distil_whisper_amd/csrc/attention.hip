@@ -24,6 +24,7 @@ struct AttnP {
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Lq, Lk;
     long q_rows, kv_rows;  // rows between consecutive batches in memory (= Lq / Lk unless reading a padded KV cache)
+    int coff;              // causal mask: key <= query + coff (0 = top-left aligned, Lk - Lq = bottom-right aligned)
     float scale;
 };
 
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 
     int nkt = (p.Lk + 63) >> 6;
     if (CAUSAL) {
-        const int lim = (min(qb0 + 127, p.Lq - 1) >> 6) + 1;
+        const int lim = ((min(qb0 + 127, p.Lq - 1) + p.coff) >> 6) + 1;
         nkt = min(nkt, lim);
     }
     const float c = p.scale * 1.4426950408889634f;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, kb, kk, lane), qf[kk], s[kb], 0, 0, 0);
         }
         // mask (key tail / causal diagonal) only on the tiles that need it -- a wave-uniform test
-        const int wq0 = qb0 + wave * 32;
+        const int wq0 = qb0 + wave * 32 + (CAUSAL ? p.coff : 0);   // last key the wave's first query may see
         const bool need_mask = ((kt + 1) * 64 > p.Lk) || (CAUSAL && kt * 64 + 63 > wq0);
         if (CAUSAL && kt * 64 > wq0 + 31) continue;  // every key of this tile is in the future of all 32 queries
         float mx = NEG_BIG;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool ok = key < p.Lk && (!CAUSAL || key <= q);
+                    const bool ok = key < p.Lk && (!CAUSAL || key <= q + p.coff);
                     s[kb][r] = ok ? s[kb][r] : NEG_BIG;
                 }
         }
@@ -418,6 +419,11 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
     p.q_rows = q_batch_rows; p.kv_rows = kv_batch_rows;
+    // causal: 1 = query i sees keys <= i (training); 2 = bottom-right aligned, query i sees keys <= i + (Lk - Lq):
+    // several new queries against a longer KV cache (multi-token verify step of speculative decoding)
+    if (causal != 0 && causal != 1 && causal != 2) return DW_EINVAL;
+    if (causal == 2 && Lk < Lq) return DW_EINVAL;
+    p.coff = causal == 2 ? Lk - Lq : 0;
     dim3 grid((Lq + 127) / 128, H, B), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, p);
@@ -433,6 +439,7 @@ extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const vo
     DW_CLEAR_ERR();
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return DW_EINVAL;
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
+    if (causal != 0 && causal != 1) return DW_EINVAL;   // (the bottom-right aligned mask is a decoding-only mode)
     if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || check_ld(ldo) || check_ld(lddo)) return DW_EINVAL;
     if ((lddq & 3) || (lddk & 3) || (lddv & 3)) return DW_EINVAL;
     if ((int64_t)Lk * ldk >= (1LL << 31) || (int64_t)Lk * ldv >= (1LL << 31) || (int64_t)Lq * ldq >= (1LL << 31) ||

@@ -35,53 +35,11 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 ? 2 : 1) * WM * WN / 4) vo
     const int wm0 = (wave / WN) * TM;
     const int wn0 = (wave % WN) * TN;
 
-    // Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.
-    // The stores of tile i are still draining while the operand loads and MFMAs of tile i+1 run (a wave cannot
-    // retire before its stores are acknowledged, so one-tile workgroups expose the whole write burst).
-    // XCD-aware: the dispatcher places block b on XCD b%8; every XCD owns a contiguous range of the job list.
-    const int total = p.nwg * p.split_k;
-    const int bid = blockIdx.x;
     int job_first, job_count, job_step;
-    if ((int)gridDim.x == total) {           // one job per workgroup (small problems)
-        const int xcd = bid & 7, local = bid >> 3;
-        const int q = total >> 3, r = total & 7;
-        job_first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-        job_count = 1;
-        job_step = 1;
-    } else {                                 // gridDim.x is a multiple of 8: gridDim.x / 8 workgroups per XCD
-        const int xcd = bid & 7, local = bid >> 3;
-        const int q = total >> 3, r = total & 7;
-        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        const int cnt = q + (xcd < r ? 1 : 0);
-        job_step = gridDim.x >> 3;
-        job_first = start + local;
-        job_count = local < cnt ? (cnt - local + job_step - 1) / job_step : 0;
-    }
+    gemm_job_range(p, job_first, job_count, job_step);
   for (int job = 0; job < job_count; ++job) {
-    int id = job_first + job * job_step;
-    const int ks = id / p.nwg;          // K slice (slice-major: neighbouring blocks share operand panels in L2)
-    id -= ks * p.nwg;
-    // Tile rasterisation: the 32 CUs of an XCD walk column strips of `sw` output tiles (strip-major, then down M),
-    // so a strip of B (sw x BN x K, <= ~2.6 MB for K = 1280) stays resident in the XCD's 4 MiB L2 while A streams
-    // through once per strip and every A panel is shared by sw concurrently running workgroups.
-    int tm, tn;
-    {
-        const int tiles_m = p.nwg / p.tiles_n;
-        const int nstrips = (p.tiles_n + p.strip - 1) / p.strip;
-        const int sw = (p.tiles_n + nstrips - 1) / nstrips;          // balanced strip width
-        const int per_strip = sw * tiles_m;
-        int strip = id / per_strip;
-        int within = id - strip * per_strip;
-        int width = sw;
-        const int full = p.tiles_n - (nstrips - 1) * sw;             // width of the last (possibly narrower) strip
-        if (strip >= nstrips - 1) {                                  // ids past the full strips belong to the last
-            strip = nstrips - 1;
-            within = id - strip * per_strip;
-            width = full;
-        }
-        tm = within / width;
-        tn = strip * sw + (within - tm * width);
-    }
+    int tm, tn, ks;
+    gemm_job_decode(p, job_first + job * job_step, tm, tn, ks);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane source pointers of the staging loads (advance by one K-step per iteration) ----
@@ -260,10 +218,14 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 ? 2 : 1) * WM * WN / 4) vo
 
 bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b);   // gemm_skinny.hip
 int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_phased_launch(const GemmP& p, int mode, hipStream_t s);  // gemm_phased.hip
 
 extern int g_attn_bwd_stage;  // attention.hip
 static int g_gemm_persistent = 1;
-static int g_gemm_variant = 3;  // 0/1: 8-wave 256 tile (1 = register double-buffered fragments); 2: 16-wave 256 tile; 3: + 8-wave 128 tile
+// 0/1: 8-wave 256 tile (1 = register double-buffered fragments); 2: 16-wave 256 tile; 3: + 8-wave 128 tile;
+// 4/5/6: as 3, with the phase-pipelined kernel (gemm_phased.hip; 5 = without s_setprio, 6 = without the wave-row
+// stagger) for row-major 256-tile GEMMs
+static int g_gemm_variant = 3;
 static int g_gemm_strip = 0;
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
@@ -373,10 +335,14 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         tile = t256 >= 512 ? 256 : 128;
     }
     if (tile == 256) {
+        if (g_gemm_variant >= 4 && !g->trans_a && !g->trans_b) {
+            p.strip = g_gemm_strip;
+            return dw_gemm_phased_launch(p, g_gemm_variant - 4, s);
+        }
         if (g_gemm_variant == 0) return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
         if (g_gemm_variant >= 2) return launch_tile<256, 256, 4, 4, 0>(p, g->trans_a, g->trans_b, s);
         return launch_tile<256, 256, 2, 4, 1>(p, g->trans_a, g->trans_b, s);
     }
-    if (g_gemm_variant == 3) return launch_tile<128, 128, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
+    if (g_gemm_variant >= 3) return launch_tile<128, 128, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
     return launch_tile<128, 128, 2, 2, 0>(p, g->trans_a, g->trans_b, s);
 }

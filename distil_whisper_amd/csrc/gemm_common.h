@@ -21,6 +21,52 @@ struct GemmP {
     long slice_stride;     // split-K without atomics: slice ks stores its partial tile at c + ks * slice_stride
 };
 
+// Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.
+// The stores of tile i are still draining while the operand loads and MFMAs of tile i+1 run (a wave cannot
+// retire before its stores are acknowledged, so one-tile workgroups expose the whole write burst).
+// XCD-aware: the dispatcher places block b on XCD b%8; every XCD owns a contiguous range of the job list.
+__device__ __forceinline__ void gemm_job_range(const GemmP& p, int& job_first, int& job_count, int& job_step) {
+    const int total = p.nwg * p.split_k;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int q = total >> 3, r = total & 7;
+    if ((int)gridDim.x == total) {           // one job per workgroup (small problems)
+        job_first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        job_count = 1;
+        job_step = 1;
+    } else {                                 // gridDim.x is a multiple of 8: gridDim.x / 8 workgroups per XCD
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int cnt = q + (xcd < r ? 1 : 0);
+        job_step = gridDim.x >> 3;
+        job_first = start + local;
+        job_count = local < cnt ? (cnt - local + job_step - 1) / job_step : 0;
+    }
+}
+
+// job id -> (row tile, column tile, K slice).  Slice-major (neighbouring blocks share operand panels in L2), then
+// tile rasterisation: the 32 CUs of an XCD walk column strips of `sw` output tiles (strip-major, then down M),
+// so a strip of B (sw x BN x K, <= ~2.6 MB for K = 1280) stays resident in the XCD's 4 MiB L2 while A streams
+// through once per strip and every A panel is shared by sw concurrently running workgroups.
+__device__ __forceinline__ void gemm_job_decode(const GemmP& p, int id, int& tm, int& tn, int& ks) {
+    ks = id / p.nwg;
+    id -= ks * p.nwg;
+    const int tiles_m = p.nwg / p.tiles_n;
+    const int nstrips = (p.tiles_n + p.strip - 1) / p.strip;
+    const int sw = (p.tiles_n + nstrips - 1) / nstrips;          // balanced strip width
+    const int per_strip = sw * tiles_m;
+    int strip = id / per_strip;
+    int within = id - strip * per_strip;
+    int width = sw;
+    const int full = p.tiles_n - (nstrips - 1) * sw;             // width of the last (possibly narrower) strip
+    if (strip >= nstrips - 1) {                                  // ids past the full strips belong to the last
+        strip = nstrips - 1;
+        within = id - strip * per_strip;
+        width = full;
+    }
+    tm = within / width;
+    tn = strip * sw + (within - tm * width);
+}
+
 // transposed (k-major) tile [64][BX]: fragment X^T[i = x + ...][k-slots] for one 16-deep k step
 template <int BX>
 __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, int lane) {

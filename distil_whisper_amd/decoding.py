@@ -14,7 +14,7 @@ import torch
 
 
 def apply_timestamp_rules(scores, tokens, n, begin_index, no_timestamps_token_id, eos_token_id,
-                          max_initial_timestamp_index=None):
+                          max_initial_timestamp_index=None, return_rule_margin=False):
     """The decoding rules of `WhisperTimeStampLogitsProcessor` (TF:generation/logits_process.py; installed by
     TF:generation_whisper.py:1774-1812 when `return_timestamps=True`, run_eval.py:690-739) on a whole batch without
     host round trips: scores f32 [B, V] (modified copy returned), tokens int64 [B, >= n] of which the first n are
@@ -50,7 +50,10 @@ def apply_timestamp_rules(scores, tokens, n, begin_index, no_timestamps_token_id
     lp = torch.log_softmax(sc.float(), dim=-1)
     ts_lp = lp[:, tb:].logsumexp(-1)
     text_max = lp[:, :tb].max(-1).values
-    return sc.masked_fill((ts_lp > text_max)[:, None] & (col < tb), neg)
+    out = sc.masked_fill((ts_lp > text_max)[:, None] & (col < tb), neg)
+    if return_rule_margin:          # distance of the probability-mass decision from its threshold (fixture generator)
+        return out, (ts_lp - text_max).abs()
+    return out
 
 
 class GreedyDecoder:
@@ -168,9 +171,9 @@ class GreedyDecoder:
 
 def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_ids, max_new_tokens,
                            num_assistant_tokens=5, eos_token_id=None, suppress_tokens=None, min_new_tokens=0,
-                           pad_token_id=None):
+                           pad_token_id=None, use_cache=True):
     """Speculative (assisted) greedy decoding: the small `assistant` engine drafts `num_assistant_tokens` tokens, the
-    `target` engine scores prefix + draft in ONE decoder pass and keeps the longest draft prefix that equals its own
+    `target` engine scores all of them in ONE decoder pass and keeps the longest draft prefix that equals its own
     greedy choices plus its next token -- the output is token-for-token what target-only greedy decoding produces.
 
     Reference: run_eval.py:578-599, 706-707 (`assistant_model` of `generate`; the distilled student drafts for the
@@ -179,7 +182,13 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
     prompt_ids int64 [B, P].  With a batch the accepted length is the minimum over the rows that are still running
     (every emitted token is still each row's own greedy token).  suppress_tokens / min_new_tokens are the target's
     logits rules (SuppressTokensLogitsProcessor, MinNewTokensLengthLogitsProcessor); finished rows are filled with
-    pad_token_id.  Returns (ids [B, P + n], drafted, accepted)."""
+    pad_token_id.
+
+    use_cache: both models keep KV caches.  The target verifies with `decode_multi` -- only the tokens it has not
+    consumed yet (last accepted + drafts) go through the decoder, against the cached keys/values with the
+    bottom-right aligned causal mask -- and rejected positions are dropped by rolling the cache position back; the
+    assistant catches up on the accepted tokens the same way and drafts one token per step.  use_cache=False re-decodes
+    the whole prefix every time (cross-check).  Returns (ids [B, P + n], drafted, accepted)."""
     dt, da = target.dims, assistant.dims
     B, P0 = prompt_ids.shape
     ids = prompt_ids.clone()
@@ -201,31 +210,54 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
             sup[V] = m
         return sup[V]
 
-    def greedy_rows(eng, d, seq, enc, first):
-        """argmax tokens of `eng` for positions first .. len(seq)-1 of seq (each predicts the next token): [B, n]"""
-        T = seq.shape[1]
-        logits, _ = eng.decode(seq.contiguous(), enc, save=False)
-        sc = logits[: B * T, : d.vocab].view(B, T, -1)[:, first:].float()
+    def pick(logits, d, first_pos):
+        """greedy tokens from scores [B, n, V] whose row j predicts the token at sequence index first_pos + j"""
+        sc = logits.float()
         m = sup_mask(d.vocab)
         if m is not None:
             sc = sc + m
         if eos_token_id is not None and min_new_tokens > 0 and eos_token_id < d.vocab:
-            gen_idx = torch.arange(first + 1 - P0, T + 1 - P0, device=dev)       # index of the token being predicted
+            gen_idx = torch.arange(first_pos - P0, first_pos - P0 + sc.shape[1], device=dev)
             sc = sc.clone()
             sc[:, :, eos_token_id] = torch.where((gen_idx < min_new_tokens)[None, :], float("-inf"),
                                                  sc[:, :, eos_token_id])
         return sc.argmax(-1)
 
+    def scores_nocache(eng, d, seq, enc, first):
+        T = seq.shape[1]
+        logits, _ = eng.decode(seq.contiguous(), enc, save=False)
+        return logits[: B * T, : d.vocab].view(B, T, -1)[:, first:]
+
+    ct = ca = None
+    if use_cache:
+        ct = target.decode_init(enc_target, B, total)
+        ca = assistant.decode_init(enc_assistant, B, total)
+
+    def scores_cached(eng, d, cache, seq):
+        """feed the tokens of seq the cache has not consumed; scores [B, n, V] for those positions"""
+        new = seq[:, cache["t"]:].contiguous()
+        n = new.shape[1]
+        logits = eng.decode_multi(new, cache)
+        return logits[: B * n, : d.vocab].view(B, n, -1)
+
     while ids.shape[1] < total and not (eos_token_id is not None and bool(done.all())):
-        k = min(int(num_assistant_tokens), total - ids.shape[1] - 1)
+        L = ids.shape[1]
+        k = min(int(num_assistant_tokens), total - L - 1)
         draft = ids
-        for _ in range(k):                                   # the assistant drafts k tokens greedily
-            nxt = greedy_rows(assistant, da, draft, enc_assistant, draft.shape[1] - 1)[:, -1]
+        for j in range(k):                                   # the assistant drafts k tokens greedily
+            if use_cache:
+                sc = scores_cached(assistant, da, ca, draft)[:, -1:]
+            else:
+                sc = scores_nocache(assistant, da, draft, enc_assistant, draft.shape[1] - 1)
+            nxt = pick(sc, da, draft.shape[1])[:, -1]
             draft = torch.cat([draft, nxt[:, None]], 1)
-        P = ids.shape[1]
-        own = greedy_rows(target, dt, draft, enc_target, P - 1)  # [B, k + 1]: target's choice after each prefix
+        if use_cache:
+            sc = scores_cached(target, dt, ct, draft)[:, -(k + 1):]
+        else:
+            sc = scores_nocache(target, dt, draft, enc_target, L - 1)
+        own = pick(sc, dt, L)                                # [B, k + 1]: target's choice after each prefix
         if k > 0:
-            agree = (own[:, :k] == draft[:, P:]) | done[:, None]
+            agree = (own[:, :k] == draft[:, L:]) | done[:, None]
             n_ok = int(agree.long().cumprod(1).sum(1).min().item())
         else:
             n_ok = 0
@@ -238,4 +270,8 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
                 new[:, j] = col
                 done = done | (col == eos_token_id)
         ids = torch.cat([ids, new], 1)
+        if use_cache:
+            # positions L .. L+n_ok-1 hold accepted drafts (their K/V are valid); everything later is dropped
+            ct["t"] = min(ct["t"], L + n_ok)
+            ca["t"] = min(ca["t"], L + n_ok)
     return ids, drafted, accepted

@@ -431,6 +431,52 @@ class WhisperEngine:
         cache["t"] = t + 1
         return logits
 
+    def decode_multi(self, ids, cache):
+        """n >= 1 new tokens per row at positions cache["t"] .. cache["t"]+n-1 against the KV cache in ONE decoder pass
+        (ids int64 [B, n]) -> logits low-precision [B*n, ldv] (row b*n + j = position t+j of row b).  The new keys and
+        values are appended first and the self-attention runs with the bottom-right aligned causal mask (query j sees
+        keys <= t + j): the cached multi-token verify step of speculative decoding (run_eval.py:578-599) and the
+        prompt prefill.  cache["t"] advances by n; callers roll it back to drop rejected positions."""
+        ops, st, d = self.ops, self.st, self.dims
+        B, t, ML = cache["B"], cache["t"], cache["max_len"]
+        n = ids.shape[1]
+        D, H, Lk = d.d_model, d.heads, d.max_src
+        assert ids.shape[0] == B and t + n <= ML and t + n <= d.max_tgt
+        f32 = self.stream == torch.float32
+        tok = (st.p if f32 else st.s)["model.decoder.embed_tokens.weight"]
+        pos = (st.p if f32 else st.s)["model.decoder.embed_positions.weight"][t:t + n]
+        x = ops.embed_fwd(ids.contiguous(), tok, pos.contiguous(), torch.float32 if f32 else self.lowp)
+        for i in range(d.dec_layers):
+            p = f"model.decoder.layers.{i}"
+            av = st.attn_views(f"{p}.self_attn")
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.self_attn_layer_norm.weight"],
+                                        st.p[f"{p}.self_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            qkv = ops.gemm(h, av["wqkv"], bias=av["bqkv"])
+            kvc = cache["self"][i]
+            kvc.view(B, ML, 2 * D)[:, t:t + n].copy_(qkv[:, D:].view(B, n, 2 * D))
+            o, _ = ops.attn_fwd(qkv[:, :D], kvc[:, :D], kvc[:, D:], B, H, n, t + n, 2 if n > 1 else False, 0.125,
+                                kv_batch_rows=ML)
+            x = ops.gemm(o, av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            cv = st.attn_views(f"{p}.encoder_attn")
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
+                                        st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            q = ops.gemm(h, cv["wqkv"][:D], bias=cv["bqkv"][:D])
+            kv = cache["cross"][i]
+            o, _ = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, n, Lk, False, 0.125)
+            x = ops.gemm(o, cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"],
+                                        1e-5, save_stats=False)
+            a = ops.gemm(h, st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
+            x = ops.gemm(a, st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
+                         out_dtype=self.stream)
+        hf, _, _ = ops.layernorm_fwd(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"],
+                                     1e-5, save_stats=False)
+        eo = st.entries["model.decoder.embed_tokens.weight"][0]
+        e_pad = st.S[eo:eo + self.ldv * D].view(self.ldv, D)
+        logits = ops.gemm(hf, e_pad)
+        cache["t"] = t + n
+        return logits
+
     # ---- backward --------------------------------------------------------------------------------------------------
     def _bias_grad(self, name):
         return self.st.g[name] if self.st.is_trainable(name) else None

@@ -102,7 +102,9 @@ int dw_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const floa
 int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int causal, float scale, void* stream);
 /* Same kernel with explicit batch pitches (rows between consecutive batches of q/o and of k/v): reads a padded KV
- * cache in place during greedy decoding (TF:modeling_whisper.py:312-335 EncoderDecoderCache).  lse may be NULL. */
+ * cache in place during greedy decoding (TF:modeling_whisper.py:312-335 EncoderDecoderCache).  lse may be NULL.
+ * causal: 0 none, 1 query i sees keys <= i, 2 bottom-right aligned (query i sees keys <= i + Lk - Lq: several new
+ * queries against a longer cache -- the multi-token verify step of speculative decoding, run_eval.py:578-599). */
 int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_batch_rows, int64_t kv_batch_rows,
                    int causal, float scale, void* stream);

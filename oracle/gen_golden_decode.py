@@ -141,6 +141,22 @@ def hf_generate(cfg, sd, gen_fields, inputs, want_plain=False, **kw):
             alive[b, int(e[0]) + 1:] = False
     sigma = raw[torch.isfinite(raw)].std().item()
     margin = (top2[..., 0] - top2[..., 1])[alive].min().item() / sigma
+    if kw.get("return_timestamps"):
+        # the timestamp rules hold one more argmax-like decision per step: "timestamps together more probable than the
+        # best text token" (WhisperTimeStampLogitsProcessor); its distance from the threshold counts as a margin too
+        from distil_whisper_amd.decoding import apply_timestamp_rules
+        neg = float("-inf")
+        for i in range(raw.shape[1]):
+            x = raw[:, i].clone()
+            if i == 0 and gen_fields.get("begin_suppress_tokens"):
+                x[:, gen_fields["begin_suppress_tokens"]] = neg
+            if gen_fields.get("suppress_tokens"):
+                x[:, gen_fields["suppress_tokens"]] = neg
+            _, rule = apply_timestamp_rules(x, seq, P + i, P, NOTIMESTAMPS, EOS,
+                                            gen_fields.get("max_initial_timestamp_index"), return_rule_margin=True)
+            rule = rule[alive[:, i] & torch.isfinite(rule)]
+            if rule.numel():
+                margin = min(margin, rule.min().item() / sigma)
     if "lang_to_id" in gen_fields and "language" not in kw and inputs is not None:
         # language detection (TF:1610-1674) is an argmax too: one decoder step on <|startoftranscript|>
         with torch.no_grad():

@@ -129,8 +129,8 @@ class RefOps:
             v = v.reshape(B, kv_batch_rows, -1)[:, :Lk].reshape(B * Lk, -1)
         qh, kh, vh = self._heads(q, B, Lq, H), self._heads(k, B, Lk, H), self._heads(v, B, Lk, H)
         s = (qh @ kh.transpose(-1, -2)) * scale
-        if causal:
-            mask = torch.ones(Lq, Lk, dtype=torch.bool, device=s.device).tril()
+        if causal:    # 1 / True: key <= query; 2: bottom-right aligned (new queries against a longer KV cache)
+            mask = torch.ones(Lq, Lk, dtype=torch.bool, device=s.device).tril(Lk - Lq if int(causal) == 2 else 0)
             s = s.masked_fill(~mask, float("-inf"))
         lse = torch.logsumexp(s, -1)
         p = torch.exp(s - lse[..., None])

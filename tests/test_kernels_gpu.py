@@ -105,6 +105,30 @@ def test_gemm_epilogues(ops, ref, tile):
     assert relerr(c, rc) < 6e-3
 
 
+@pytest.mark.parametrize("variant", [4, 5, 6])
+def test_gemm_phase_pipelined_variant_is_bit_identical(ops, ref, variant):
+    """gemm_phased.hip (counted-vmcnt, slot-staggered main loop) against the plain kernel: same k order per
+    accumulator, so every output bit must agree -- ragged M/N edges, 1..5 K tiles (prologue / tail wait counts),
+    persistent job walk (> 256 tiles), fused epilogues, repeated launches (race screen)."""
+    try:
+        for M, N, K in ((520, 392, 64), (520, 392, 128), (300, 512, 192), (777, 1031 // 8 * 8, 320), (4096, 4608, 256),
+                        (16 * 1500, 1280, 1280)):
+            a, b = rnd((M, K), 0.5, seed=41), rnd((N, K), 0.1, seed=42)
+            bias = rnd((N,), 0.5, torch.float32, seed=43)
+            ops.lib.dw_debug_set(0, 3)
+            want = ops.gemm(a, b, bias=bias, act=1, tile=256).clone()
+            want32 = ops.gemm(a, b, out_dtype=torch.float32, tile=256).clone()
+            ops.lib.dw_debug_set(0, variant)
+            for rep in range(4):
+                got = ops.gemm(a, b, bias=bias, act=1, tile=256)
+                assert torch.equal(got, want), (M, N, K, rep, (got.float() - want.float()).abs().max().item())
+                got32 = ops.gemm(a, b, out_dtype=torch.float32, tile=256)
+                assert torch.equal(got32, want32), (M, N, K, rep)
+            assert relerr(want32, ref.gemm(a, b, out_dtype=torch.float32)) < 1e-5
+    finally:
+        ops.lib.dw_debug_set(0, 3)
+
+
 @pytest.mark.parametrize("M", [1, 16, 17, 40, 64])
 @pytest.mark.parametrize("N,K", [(1280, 1280), (5120, 1280), (1280, 5120), (48, 64), (51904, 1280)])
 def test_gemm_skinny_decode_shapes(ops, ref, M, N, K):
@@ -209,6 +233,23 @@ def test_attention_fwd_bwd(ops, ref, B, H, Lq, Lk, causal):
     assert relerr(dv, rdv) < 1.5e-2, relerr(dv, rdv)
     assert relerr(dq, rdq) < 1.5e-2, relerr(dq, rdq)
     assert relerr(dk, rdk) < 1.5e-2, relerr(dk, rdk)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,pitch", [(2, 2, 6, 37, 48), (3, 1, 1, 9, 16), (1, 2, 70, 200, 200), (2, 1, 33, 33, 40),
+                                              (1, 1, 130, 447, 448)])
+def test_attention_bottom_right_causal_against_padded_kv_cache(ops, ref, B, H, Lq, Lk, pitch):
+    """causal = 2: query i sees keys <= i + Lk - Lq, K/V read in place from a cache with `pitch` rows per batch --
+    the multi-token verify / prefill step of cached decoding (engine.decode_multi)."""
+    D = H * 64
+    q = rnd((B * Lq, D), 1.0, seed=35)
+    cache = rnd((B * pitch, 2 * D), 1.0, seed=36)
+    o, lse = ops.attn_fwd(q, cache[:, :D], cache[:, D:], B, H, Lq, Lk, 2, 0.125, kv_batch_rows=pitch)
+    ro, rlse = ref.attn_fwd(q, cache[:, :D], cache[:, D:], B, H, Lq, Lk, 2, 0.125, kv_batch_rows=pitch)
+    assert maxerr(lse, rlse) < 2e-3 and relerr(o, ro) < 1e-2
+    # the last query row sees every key; the first one exactly Lk - Lq + 1 of them
+    o1, _ = ops.attn_fwd(q.view(B, Lq, D)[:, -1].contiguous(), cache[:, :D], cache[:, D:], B, H, 1, Lk, False, 0.125,
+                         kv_batch_rows=pitch)
+    assert relerr(o.view(B, Lq, D)[:, -1], o1) < 2e-3
 
 
 def test_attention_spiked_row(ops, ref):

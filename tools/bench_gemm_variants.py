@@ -28,7 +28,7 @@ for name, M, N, K, ta, tb in shapes:
         for rep in range(3):
             o = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256)
             d = (o.float() - ref.float()).abs().max().item()
-            if d != 0.0 and (KEY == 1 or v < 6):
+            if d != 0.0 and (KEY == 1 or v < 8):
                 print("MISMATCH variant", v, "rep", rep, "max abs diff", d, flush=True)
     for rnd_i in range(5):
         for v in variants:
