@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// backward pre-pass: delta[b][h][q] = sum_d dO[q][d] * O[q][d]      (one wave handles 8 rows x 8 lanes)
+// backward pre-pass: delta[b][h][q] = -sum_d dO[q][d] * O[q][d], delta[B*H*Lq + ...] = -lse / scale
+// (one wave handles 8 rows x 8 lanes)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -188,7 +189,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     acc += __shfl_xor(acc, 4);
-    if (part == 0 && row < total) p.delta[row] = acc;
+    // the dK/dV kernel starts its S and dP accumulators from these two tables (one LDS read instead of per-element
+    // subtractions): -delta, and -lse / scale (so that P = exp2(scale * log2e * (S - lse / scale)))
+    if (part == 0 && row < total) {
+        p.delta[row] = -acc;
+        p.delta[total + row] = -p.lse[row] / p.scale;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
     const long sidx = ((long)b * p.H + h) * p.Lq + qc;
     const float c = p.scale * 1.4426950408889634f;
     const float lse2 = p.lse[sidx] * 1.4426950408889634f;
-    const float dl = p.delta[sidx];
+    const float dl = -p.delta[sidx];
 
     int nkt = (p.Lk + 63) >> 6;
     if (CAUSAL) nkt = min(nkt, (min(qb0 + 127, p.Lq - 1) >> 6) + 1);
@@ -282,8 +288,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
 //   S = Q.K^T, dP = dO.V^T  (rows = queries in registers, column = key = lane&31)
 //   dV^T[d][key] += dO^T . P,   dK^T[d][key] += Q^T . dS
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL, bool FS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
+template <bool CAUSAL, bool FS, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
     // [buf][Q tile 8K | dO tile 8K | lse 64 f32 | delta 64 f32]
     constexpr int STG = 16384 + 512;
     __shared__ __attribute__((aligned(1024))) char smem[2 * 17408];
@@ -299,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     const bf16* DO = p.d_o + (long)b * p.Lq * p.lddo + h * 64;
     const bf16* K = p.k + (long)b * p.Lk * p.ldk + h * 64;
     const bf16* V = p.v + (long)b * p.Lk * p.ldv + h * 64;
-    const float* LSE = p.lse + ((long)b * p.H + h) * p.Lq;
-    const float* DEL = p.delta + ((long)b * p.H + h) * p.Lq;
+    const float* DEL = p.delta + ((long)b * p.H + h) * p.Lq;               // -delta
+    const float* LSE = DEL + (long)p.B * p.H * p.Lq;                        // -lse / scale
 
     bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -346,9 +352,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
         if (CAUSAL && wk0 > qt * 64 + 63) continue;  // all 64 queries of this tile precede every key of this wave
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            // accumulators start from -lse/scale and -delta of their query rows (register r <-> query
+            // (r&3) + 8(r>>2) + 4hi of the 32-query block: four consecutive queries per 16-byte LDS read)
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int g = 0; g < 4; ++g) {
+                const int ql = qb * 32 + g * 8 + hi * 4;
+                const f32x4 l4 = *(const f32x4*)(tL + ql);
+                const f32x4 d4 = *(const f32x4*)(tD + ql);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[g * 4 + e] = l4[e]; dp[g * 4 + e] = d4[e]; }
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tQ, qb, kk, lane), kf[kk], s, 0, 0, 0);
@@ -356,19 +370,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
             }
             f32x16 pr;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ql = qb * 32 + g * 8 + hi * 4;  // 4 consecutive local queries
-                const f32x4 l4 = *(const f32x4*)(tL + ql);
-                const f32x4 d4 = *(const f32x4*)(tD + ql);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = g * 4 + e;
-                    const int qi = qt * 64 + ql + e;
-                    float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -l4[e] * 1.4426950408889634f));
-                    if (need_mask) pv = (qi < p.Lq && k_ok && (!CAUSAL || key <= qi)) ? pv : 0.f;
-                    pr[r] = pv;
-                    s[r] = pv * (dp[r] - d4[e]);  // dS
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(s[r] * c);           // P = exp(scale * S - lse)
+                if (need_mask) {
+                    const int qi = qt * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    pv = (qi < p.Lq && k_ok && (!CAUSAL || key <= qi)) ? pv : 0.f;
                 }
+                pr[r] = pv;
+                s[r] = pv * dp[r];                                     // dS = P * (dP - delta)
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -391,7 +400,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP p) {
     store_t(DV, p.lddv, key, k_ok, 1, hi, av[1], 1.0f);
 }
 
-int g_attn_bwd_stage = 1;  // bit 0: dq kernel, bit 1: dkv kernel use the 32-bit-offset tile staging (dw_debug_set key 3)
+// bit 0: dq kernel, bit 1: dkv kernel use the 32-bit-offset tile staging; bit 2: dkv kernel compiled for 3 waves per
+// SIMD (168 registers; since the accumulators start from the -lse/-delta tables it spills 1-2 registers instead of 14)
+int g_attn_bwd_stage = 1;  // (dw_debug_set key 3)
 static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
 
 extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
@@ -461,12 +472,15 @@ extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const vo
     const int fs = g_attn_bwd_stage;
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, block, 0, s, p);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), gk, block, 0, s, p);
+        if (fs & 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 3>), gk, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 2>), gk, block, 0, s, p);
     } else {
         if (fs & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, block, 0, s, p);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, block, 0, s, p);
-        if (fs & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), gk, block, 0, s, p);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), gk, block, 0, s, p);
+        if ((fs & 6) == 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true, 3>), gk, block, 0, s, p);
+        else if (fs & 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 3>), gk, block, 0, s, p);
+        else if (fs & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true, 2>), gk, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 2>), gk, block, 0, s, p);
     }
     DW_CHECK_LAUNCH();
     return DW_OK;

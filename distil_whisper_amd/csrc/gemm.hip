@@ -218,13 +218,13 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 ? 2 : 1) * WM * WN / 4) vo
 
 bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b);   // gemm_skinny.hip
 int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
-int dw_gemm_phased_launch(const GemmP& p, int mode, hipStream_t s);  // gemm_phased.hip
+int dw_gemm_phased_launch(const GemmP& p, int ta, int tb, int mode, hipStream_t s);  // gemm_phased.hip
 
 extern int g_attn_bwd_stage;  // attention.hip
 static int g_gemm_persistent = 1;
 // 0/1: 8-wave 256 tile (1 = register double-buffered fragments); 2: 16-wave 256 tile; 3: + 8-wave 128 tile;
 // 4/5/6: as 3, with the phase-pipelined kernel (gemm_phased.hip; 5 = without s_setprio, 6 = without the wave-row
-// stagger) for row-major 256-tile GEMMs
+// stagger) for the 256-tile GEMMs
 static int g_gemm_variant = 3;
 static int g_gemm_strip = 0;
 extern "C" int dw_debug_set(int key, int value) {
@@ -335,9 +335,9 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         tile = t256 >= 512 ? 256 : 128;
     }
     if (tile == 256) {
-        if (g_gemm_variant >= 4 && !g->trans_a && !g->trans_b) {
+        if (g_gemm_variant >= 4) {
             p.strip = g_gemm_strip;
-            return dw_gemm_phased_launch(p, g_gemm_variant - 4, s);
+            return dw_gemm_phased_launch(p, g->trans_a, g->trans_b, g_gemm_variant - 4, s);
         }
         if (g_gemm_variant == 0) return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
         if (g_gemm_variant >= 2) return launch_tile<256, 256, 4, 4, 0>(p, g->trans_a, g->trans_b, s);

@@ -313,7 +313,7 @@ class HipOps:
             dk = self.empty((B * Lk, H * 64), torch.bfloat16)
         if dv is None:
             dv = self.empty((B * Lk, H * 64), torch.bfloat16)
-        delta = self.empty((B, H, Lq), torch.float32)
+        delta = self.empty((2, B, H, Lq), torch.float32)     # scratch: [-delta | -lse / scale]
         for t in (q, k, v, o, do, dq, dk, dv):
             assert t.dtype == torch.bfloat16 and t.stride(1) == 1
         e0 = self._t0()

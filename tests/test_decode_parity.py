@@ -112,9 +112,9 @@ def _check_pseudo_label(ops, s, graphs):
 
 
 def _run_all(ops, graphs):
-    assert GOLD["meta"]["min_margin"] >= 0.05
+    assert GOLD["meta"]["min_margin"] >= 0.05      # bf16 logit noise on these weights: ~0.007 sigma (std)
     for s in GOLD["scenarios"]:
-        assert s["margin"] >= GOLD["meta"]["min_margin"] or os.environ.get("DECODE_GOLDEN_DEBUG"), (s["name"], s["margin"])
+        assert s["margin"] >= GOLD["meta"]["min_margin"], (s["name"], s["margin"])
         if s["kind"] == "short":
             _check_short(ops, s, graphs)
         elif s["kind"] == "longform":

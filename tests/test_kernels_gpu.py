@@ -106,25 +106,37 @@ def test_gemm_epilogues(ops, ref, tile):
 
 
 @pytest.mark.parametrize("variant", [4, 5, 6])
-def test_gemm_phase_pipelined_variant_is_bit_identical(ops, ref, variant):
-    """gemm_phased.hip (counted-vmcnt, slot-staggered main loop) against the plain kernel: same k order per
-    accumulator, so every output bit must agree -- ragged M/N edges, 1..5 K tiles (prologue / tail wait counts),
-    persistent job walk (> 256 tiles), fused epilogues, repeated launches (race screen)."""
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_phase_pipelined_variant_is_bit_identical(ops, ref, variant, ta, tb):
+    """gemm_phased.hip (counted-vmcnt, slot-staggered main loop, region-major LDS image) against the plain kernel:
+    same k order per accumulator, so every output bit must agree -- all four operand layouts, ragged M/N edges,
+    1..5 K tiles (prologue / tail wait counts), persistent job walk (> 256 tiles), fused epilogue, split-K slices,
+    repeated launches (race screen)."""
     try:
-        for M, N, K in ((520, 392, 64), (520, 392, 128), (300, 512, 192), (777, 1031 // 8 * 8, 320), (4096, 4608, 256),
-                        (16 * 1500, 1280, 1280)):
-            a, b = rnd((M, K), 0.5, seed=41), rnd((N, K), 0.1, seed=42)
+        for M, N, K in ((520, 392, 64), (520, 392, 128), (304, 512, 192), (776, 1024, 320), (4096, 4608, 256),
+                        (8 * 1500, 1280, 1280)):
+            a = rnd((K, M) if ta else (M, K), 0.5, seed=41)
+            b = rnd((K, N) if tb else (N, K), 0.1, seed=42)
             bias = rnd((N,), 0.5, torch.float32, seed=43)
             ops.lib.dw_debug_set(0, 3)
-            want = ops.gemm(a, b, bias=bias, act=1, tile=256).clone()
-            want32 = ops.gemm(a, b, out_dtype=torch.float32, tile=256).clone()
+            want = ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, act=1, tile=256).clone()
+            want32 = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, tile=256).clone()
             ops.lib.dw_debug_set(0, variant)
-            for rep in range(4):
-                got = ops.gemm(a, b, bias=bias, act=1, tile=256)
+            for rep in range(3):
+                got = ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, act=1, tile=256)
                 assert torch.equal(got, want), (M, N, K, rep, (got.float() - want.float()).abs().max().item())
-                got32 = ops.gemm(a, b, out_dtype=torch.float32, tile=256)
+                got32 = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, tile=256)
                 assert torch.equal(got32, want32), (M, N, K, rep)
-            assert relerr(want32, ref.gemm(a, b, out_dtype=torch.float32)) < 1e-5
+            assert relerr(want32, ref.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32)) < 1e-5
+        if ta and tb:       # weight-gradient form: K = tokens, split into slices, fp32 partials + deterministic reduce
+            a, b = rnd((6400, 1280), 0.5, seed=44), rnd((6400, 384), 0.5, seed=45)
+            ops.lib.dw_debug_set(0, 3)
+            want = torch.zeros(1280, 384, device="cuda")
+            ops.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32, out=want, atomic_acc=True, split_k=5)
+            ops.lib.dw_debug_set(0, variant)
+            got = torch.zeros(1280, 384, device="cuda")
+            ops.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32, out=got, atomic_acc=True, split_k=5)
+            assert torch.equal(got, want)
     finally:
         ops.lib.dw_debug_set(0, 3)
 

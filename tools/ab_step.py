@@ -18,12 +18,14 @@ ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
 dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
 def step():
     return tr.train_step(tr.features(audio), dec_in, labels)
-configs = eval(os.environ.get("DW_AB", "[(1,0),(3,0)]"))  # (variant, strip); variant 1 = 8-wave, 3 = 16-wave default; strip 0 = auto rule
+# (GEMM variant, strip[, attention-backward mode]); variant 3 = default, 4 = phase-pipelined kernel; strip 0 = auto rule;
+# attention mode = dw_debug_set key 3 (default 1)
+configs = eval(os.environ.get("DW_AB", "[(3,0,1),(4,0,1)]"))
 step(); torch.cuda.synchronize()
 res = {c: [] for c in configs}
 for r in range(4):
     for c in configs:
-        ops.lib.dw_debug_set(0, c[0]); ops.lib.dw_debug_set(1, c[1])
+        ops.lib.dw_debug_set(0, c[0]); ops.lib.dw_debug_set(1, c[1]); ops.lib.dw_debug_set(3, c[2] if len(c) > 2 else 1)
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(2): step()

@@ -1,4 +1,5 @@
-"""In-process A/B of the attention backward tile-staging variants (dw_debug_set key 3) at the encoder shape."""
+"""In-process A/B of the attention backward variants (dw_debug_set key 3: bit 1 = dK/dV fast staging, bit 2 = dK/dV at
+3 waves per SIMD) at the encoder shape."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distil_whisper_amd.ops_hip import HipOps
@@ -10,7 +11,7 @@ o, lse = ops.attn_fwd(q, k, v, B, H, L, L, False, 0.125)
 do = torch.randn(B * L, D, device="cuda").bfloat16()
 res = {}
 for rnd in range(3):
-    for mode in (0, 1, 2, 3):
+    for mode in (1, 3, 5, 7):
         ops.lib.dw_debug_set(3, mode)
         for _ in range(2): ops.attn_bwd(q, k, v, o, do, lse, B, H, L, L, False, 0.125)
         torch.cuda.synchronize()
