@@ -168,6 +168,101 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// decode: ONE query per (batch, head) against Lk cached keys/values (cross-attention over the 1500 encoder positions
+// and self-attention over the tokens so far, TF:modeling_whisper.py:312-335).  HBM-bound: every K and V byte is read
+// exactly once (15.4 MB of cross K/V per sequence and decoder layer pair), nothing is staged or re-read.
+// One workgroup per (batch, head), NW waves; 8 lanes share a key (16 bytes = 8 of the 64 head dimensions each), so a
+// wave instruction reads 8 complete 128-byte rows.  Pass 1: scores -> LDS + block max.  Pass 2: p = exp2(s - m),
+// l += p, o += bf16(p) * v (P is rounded to bf16 before the PV product exactly like the tile kernel does), lane and
+// wave partials meet through shuffles and LDS.  All (batch, head) workgroups are resident at once (320 for the
+// long-form batch of 16), unlike the 128-query tile kernel which would run 1.25 rounds of mostly idle tiles.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];   // [Lk scores | NW x 64 partial outputs | NW | NW]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int sub = lane >> 3, ds = (lane & 7) * 8;              // key sub-index within a group of 8, first head dim
+    float* sc = dsm;
+    float* part = dsm + ((p.Lk + 3) & ~3);
+    float* redm = part + NW * 64;
+    float* redl = redm + NW;
+    const bf16* Q = p.q + (long)b * p.q_rows * p.ldq + h * 64 + ds;
+    const bf16* K = p.k + (long)b * p.kv_rows * p.ldk + h * 64 + ds;
+    const bf16* V = p.v + (long)b * p.kv_rows * p.ldv + h * 64 + ds;
+    const float c = p.scale * 1.4426950408889634f;
+    float qv[8];
+    {
+        const bf16x8 q8 = *(const bf16x8*)Q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = bf2f(q8[e]) * c;
+    }
+    // ---- pass 1: scores (in log2 units) and their maximum ----
+    float mx = NEG_BIG;
+    for (int k0 = wave * 8; k0 < p.Lk; k0 += NW * 8) {
+        const int k = k0 + sub;
+        float s = 0.f;
+        if (k < p.Lk) {
+            const bf16x8 k8 = *(const bf16x8*)(K + (long)k * p.ldk);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qv[e], bf2f(k8[e]), s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (k < p.Lk) {
+            if ((lane & 7) == 0) sc[k] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) redm[wave] = mx;
+    __syncthreads();
+    mx = redm[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) mx = fmaxf(mx, redm[i]);
+    // ---- pass 2: probabilities, normaliser and the weighted sum of V ----
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (int k0 = wave * 8; k0 < p.Lk; k0 += NW * 8) {
+        const int k = k0 + sub;
+        if (k < p.Lk) {
+            const float pv = __builtin_amdgcn_exp2f(sc[k] - mx);
+            l += pv;
+            const float pb = round_bf16(pv);
+            const bf16x8 v8 = *(const bf16x8*)(V + (long)k * p.ldv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pb, bf2f(v8[e]), o[e]);
+        }
+    }
+    // the 8 lanes of a key group hold the same l contribution: count it once (lane & 7 == 0), then reduce
+    l = (lane & 7) == 0 ? l : 0.f;
+    l = wave_sum(l);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e] += __shfl_xor(o[e], 8);
+        o[e] += __shfl_xor(o[e], 16);
+        o[e] += __shfl_xor(o[e], 32);
+    }
+    if (sub == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[wave * 64 + ds + e] = o[e];
+    }
+    if (lane == 0) redl[wave] = l;
+    __syncthreads();
+    if (wave == 0) {
+        float acc = 0.f, lt = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { acc += part[i * 64 + lane]; lt += redl[i]; }
+        bf16* O = p.o + (long)b * p.q_rows * p.ldo + h * 64;
+        O[lane] = f2bf(acc / lt);
+        // natural-log logsumexp of scale * q.k, as the tile kernel reports it
+        if (p.lse && lane == 0) p.lse[(long)b * p.H + h] = (mx + __log2f(lt)) * 0.6931471805599453f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // backward pre-pass: delta[b][h][q] = -sum_d dO[q][d] * O[q][d], delta[B*H*Lq + ...] = -lse / scale
 // (one wave handles 8 rows x 8 lanes)
 // ---------------------------------------------------------------------------------------------------------------
@@ -402,7 +497,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
 
 // bit 0: dq kernel, bit 1: dkv kernel use the 32-bit-offset tile staging; bit 2: dkv kernel compiled for 3 waves per
 // SIMD (168 registers; since the accumulators start from the -lse/-delta tables it spills 1-2 registers instead of 14)
-int g_attn_bwd_stage = 1;  // (dw_debug_set key 3)
+int g_attn_bwd_stage = 5;  // (dw_debug_set key 3; 5 measured best: 1.65 vs 1.75 ms per encoder-layer backward)
+int g_attn_decode = 1;     // dw_debug_set key 4: 1 = single-query attention runs the streaming decode kernel
 static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
 
 extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq,
@@ -435,8 +531,16 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     if (causal != 0 && causal != 1 && causal != 2) return DW_EINVAL;
     if (causal == 2 && Lk < Lq) return DW_EINVAL;
     p.coff = causal == 2 ? Lk - Lq : 0;
-    dim3 grid((Lq + 127) / 128, H, B), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (Lq == 1 && g_attn_decode && Lk <= 8192) {
+        // one query per (batch, head): the streaming decode kernel (the causal mask is void for a single last query)
+        const size_t smem = (((size_t)Lk + 3) & ~(size_t)3) * 4 + 16 * 64 * 4 + 2 * 16 * 4;
+        if (Lk >= 512) hipLaunchKernelGGL(attn_decode_kernel<16>, dim3(1, H, B), dim3(1024), smem, s, p);
+        else hipLaunchKernelGGL(attn_decode_kernel<4>, dim3(1, H, B), dim3(256), smem, s, p);
+        DW_CHECK_LAUNCH();
+        return DW_OK;
+    }
+    dim3 grid((Lq + 127) / 128, H, B), block(256);
     if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, p);
     DW_CHECK_LAUNCH();

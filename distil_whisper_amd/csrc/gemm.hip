@@ -221,17 +221,21 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_phased_launch(const GemmP& p, int ta, int tb, int mode, hipStream_t s);  // gemm_phased.hip
 
 extern int g_attn_bwd_stage;  // attention.hip
+extern int g_attn_decode;
 static int g_gemm_persistent = 1;
 // 0/1: 8-wave 256 tile (1 = register double-buffered fragments); 2: 16-wave 256 tile; 3: + 8-wave 128 tile;
 // 4/5/6: as 3, with the phase-pipelined kernel (gemm_phased.hip; 5 = without s_setprio, 6 = without the wave-row
-// stagger) for the 256-tile GEMMs
-static int g_gemm_variant = 3;
+// stagger) for every 256-tile GEMM; 7 (default): as 3, with the phase-pipelined kernel where it measured faster on
+// MI355X -- k-major B operand and a long contraction (dX = dY.W with K >= 3840: +7..10 %; it loses 5-20 % on the
+// short-K and row-major shapes, profiles/r2_gemm_variants.md)
+static int g_gemm_variant = 7;
 static int g_gemm_strip = 0;
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
     if (key == 1) { g_gemm_strip = value; return DW_OK; }
     if (key == 2) { g_gemm_persistent = value; return DW_OK; }
     if (key == 3) { g_attn_bwd_stage = value; return DW_OK; }
+    if (key == 4) { g_attn_decode = value; return DW_OK; }
     return DW_EINVAL;
 }
 
@@ -335,9 +339,13 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         tile = t256 >= 512 ? 256 : 128;
     }
     if (tile == 256) {
-        if (g_gemm_variant >= 4) {
+        if (g_gemm_variant >= 4 && g_gemm_variant <= 6) {
             p.strip = g_gemm_strip;
             return dw_gemm_phased_launch(p, g->trans_a, g->trans_b, g_gemm_variant - 4, s);
+        }
+        if (g_gemm_variant == 7 && !g->trans_a && g->trans_b && g->k >= 3840 && p.split_k == 1) {
+            p.strip = g_gemm_strip;
+            return dw_gemm_phased_launch(p, 0, 1, 1, s);
         }
         if (g_gemm_variant == 0) return launch_tile<256, 256, 2, 4, 0>(p, g->trans_a, g->trans_b, s);
         if (g_gemm_variant >= 2) return launch_tile<256, 256, 4, 4, 0>(p, g->trans_a, g->trans_b, s);

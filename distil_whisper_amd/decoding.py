@@ -71,27 +71,20 @@ class GreedyDecoder:
         self.tokens = torch.zeros((self.B, self.max_len), dtype=torch.long, device=dev)
         self.cur = torch.zeros((self.B, 1), dtype=torch.long, device=dev)
         self.done = torch.zeros((self.B,), dtype=torch.bool, device=dev)
-        # finished rows are filled with pad_token_id (GenerationMixin: next = next * unfinished + pad * (1 - unfinished));
-        # Whisper checkpoints have pad == eos
-        fill = eos_token_id if pad_token_id is None else pad_token_id
-        self.eos_fill = None if eos_token_id is None else torch.full((self.B,), fill, dtype=torch.long, device=dev)
-        self.eos_mask = None
-        if eos_token_id is not None:   # MinNewTokensLengthLogitsProcessor: EOS cannot be sampled before min_new_tokens
-            self.eos_mask = torch.zeros((d.vocab,), dtype=torch.float32, device=dev)
-            self.eos_mask[eos_token_id] = float("-inf")
 
         def mask(ids):
             if ids is None or len(ids) == 0:
                 return None
-            m = torch.zeros((d.vocab,), dtype=torch.float32, device=dev)
-            m[torch.as_tensor(list(ids), dtype=torch.long, device=dev)] = float("-inf")
+            m = torch.zeros((d.vocab,), dtype=torch.uint8, device=dev)
+            m[torch.as_tensor(list(ids), dtype=torch.long, device=dev)] = 1
             return m
         self.suppress = mask(suppress_tokens)
         self.begin_suppress = mask(begin_suppress_tokens)
-        # dict(begin_index=, no_timestamps_token_id=, max_initial_timestamp_index=) -> apply_timestamp_rules each step
+        # dict(begin_index=, no_timestamps_token_id=, max_initial_timestamp_index=): WhisperTimeStampLogitsProcessor
         self.timestamp_rules = timestamp_rules
         if timestamp_rules is not None and eos_token_id is None:
             raise ValueError("timestamp rules need eos_token_id")
+        self.fill = -1 if eos_token_id is None else (eos_token_id if pad_token_id is None else pad_token_id)
         self.cache = None
         self.graphs = {}
         self.pool = None
@@ -102,27 +95,17 @@ class GreedyDecoder:
         eng, d = self.eng, self.eng.dims
         self.cache["t"] = t
         logits = eng.decode_step(self.cur, self.cache)
-        if mode == 0:
-            nxt = self.tokens[:, t + 1]
-        else:
-            # processor order of the reference: min-new-tokens, begin-suppress, suppress, timestamp rules
-            sc = logits[:, : d.vocab].float()
-            if no_eos and self.eos_mask is not None:
-                sc = sc + self.eos_mask
-            if mode == 1 and self.begin_suppress is not None:
-                sc = sc + self.begin_suppress
-            if self.suppress is not None:
-                sc = sc + self.suppress
-            if self.timestamp_rules is not None:
-                r = self.timestamp_rules
-                sc = apply_timestamp_rules(sc, self.tokens, t + 1, r["begin_index"], r["no_timestamps_token_id"],
-                                           self.eos, r.get("max_initial_timestamp_index"))
-            nxt = sc.argmax(-1)
-            if self.eos is not None:
-                nxt = torch.where(self.done, self.eos_fill, nxt)
-                self.done.logical_or_(nxt == self.eos)
-            self.tokens[:, t + 1].copy_(nxt)
-        self.cur.copy_(nxt.view(self.B, 1))
+        r = self.timestamp_rules
+        # logits processors of the reference (min-new-tokens, begin-suppress, suppress, timestamp rules), argmax and the
+        # EOS bookkeeping in one launch (csrc/decode.hip); the next token lands in tokens[:, t+1] and in cur
+        eng.ops.greedy_select(
+            logits, d.vocab, self.tokens, t + 1, self.cur, suppress=self.suppress, begin_suppress=self.begin_suppress,
+            first=(mode == 1), no_eos=no_eos, forced=(mode == 0),
+            ts_begin=-1 if r is None else r["no_timestamps_token_id"] + 1,
+            max_initial=-1 if (r is None or r.get("max_initial_timestamp_index") is None)
+            else r["max_initial_timestamp_index"],
+            begin_index=1 if r is None else r["begin_index"], eos=-1 if self.eos is None else self.eos,
+            fill=self.fill, done=self.done)
 
     def _run_step(self, t, mode, no_eos=False):
         if not self.use_graphs:

@@ -63,6 +63,9 @@ _SIGS = {
     "dw_selftest_tr16": ([C.c_void_p, C.c_void_p], C.c_int),
     "dw_debug_set": ([C.c_int, C.c_int], C.c_int),
     "dw_reduce_slices": ([C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p], C.c_int),
+    "dw_greedy_select": ([C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_int] * 5 +
+                         [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                          C.c_void_p], C.c_int),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
@@ -438,6 +441,23 @@ class HipOps:
         self._chk(self.lib.dw_sumsq_f32(_p(g), g.numel(), _p(out), _p(self._sumsq_ws), self._stream()), "sumsq")
         return out
 
+    def greedy_select(self, logits, V, tokens, n, cur, *, suppress=None, begin_suppress=None, first=False, no_eos=False,
+                      forced=False, ts_begin=-1, max_initial=-1, begin_index=1, eos=-1, fill=-1, done=None):
+        """One decoding step's token selection for the whole batch (csrc/decode.hip): logits bf16 [B, ld] -> next token
+        written to tokens[:, n] and cur[:, 0]; masks are uint8 [V] (1 = never sampled); done bool [B] in/out."""
+        B = tokens.shape[0]
+        assert tokens.dtype == torch.int64 and tokens.is_contiguous() and cur.dtype == torch.int64 and cur.is_contiguous()
+        if not forced:
+            assert logits.dtype == torch.bfloat16 and logits.stride(1) == 1 and logits.shape[0] >= B
+        for m in (suppress, begin_suppress):
+            assert m is None or (m.dtype == torch.uint8 and m.numel() >= V and m.is_contiguous())
+        assert done is None or (done.dtype == torch.bool and done.is_contiguous())
+        self._chk(self.lib.dw_greedy_select(_p(logits), B, int(V), logits.stride(0) if logits is not None else 0,
+                                            _p(suppress), _p(begin_suppress), int(first), int(no_eos), int(forced),
+                                            int(ts_begin), int(max_initial), _p(tokens), tokens.stride(0), int(n),
+                                            int(begin_index), int(eos), int(fill), _p(done), _p(cur), self._stream()),
+                  "greedy_select")
+
     def adamw(self, p, g, m, v, shadow, sumsq, max_norm, grad_mul, lr, beta1, beta2, eps, weight_decay, step):
         assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
         self._chk(self.lib.dw_adamw(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(sumsq), float(max_norm),
@@ -461,5 +481,5 @@ for _name, _key in (("layernorm_fwd", "ln_fwd"), ("layernorm_bwd", "ln_bwd"), ("
                     ("logmel", "logmel"), ("adamw", "adamw"), ("cast_bf16", "cast"), ("colsum", "colsum"),
                     ("sumsq", "sumsq"), ("embed_fwd", "embed"), ("embed_bwd", "embed"), ("im2col_mel", "conv_aux"),
                     ("im2col_s2", "conv_aux"), ("col2im_s2_gelu_bwd", "conv_aux"), ("gelu_bwd", "conv_aux"),
-                    ("pack_conv_weight", "conv_aux"), ("unpack_conv_grad", "conv_aux")):
+                    ("pack_conv_weight", "conv_aux"), ("unpack_conv_grad", "conv_aux"), ("greedy_select", "select")):
     setattr(HipOps, _name, _timed(_key)(getattr(HipOps, _name)))

@@ -56,7 +56,6 @@ class PseudoLabeller:
                                       dtype=torch.long, device=dev)
         if timestamp_rules is not None:
             timestamp_rules = dict(timestamp_rules, begin_index=len(self.prompt))
-            use_graphs = False
         self.eos = eos_token_id
         self.decoder = GreedyDecoder(model.engine, self.B, len(self.prompt) + self.max_new, eos_token_id=eos_token_id,
                                      suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens,

@@ -186,6 +186,34 @@ class RefOps:
         n = (labels != -100).sum().float()
         return torch.stack([ce.detach(), kl.detach(), total.detach(), n]).float()
 
+    # GenerationMixin._sample with Whisper's logits processors (TF:generation/logits_process.py, installed by
+    # TF:models/whisper/generation_whisper.py:1774-1812): min-new-tokens, begin-suppress, suppress, timestamp rules
+    # (the restatement in distil_whisper_amd.decoding.apply_timestamp_rules is pinned against the transformers class in
+    # tests/test_longform.py), argmax, finished rows filled with the pad token.
+    def greedy_select(self, logits, V, tokens, n, cur, *, suppress=None, begin_suppress=None, first=False, no_eos=False,
+                      forced=False, ts_begin=-1, max_initial=-1, begin_index=1, eos=-1, fill=-1, done=None):
+        from distil_whisper_amd.decoding import apply_timestamp_rules
+        B = tokens.shape[0]
+        if forced:
+            cur.copy_(tokens[:, n].view(B, 1))
+            return
+        neg = float("-inf")
+        sc = logits[:B, :V].float()
+        if no_eos and eos >= 0:
+            sc[:, eos] = neg
+        if first and begin_suppress is not None:
+            sc = sc.masked_fill(begin_suppress[:V].bool()[None, :], neg)
+        if suppress is not None:
+            sc = sc.masked_fill(suppress[:V].bool()[None, :], neg)
+        if ts_begin >= 0:
+            sc = apply_timestamp_rules(sc, tokens, n, begin_index, ts_begin - 1, eos, None if max_initial < 0 else max_initial)
+        nxt = sc.argmax(-1)
+        if eos >= 0:
+            nxt = torch.where(done, torch.full_like(nxt, fill), nxt)
+            done.logical_or_(nxt == eos)
+        tokens[:, n].copy_(nxt)
+        cur.copy_(nxt.view(B, 1))
+
     def embed_fwd(self, ids, tok, pos, out_dtype):
         B, T = ids.shape
         x = tok.float()[ids.reshape(-1)] + pos.float()[:T].repeat(B, 1)

@@ -138,7 +138,7 @@ def test_gemm_phase_pipelined_variant_is_bit_identical(ops, ref, variant, ta, tb
             ops.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32, out=got, atomic_acc=True, split_k=5)
             assert torch.equal(got, want)
     finally:
-        ops.lib.dw_debug_set(0, 3)
+        ops.lib.dw_debug_set(0, 7)
 
 
 @pytest.mark.parametrize("M", [1, 16, 17, 40, 64])
@@ -389,3 +389,46 @@ def test_adamw_and_clip(ops, ref):
     for i in range(3):
         assert relerr(st["hip"][i], st["ref"][i]) < 1e-5, i
     assert relerr(st["hip"][3], st["ref"][3]) < 1e-3
+
+
+def test_greedy_select_matches_restatement(ops, ref):
+    """csrc/decode.hip (logits processors + argmax + EOS bookkeeping in one launch) against the torch restatement whose
+    timestamp rules are pinned against transformers' WhisperTimeStampLogitsProcessor (tests/test_longform.py): random
+    logits and histories, every rule combination, exact token equality (ties are broken towards the smaller id)."""
+    V, ld, eos, no_ts = 1000, 1024, 900, 911
+    tb = no_ts + 1
+    g = torch.Generator().manual_seed(0)
+    sup = torch.zeros(V, dtype=torch.uint8)
+    sup[torch.randint(0, V, (150,), generator=g)] = 1
+    bsup = torch.zeros(V, dtype=torch.uint8)
+    bsup[[220, eos]] = 1
+    for trial in range(120):
+        B, begin = 6, 3
+        n = begin + int(torch.randint(0, 9, (1,), generator=g))
+        toks = torch.randint(0, eos, (B, 24), generator=g)
+        for b in range(B):                       # sprinkle non-decreasing timestamps into the generated part
+            curts = tb
+            for j in range(begin, n):
+                if float(torch.rand(1, generator=g)) < 0.45:
+                    curts = min(V - 1, curts + int(torch.randint(0, 4, (1,), generator=g)))
+                    toks[b, j] = curts
+        logits = (torch.randn(B, ld, generator=g) * (3.0 if trial % 2 else 0.3))
+        if trial % 3 == 0:
+            logits[:, tb:] += 2.0                # the "timestamps together beat the best text token" branch
+        logits = logits.to(torch.bfloat16)
+        done0 = torch.rand(B, generator=g) < 0.2
+        kw = dict(suppress=sup if trial % 4 else None, begin_suppress=bsup, first=(n == begin), no_eos=bool(trial % 5 == 0),
+                  forced=bool(trial % 17 == 16), ts_begin=tb if trial % 2 == 0 else -1, max_initial=7 if trial % 4 < 2 else -1,
+                  begin_index=begin, eos=eos, fill=eos if trial % 7 else 0)
+        out = {}
+        for name, o in (("hip", ops), ("ref", ref)):
+            t = toks.clone().cuda()
+            cur = torch.zeros(B, 1, dtype=torch.long, device="cuda")
+            done = done0.clone().cuda()
+            k2 = dict(kw)
+            for m in ("suppress", "begin_suppress"):
+                k2[m] = None if k2[m] is None else k2[m].cuda()
+            o.greedy_select(logits.cuda(), V, t, n, cur, done=done, **k2)
+            out[name] = (t.cpu(), cur.cpu(), done.cpu())
+        for a, b in zip(out["hip"], out["ref"]):
+            assert torch.equal(a, b), (trial, kw, out["hip"][1].view(-1).tolist(), out["ref"][1].view(-1).tolist())
