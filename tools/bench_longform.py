@@ -19,6 +19,17 @@ fe = WhisperFeatureExtractor(feature_size=128, ops=ops)
 CLIPS, NEW, B = int(os.environ.get("CLIPS", 4)), int(os.environ.get("NEW", 128)), int(os.environ.get("B", 16))
 audio = [0.1 * torch.randn(4_800_000, device=dev) for _ in range(CLIPS)]
 res = {"clips": CLIPS, "clip_s": 300, "batch": B, "new_tokens": NEW}
+if os.environ.get("DW_DECODE_AB"):            # streaming single-query attention kernel off (tile kernel) vs on
+    for mode in (0, 1):
+        ops.lib.dw_debug_set(4, mode)
+        tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True)
+        feats = torch.randn(B, 128, 3000, device=dev) * 0.5
+        enc, _ = model.engine.encode(feats, save=False)
+        prompt = tr.prompt[None, :].expand(B, -1).contiguous()
+        tr.decoder.run(enc, prompt, NEW); torch.cuda.synchronize()
+        t0 = time.perf_counter(); tr.decoder.run(enc, prompt, NEW); torch.cuda.synchronize(); td = time.perf_counter() - t0
+        res[f"decode_attn_kernel_{mode}"] = {"ms_per_decode_step": td / NEW * 1e3}
+    ops.lib.dw_debug_set(4, 1)
 for graphs in (False, True):
     tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=graphs)
     windows = len(tr.plan([a.numel() for a in audio]))
@@ -33,4 +44,15 @@ for graphs in (False, True):
     t0 = time.perf_counter(); tr.decoder.run(enc, prompt, NEW); torch.cuda.synchronize(); td = time.perf_counter() - t0
     res["graphs" if graphs else "eager"] = {"windows": windows, "wall_s": dt, "audio_s_per_s": CLIPS * 300 / dt,
                                             "ms_per_decode_step": td / NEW * 1e3, "decode_tokens_per_s": B * NEW / td}
+# per-launch-class breakdown of the decode step (eager, HIP events around every launch; 32 steps)
+tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=33, use_graphs=False)
+feats = torch.randn(B, 128, 3000, device=dev) * 0.5
+enc, _ = model.engine.encode(feats, save=False)
+prompt = tr.prompt[None, :].expand(B, -1).contiguous()
+tr.decoder.run(enc, prompt, 33); torch.cuda.synchronize()
+ops.profile, ops.profile_detail = {}, True
+tr.decoder.run(enc, prompt, 33); torch.cuda.synchronize()
+prof = ops.collect_profile(); ops.profile = None
+res["decode_step_breakdown_us"] = {k: {"n_per_step": round(v["n"] / 32, 2), "us_per_step": round(v["ms"] / 32 * 1e3, 2)}
+                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 print(json.dumps(res))
