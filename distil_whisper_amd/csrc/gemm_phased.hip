@@ -1,4 +1,4 @@
-// Phase-pipelined main loop for the 256x256x64 bf16 MFMA GEMM (all four operand layouts).
+// Phase-pipelined main loop for the 256x256x64 bf16 MFMA GEMM (written for all four operand layouts; built for dX).
 //
 // Same tile, fragment layout, k order and fused epilogue as gemm.hip (bit-identical results); what differs is HOW a
 // K tile moves through the CU:
@@ -245,17 +245,13 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmP p) {
     }
 }
 
-template <int PRIO, int STAGGER>
-static void launch_phased(const GemmP& p, int ta, int tb, int nblk, hipStream_t s) {
-    dim3 grid(nblk), block(512);
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_phased_kernel<false, false, PRIO, STAGGER>), grid, block, 0, s, p);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_phased_kernel<false, true, PRIO, STAGGER>), grid, block, 0, s, p);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_phased_kernel<true, false, PRIO, STAGGER>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_phased_kernel<true, true, PRIO, STAGGER>), grid, block, 0, s, p);
-}
-
-// mode 0: setprio + stagger (default)   1: no setprio   2: no stagger (both wave rows in lock step)
-int dw_gemm_phased_launch(const GemmP& p0, int ta, int tb, int mode, hipStream_t s) {
+// One build is kept: row-major A, k-major B (the dX GEMMs), wave rows staggered, no s_setprio -- the measured best of the
+// variants tried on MI355X: with s_setprio around the MFMA slots -2 %, with both wave rows in lock step +3..7 % at
+// K = 1280 but -1 % at K >= 3840; the other three operand layouts ran 5-20 % behind the plain kernel and are not
+// instantiated (each instantiation costs ~40 s of compile time for its unrolled epilogue), profiles/r2_gemm_variants.md.
+// TA / TB / PRIO / STAGGER stay template parameters of the kernel for such experiments.
+int dw_gemm_phased_launch(const GemmP& p0, int ta, int tb, hipStream_t s) {
+    if (ta || !tb) return DW_EINVAL;
     GemmP p = p0;
     const int tiles_m = (p.m + 255) / 256;
     p.tiles_n = (p.n + 255) / 256;
@@ -268,9 +264,7 @@ int dw_gemm_phased_launch(const GemmP& p0, int ta, int tb, int mode, hipStream_t
     }
     int nblk = p.nwg * p.split_k;
     if (nblk > 256) nblk = 256;
-    if (mode == 0) launch_phased<1, 1>(p, ta, tb, nblk, s);
-    else if (mode == 1) launch_phased<0, 1>(p, ta, tb, nblk, s);
-    else launch_phased<1, 0>(p, ta, tb, nblk, s);
+    hipLaunchKernelGGL((gemm_phased_kernel<false, true, 0, 1>), dim3(nblk), dim3(512), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

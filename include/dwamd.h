@@ -77,6 +77,15 @@ typedef struct DwGemm {
                            storing fp32 partials at c + slice * slice_stride (then call dw_reduce_slices) */
     int32_t atomic_acc; /* 1: C (f32, plain epilogue) += result with float atomics (gradient accumulation) */
     int64_t slice_stride; /* elements between the partial outputs of consecutive K slices (split_k > 1, no atomics) */
+    /* LayerNorm prologue (decode step, m <= 64 only): when ln_x != NULL the A operand is bf16(LayerNorm(ln_x)) computed
+       inside the kernel (`a` is ignored): ln_x [m][k] f32 or bf16 (ln_x_dtype) with row stride ldx, gamma/beta f32 [k].
+       Replaces the LayerNorm launch in front of the q/k/v, fc1 and LM-head projections of one token step. */
+    const void* ln_x;
+    const float* ln_gamma;
+    const float* ln_beta;
+    int64_t ldx;
+    int32_t ln_x_dtype;
+    float ln_eps;
 } DwGemm;
 int dw_gemm_bf16(const DwGemm* g, void* stream);
 /* out[i] (+)= sum over slices of part[s*stride + i]; n, stride multiples of 4 (split-K combination, deterministic). */
@@ -166,12 +175,29 @@ int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, in
              float max_norm, float grad_mul, double lr, double beta1, double beta2, double eps, double weight_decay,
              int step, void* stream);
 
+/* ---- a11: token selection of one greedy-decoding step for the whole batch (TF:generation/logits_process.py processors
+ * MinNewTokensLength, SuppressTokensAtBegin, SuppressTokens, WhisperTimeStamp as installed by
+ * TF:models/whisper/generation_whisper.py:1774-1812, then argmax and the EOS / pad bookkeeping of GenerationMixin).
+ * logits bf16 [B][ld] (V valid columns); suppress / begin_suppress: uint8 [V] masks (1 = never sampled) or NULL,
+ * begin_suppress applies when first != 0; no_eos != 0 masks eos (min_new_tokens not reached); forced != 0: position n is
+ * still inside the forced prefix (cur = tokens[b][n], nothing else happens).  Timestamp rules: ts_begin =
+ * no_timestamps_token_id + 1 (< 0 disables), max_initial = max_initial_timestamp_index (< 0 none), begin_index = length
+ * of the forced prefix.  tokens int64 [B][tok_ld]: history in [0, n), the selected token is written to [n]; cur int64 [B]
+ * receives it as well; done uint8 [B] in/out (finished rows get `fill`); eos < 0 disables the bookkeeping. */
+int dw_greedy_select(const void* logits, int B, int V, int64_t ld, const uint8_t* suppress,
+                     const uint8_t* begin_suppress, int first, int no_eos, int forced, int ts_begin, int max_initial,
+                     int64_t* tokens, int64_t tok_ld, int n, int begin_index, int eos, int fill, uint8_t* done,
+                     int64_t* cur, void* stream);
+
 /* ---- self tests (diagnostics for bring-up; not on the hot path) --------------------------------------------------
  * Runs ds_read_b64_tr_b16 on a known LDS image: out int32 [64][4] = element ids received by each lane. */
 int dw_selftest_tr16(int32_t* out, void* stream);
-/* Tuning knobs for kernel A/B experiments; not part of the hot path.  key 0: GEMM layout (0/1 = 8-wave 256x256 tile,
- * 2 = 16-wave, 3 = 16-wave + 8-wave 128x128 tile [default]); key 1: strip width override (0 = rule); key 2: persistent
- * workgroups on/off; key 3: attention backward tile-staging variant (bit 0 dQ, bit 1 dK/dV; default 1). */
+/* Tuning knobs for kernel A/B experiments; not part of the hot path.  key 0: GEMM main loop (3 = plain 16-wave
+ * 256x256 / 8-wave 128x128 tile kernels, 5 = phase-pipelined kernel for every 256-tile dX GEMM,
+ * 7 = 3 + phase-pipelined kernel for long-K dX GEMMs [default]); key 1:
+ * strip width override (0 = rule); key 2: persistent workgroups on/off; key 3: attention backward variant (bit 0 dQ,
+ * bit 1 dK/dV fast tile staging, bit 2 dK/dV at 3 waves per SIMD; default 5); key 4: single-query attention through
+ * the streaming decode kernel (default 1). */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ if os.environ.get("DW_MORE"):
               ("dec qkv M=14304", B*447, 3840, 1280, False, False), ("dec fc1 M=14304", B*447, 5120, 1280, False, False),
               ("lm head", B*447, 51904, 1280, False, False), ("lm head dX", B*447, 1280, 51904, False, True),
               ("dW qkv 3840x1280", 3840, 1280, B*1500, True, True), ("dW out 1280x1280", 1280, 1280, B*1500, True, True)]
-variants = [int(v) for v in os.environ.get("DW_VARIANTS", "0,1,2,3").split(",")]
+variants = [int(v) for v in os.environ.get("DW_VARIANTS", "3,5,7").split(",")]
 KEY = int(os.environ.get("DW_KEY", "0"))
 for name, M, N, K, ta, tb in shapes:
     a = rnd((K, M) if ta else (M, K)); b = rnd((K, N) if tb else (N, K), 0.05)
