@@ -26,6 +26,7 @@ int dw_gemm_tile128_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // g
 
 extern int g_attn_bwd_stage;  // attention.hip
 extern int g_attn_decode;
+extern int g_logmel_mfma;     // logmel.hip
 int g_gemm_persistent = 1;
 // 3: 16-wave 256x256 tile + 8-wave 128x128 tile (the 8-wave 256-tile layouts and the 4-wave 128 tile of round 1 lost
 // to these and were removed, profiles/r1_gemm_pmc.md); 5: as 3, with the phase-pipelined kernel (gemm_phased.hip) for
@@ -40,6 +41,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 2) { g_gemm_persistent = value; return DW_OK; }
     if (key == 3) { g_attn_bwd_stage = value; return DW_OK; }
     if (key == 4) { g_attn_decode = value; return DW_OK; }
+    if (key == 5) { g_logmel_mfma = value; return DW_OK; }
     return DW_EINVAL;
 }
 
@@ -71,15 +73,10 @@ extern "C" int dw_reduce_slices(const float* part, int64_t stride, int slices, f
 
 extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     DW_CLEAR_ERR();
-    if (!g || !g->b || !g->c || (!g->a && !g->ln_x)) return DW_EINVAL;
+    if (!g || !g->a || !g->b || !g->c) return DW_EINVAL;
     if (g->m <= 0 || g->n <= 0 || g->k <= 0 || (g->k & 63)) return DW_EINVAL;
-    if (g->ln_x) {   // LayerNorm prologue: only the skinny (decode) kernel implements it
-        if (!g->ln_gamma || !g->ln_beta || g->trans_a || g->trans_b || g->m > 64 || (g->ldx & 7) ||
-            ((uintptr_t)g->ln_x & 15) || ((uintptr_t)g->ln_gamma & 15) || ((uintptr_t)g->ln_beta & 15) ||
-            (g->ln_x_dtype != DW_F32 && g->ln_x_dtype != DW_BF16))
-            return DW_EINVAL;
-    } else if ((g->lda & 7) || ((uintptr_t)g->a & 15)) return DW_EINVAL;
-    if ((g->ldb & 7) || ((uintptr_t)g->b & 15)) return DW_EINVAL;
+    if ((g->lda & 7) || (g->ldb & 7)) return DW_EINVAL;
+    if (((uintptr_t)g->a & 15) || ((uintptr_t)g->b & 15)) return DW_EINVAL;
     // k-major operands are fetched in 16-byte column slots: a slot whose first column is valid is read whole, so the
     // row must be readable up to the next multiple of 8 columns (true whenever ld covers the padded width)
     if (g->trans_a && g->lda < ((g->m + 7) & ~7)) return DW_EINVAL;
@@ -95,8 +92,6 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.atomic = g->atomic_acc ? 1 : 0;
     if (p.split_k > (g->k >> 6)) p.split_k = g->k >> 6;
     p.slice_stride = 0;
-    p.ln_x = g->ln_x; p.ln_gamma = g->ln_gamma; p.ln_beta = g->ln_beta; p.ldx = g->ldx; p.ln_x_dtype = g->ln_x_dtype;
-    p.ln_eps = g->ln_eps;
     if (p.split_k > 1 && !p.atomic) {
         // K slices without atomics: every slice stores a plain fp32 partial at c + ks * slice_stride (the caller
         // reduces them, see dw_reduce_slices); only the bare epilogue makes sense here
@@ -119,7 +114,6 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     // decode regime (M = batch rows): weight-streaming kernel; tile = 16 requests it explicitly
     if (tile == 16 && !dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return DW_EINVAL;
     if ((tile == 0 || tile == 16) && dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return dw_gemm_skinny_launch(p, s);
-    if (g->ln_x) return DW_EINVAL;   // (the tile kernels take a ready-made bf16 operand)
     if (tile != 128 && tile != 256) {
         const long t256 = (long)((g->m + 255) / 256) * ((g->n + 255) / 256);
         tile = t256 >= 512 ? 256 : 128;

@@ -19,13 +19,6 @@ struct GemmP {
     int split_k, atomic;   // K slices per tile (grid = nwg * split_k); atomic: C (f32) += v with atomics
     int vec;               // all epilogue pointers / leading dimensions allow 4-wide vector access
     long slice_stride;     // split-K without atomics: slice ks stores its partial tile at c + ks * slice_stride
-    // LayerNorm prologue of the skinny (decode) kernel: A = bf16(LayerNorm(ln_x)) when ln_x != nullptr
-    const void* ln_x;
-    const float* ln_gamma;
-    const float* ln_beta;
-    long ldx;
-    int ln_x_dtype;
-    float ln_eps;
 };
 
 // Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.

@@ -21,26 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 constexpr int SK_MAXS = 10;   // 32-deep k steps a wave keeps in registers (10 x 16 B of W + as much of A per lane)
 constexpr int SK_MAXW = 16;   // waves per workgroup
 
-// 8 consecutive elements of row `row` of the LayerNorm input (f32 or bf16) as floats
-template <bool XBF>
-__device__ __forceinline__ void ld_x8(const void* x, long off, float (&v)[8]) {
-    if (XBF) {
-        const bf16x8 t = *(const bf16x8*)((const bf16*)x + off);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = bf2f(t[e]);
-    } else {
-        const f32x4_t a = *(const f32x4_t*)((const float*)x + off);
-        const f32x4_t b = *(const f32x4_t*)((const float*)x + off + 4);
-        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    }
-}
-
-// LN: 0 = A is a ready bf16 operand; 1 / 2 = A = bf16(LayerNorm(ln_x)) with ln_x in f32 / bf16.  The waves of a
-// workgroup hold disjoint K slices of the 16..64 activation rows, so the row statistics (two passes, as
-// csrc/norm.hip computes them: mean, then the centred sum of squares) are combined through LDS before the main
-// loop; the normalised operand is built on the fly from ln_x (a few KB per row block, L2 resident) -- the
-// LayerNorm launch in front of the projection and its round trip through HBM disappear from the token step.
-template <int MB, int LN>
+template <int MB>
 __global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p, int nw, int steps_total) {
     extern __shared__ float red[];  // [nw][MB][64][4]
     const int lane = threadIdx.x & 63;
@@ -60,73 +41,6 @@ __global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p
     for (int s = 0; s < SK_MAXS; ++s)
         if (s < ns) wf[s] = *(const bf16x8*)(wp + s * 32);
 
-    // ---- LayerNorm statistics of this lane's rows (row mb*16 + r16), over the whole K ----
-    float mu[MB], rs[MB];
-    if (LN) {
-        constexpr bool XBF = LN == 2;
-        float part[MB];
-        // pass 1: mean
-        static_for<0, MB>([&](auto mc) {
-            constexpr int mb = decltype(mc)::value;
-            int arow = mb * 16 + r16;
-            arow = arow < p.m ? arow : p.m - 1;
-            float acc1 = 0.f;
-#pragma unroll
-            for (int s = 0; s < SK_MAXS; ++s)
-                if (s < ns) {
-                    float v[8];
-                    ld_x8<XBF>(p.ln_x, (long)arow * p.ldx + (long)(s0 + s) * 32 + g * 8, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc1 += v[e];
-                }
-            acc1 += __shfl_xor(acc1, 16);
-            acc1 += __shfl_xor(acc1, 32);
-            part[mb] = acc1;
-        });
-        if (g == 0) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) red[(wave * MB + mb) * 16 + r16] = part[mb];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            float t = 0.f;
-            for (int w = 0; w < nw; ++w) t += red[(w * MB + mb) * 16 + r16];
-            mu[mb] = t / (float)p.k;
-        }
-        __syncthreads();
-        // pass 2: centred sum of squares
-        static_for<0, MB>([&](auto mc) {
-            constexpr int mb = decltype(mc)::value;
-            int arow = mb * 16 + r16;
-            arow = arow < p.m ? arow : p.m - 1;
-            float acc2 = 0.f;
-#pragma unroll
-            for (int s = 0; s < SK_MAXS; ++s)
-                if (s < ns) {
-                    float v[8];
-                    ld_x8<XBF>(p.ln_x, (long)arow * p.ldx + (long)(s0 + s) * 32 + g * 8, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = v[e] - mu[mb]; acc2 += d * d; }
-                }
-            acc2 += __shfl_xor(acc2, 16);
-            acc2 += __shfl_xor(acc2, 32);
-            part[mb] = acc2;
-        });
-        if (g == 0) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) red[(wave * MB + mb) * 16 + r16] = part[mb];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            float t = 0.f;
-            for (int w = 0; w < nw; ++w) t += red[(w * MB + mb) * 16 + r16];
-            rs[mb] = rsqrtf(t / (float)p.k + p.ln_eps);
-        }
-        __syncthreads();   // `red` is reused for the accumulator exchange below
-    }
-
     f32x4_t acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -134,26 +48,11 @@ __global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p
         constexpr int mb = decltype(mc)::value;
         int arow = mb * 16 + r16;
         arow = arow < p.m ? arow : p.m - 1;
+        const bf16* ap = p.a + (long)arow * p.lda + (long)s0 * 32 + g * 8;
         bf16x8 af[SK_MAXS];
-        if (LN) {
-            constexpr bool XBF = LN == 2;
 #pragma unroll
-            for (int s = 0; s < SK_MAXS; ++s)
-                if (s < ns) {
-                    const int k0 = (s0 + s) * 32 + g * 8;
-                    float v[8], gm[8], bt[8];
-                    ld_x8<XBF>(p.ln_x, (long)arow * p.ldx + k0, v);
-                    ld_x8<false>(p.ln_gamma, k0, gm);
-                    ld_x8<false>(p.ln_beta, k0, bt);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) af[s][e] = f2bf((v[e] - mu[mb]) * rs[mb] * gm[e] + bt[e]);
-                }
-        } else {
-            const bf16* ap = p.a + (long)arow * p.lda + (long)s0 * 32 + g * 8;
-#pragma unroll
-            for (int s = 0; s < SK_MAXS; ++s)
-                if (s < ns) af[s] = *(const bf16x8*)(ap + s * 32);
-        }
+        for (int s = 0; s < SK_MAXS; ++s)
+            if (s < ns) af[s] = *(const bf16x8*)(ap + s * 32);
 #pragma unroll
         for (int s = 0; s < SK_MAXS; ++s)
             if (s < ns) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[s], acc[mb], 0, 0, 0);
@@ -230,17 +129,9 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s) {
     const int mb = (p.m + 15) / 16;
     dim3 grid(p.n / 16), block(64 * nw);
     const size_t lds = (size_t)nw * (mb == 3 ? 4 : mb) * 64 * 4 * sizeof(float);
-    const int ln = !p.ln_x ? 0 : (p.ln_x_dtype == DW_BF16 ? 2 : 1);
-#define SK_LAUNCH(MBV)                                                                                            \
-    do {                                                                                                          \
-        if (ln == 0) hipLaunchKernelGGL((gemm_skinny_kernel<MBV, 0>), grid, block, lds, s, p, nw, steps);         \
-        else if (ln == 1) hipLaunchKernelGGL((gemm_skinny_kernel<MBV, 1>), grid, block, lds, s, p, nw, steps);    \
-        else hipLaunchKernelGGL((gemm_skinny_kernel<MBV, 2>), grid, block, lds, s, p, nw, steps);                 \
-    } while (0)
-    if (mb == 1) SK_LAUNCH(1);
-    else if (mb == 2) SK_LAUNCH(2);
-    else SK_LAUNCH(4);
-#undef SK_LAUNCH
+    if (mb == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, lds, s, p, nw, steps);
+    else if (mb == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, lds, s, p, nw, steps);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, block, lds, s, p, nw, steps);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -404,26 +404,30 @@ class WhisperEngine:
         for i in range(d.dec_layers):
             p = f"model.decoder.layers.{i}"
             av = st.attn_views(f"{p}.self_attn")
-            qkv = ops.ln_gemm(x, st.p[f"{p}.self_attn_layer_norm.weight"], st.p[f"{p}.self_attn_layer_norm.bias"],
-                              1e-5, av["wqkv"], bias=av["bqkv"])
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.self_attn_layer_norm.weight"],
+                                        st.p[f"{p}.self_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            qkv = ops.gemm(h, av["wqkv"], bias=av["bqkv"])
             kvc = cache["self"][i]
             kvc.view(B, ML, 2 * D)[:, t].copy_(qkv[:, D:])  # append this step's K/V (plumbing copy of B rows)
             o, _ = ops.attn_fwd(qkv[:, :D], kvc[:, :D], kvc[:, D:], B, H, 1, t + 1, False, 0.125, kv_batch_rows=ML)
             x = ops.gemm(o, av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
             cv = st.attn_views(f"{p}.encoder_attn")
-            q = ops.ln_gemm(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
-                            st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, cv["wqkv"][:D], bias=cv["bqkv"][:D])
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
+                                        st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            q = ops.gemm(h, cv["wqkv"][:D], bias=cv["bqkv"][:D])
             kv = cache["cross"][i]
             o, _ = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, 1, Lk, False, 0.125)
             x = ops.gemm(o, cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
-            a = ops.ln_gemm(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"], 1e-5,
-                            st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"],
+                                        1e-5, save_stats=False)
+            a = ops.gemm(h, st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
             x = ops.gemm(a, st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
                          out_dtype=self.stream)
+        hf, _, _ = ops.layernorm_fwd(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"],
+                                     1e-5, save_stats=False)
         eo = st.entries["model.decoder.embed_tokens.weight"][0]
         e_pad = st.S[eo:eo + self.ldv * D].view(self.ldv, D)
-        logits = ops.ln_gemm(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"], 1e-5,
-                             e_pad)
+        logits = ops.gemm(hf, e_pad)
         cache["t"] = t + 1
         return logits
 
@@ -445,27 +449,31 @@ class WhisperEngine:
         for i in range(d.dec_layers):
             p = f"model.decoder.layers.{i}"
             av = st.attn_views(f"{p}.self_attn")
-            qkv = ops.ln_gemm(x, st.p[f"{p}.self_attn_layer_norm.weight"], st.p[f"{p}.self_attn_layer_norm.bias"],
-                              1e-5, av["wqkv"], bias=av["bqkv"])
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.self_attn_layer_norm.weight"],
+                                        st.p[f"{p}.self_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            qkv = ops.gemm(h, av["wqkv"], bias=av["bqkv"])
             kvc = cache["self"][i]
             kvc.view(B, ML, 2 * D)[:, t:t + n].copy_(qkv[:, D:].view(B, n, 2 * D))
             o, _ = ops.attn_fwd(qkv[:, :D], kvc[:, :D], kvc[:, D:], B, H, n, t + n, 2 if n > 1 else False, 0.125,
                                 kv_batch_rows=ML)
             x = ops.gemm(o, av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
             cv = st.attn_views(f"{p}.encoder_attn")
-            q = ops.ln_gemm(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
-                            st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, cv["wqkv"][:D], bias=cv["bqkv"][:D])
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
+                                        st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, save_stats=False)
+            q = ops.gemm(h, cv["wqkv"][:D], bias=cv["bqkv"][:D])
             kv = cache["cross"][i]
             o, _ = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, n, Lk, False, 0.125)
             x = ops.gemm(o, cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
-            a = ops.ln_gemm(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"], 1e-5,
-                            st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
+            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"],
+                                        1e-5, save_stats=False)
+            a = ops.gemm(h, st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
             x = ops.gemm(a, st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
                          out_dtype=self.stream)
+        hf, _, _ = ops.layernorm_fwd(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"],
+                                     1e-5, save_stats=False)
         eo = st.entries["model.decoder.embed_tokens.weight"][0]
         e_pad = st.S[eo:eo + self.ldv * D].view(self.ldv, D)
-        logits = ops.ln_gemm(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"], 1e-5,
-                             e_pad)
+        logits = ops.gemm(hf, e_pad)
         cache["t"] = t + n
         return logits
 

@@ -27,8 +27,6 @@ class DwGemm(C.Structure):
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("act", C.c_int32), ("c_dtype", C.c_int32),
         ("r_dtype", C.c_int32), ("r_row_mod", C.c_int32), ("round_res", C.c_int32), ("tile", C.c_int32),
         ("split_k", C.c_int32), ("atomic_acc", C.c_int32), ("slice_stride", C.c_int64),
-        ("ln_x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ldx", C.c_int64),
-        ("ln_x_dtype", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -268,37 +266,6 @@ class HipOps:
                     f"{' sk%d' % g.split_k if g.split_k else ''}")
         self._t1(e0, key, 2.0 * M * N * K)
         return (out, z) if want_z else out
-
-    def ln_gemm(self, x, gamma, beta, eps, w, *, bias=None, act=0, residual=None, round_res=True, out_dtype=None):
-        """bf16(LayerNorm(x)) @ w^T with the fused epilogue -- one launch for the token step of cached decoding
-        (x: [M <= 64, K] f32 or bf16 residual stream; the LayerNorm runs inside the weight-streaming kernel).
-        Larger M goes through the LayerNorm kernel and the tile GEMM (two launches, both HIP)."""
-        M, K = x.shape
-        N = w.shape[0]
-        skinny = M <= 64 and N % 16 == 0 and K % 64 == 0 and K <= 5120 and x.stride(1) == 1
-        if not skinny:
-            h, _, _ = self.layernorm_fwd(x.contiguous(), gamma, beta, eps, save_stats=False)
-            return self.gemm(h, w, bias=bias, act=act, residual=residual, round_res=round_res, out_dtype=out_dtype)
-        assert w.dtype == torch.bfloat16 and w.stride(1) == 1 and w.shape[1] == K
-        assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == K
-        out = self.empty((M, N), self.lowp if out_dtype is None else out_dtype)
-        g = DwGemm()
-        g.a, g.b, g.c = None, w.data_ptr(), out.data_ptr()
-        g.lda, g.ldb, g.ldc = K, w.stride(0), out.stride(0)
-        g.m, g.n, g.k = M, N, K
-        g.act, g.c_dtype, g.tile = int(act), _dt(out), 16
-        g.ln_x, g.ln_gamma, g.ln_beta = x.data_ptr(), gamma.data_ptr(), beta.data_ptr()
-        g.ldx, g.ln_x_dtype, g.ln_eps = x.stride(0), _dt(x), float(eps)
-        if bias is not None:
-            assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-            g.bias = bias.data_ptr()
-        if residual is not None:
-            assert residual.stride(1) == 1 and residual.shape == (M, N)
-            g.r, g.ldr, g.r_dtype, g.round_res = residual.data_ptr(), residual.stride(0), _dt(residual), int(bool(round_res))
-        e0 = self._t0()
-        self._chk(self.lib.dw_gemm_bf16(C.byref(g), self._stream()), f"ln_gemm m={M} n={N} k={K}")
-        self._t1(e0, f"ln_gemm m{M} n{N} k{K}" if self.profile_detail else "ln_gemm", 2.0 * M * N * K)
-        return out
 
     def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):
         rows, cols = x.shape

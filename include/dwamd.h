@@ -77,15 +77,6 @@ typedef struct DwGemm {
                            storing fp32 partials at c + slice * slice_stride (then call dw_reduce_slices) */
     int32_t atomic_acc; /* 1: C (f32, plain epilogue) += result with float atomics (gradient accumulation) */
     int64_t slice_stride; /* elements between the partial outputs of consecutive K slices (split_k > 1, no atomics) */
-    /* LayerNorm prologue (decode step, m <= 64 only): when ln_x != NULL the A operand is bf16(LayerNorm(ln_x)) computed
-       inside the kernel (`a` is ignored): ln_x [m][k] f32 or bf16 (ln_x_dtype) with row stride ldx, gamma/beta f32 [k].
-       Replaces the LayerNorm launch in front of the q/k/v, fc1 and LM-head projections of one token step. */
-    const void* ln_x;
-    const float* ln_gamma;
-    const float* ln_beta;
-    int64_t ldx;
-    int32_t ln_x_dtype;
-    float ln_eps;
 } DwGemm;
 int dw_gemm_bf16(const DwGemm* g, void* stream);
 /* out[i] (+)= sum over slices of part[s*stride + i]; n, stride multiples of 4 (split-K combination, deterministic). */

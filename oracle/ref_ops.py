@@ -86,10 +86,6 @@ class RefOps:
             v = out
         return (v, z) if want_z else v
 
-    def ln_gemm(self, x, gamma, beta, eps, w, *, bias=None, act=0, residual=None, round_res=True, out_dtype=None):
-        h, _, _ = self.layernorm_fwd(x, gamma, beta, eps, save_stats=False)
-        return self.gemm(h, w, bias=bias, act=act, residual=residual, round_res=round_res, out_dtype=out_dtype)
-
     # nn.LayerNorm in fp32 (autocast keeps layer_norm in fp32), output cast to bf16 by the consumer
     def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):
         xf = x.float()

@@ -234,3 +234,41 @@ def test_graph_replayed_greedy_decode_and_longform_scheduler(ops):
                 seqs.append(text)
         want.append(merge_sequences(seqs))
     assert got[True] == want
+
+
+def test_device_resident_input_pipeline(ops):
+    """SURVEY section 8 a2 / f3 on the device: token labels prepared by labels.prepare_train_labels (timestamps filtered,
+    prompt in front) -> DataCollatorSpeechSeq2SeqWithPadding with device="cuda" (pad / shift / -100 / prompt mask as
+    integer kernels on the GPU) must equal the oracle's restatement of the reference collator bit for bit, and raw audio ->
+    log-mel -> the distillation step consumes those tensors without any host round trip."""
+    from distil_whisper_amd.collator import DataCollatorSpeechSeq2SeqWithPadding
+    from distil_whisper_amd.labels import prepare_train_labels
+    cfg_t = wo.CONFIGS["micro"]
+    sot, prev, pad, tb = cfg_t.decoder_start_token_id, 990, cfg_t.pad_token_id, 950
+    rng = np.random.default_rng(5)
+    toks, prevs = [], []
+    for i in range(6):
+        ids = [sot, 902, 907] + rng.integers(2, 900, size=int(rng.integers(4, 40))).tolist() + [900]
+        if i % 2:
+            for ppos in sorted(rng.integers(3, len(ids) - 1, size=3).tolist(), reverse=True):
+                ids.insert(ppos, int(tb + 1 + rng.integers(0, 40)))
+        toks.append(ids)
+        prevs.append(None if i % 3 == 0 else rng.integers(2, 900, size=int(rng.integers(1, 30))).tolist())
+    np.random.seed(3)
+    lists = prepare_train_labels(toks, prevs, timestamp_begin=tb, timestamp_position=3, decoder_prev_token_id=prev,
+                                 timestamp_probability=0.5, condition_on_prev_probability=0.7, max_label_length=64)
+    coll = DataCollatorSpeechSeq2SeqWithPadding(decoder_start_token_id=sot, decoder_prev_token_id=prev,
+                                                max_target_length=64, pad_token_id=pad, device="cuda")
+    out = coll([{"labels": l} for l in lists])
+    dec_in, labels = wo.collate(lists, sot, max_target_length=64, pad_token_id=pad)
+    assert out["labels"].is_cuda and out["decoder_input_ids"].is_cuda
+    assert torch.equal(out["labels"].cpu(), labels) and torch.equal(out["decoder_input_ids"].cpu(), dec_in)
+    assert bool((out["labels"][1] == -100).any())
+    # audio -> features -> step, everything on the device
+    t_sd = wo.init_state_dict(cfg_t, 41)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    audio = (0.1 * torch.randn(6, 480000, generator=torch.Generator().manual_seed(2))).cuda()
+    feats = tr.features(audio)
+    losses = tr.train_step(feats, out["decoder_input_ids"], out["labels"])
+    assert feats.is_cuda and torch.isfinite(losses).all() and losses[3].item() == float((labels != -100).sum())
