@@ -171,7 +171,8 @@ def main():
             roofline = {"bound": "mfma", "kernel": key, "launches": p["n"],
                         "avg_launch_ms": p["ms"] / p["n"], "flops_per_launch": p["flops"] / p["n"],
                         "achieved": p["flops"] / (p["ms"] * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+                        "frac": p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                        "traffic": pmc_traffic(key, args),
                         "all_gemm_ms": sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")),
                         "all_gemm_tflops": sum(v["flops"] for k, v in prof.items() if k.startswith("gemm")) /
                         max(sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9,
@@ -199,6 +200,18 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(key, args):
+    """L2-fabric-side bytes per launch of the reported kernel class, from the committed PMC passes of this same
+    workload (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE cannot be collected inside a timed run).  None when the
+    committed summary is for another workload or does not hold the class."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    if not os.path.exists(path) or args.model != "large-v3" or args.mode != "full" or args.batch != 32:
+        return None
+    with open(path) as f:
+        c = json.load(f).get("classes", {}).get(key)
+    return None if c is None else c["traffic_bytes_per_launch"]
 
 
 def log(msg):

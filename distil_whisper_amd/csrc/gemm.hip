@@ -23,6 +23,9 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_phased_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_phased.hip
 int dw_gemm_tile256_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile256.hip: 16 waves, 4 x 4
 int dw_gemm_tile128_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile128.hip: 8 waves, 2 x 4
+int dw_gemm_w4_nn_launch(const GemmP& p, hipStream_t s);                    // gemm_w4_*.hip: 4 waves, 128 x 128 per wave
+int dw_gemm_w4_nt_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_w4_tt_launch(const GemmP& p, hipStream_t s);
 
 extern int g_attn_bwd_stage;  // attention.hip
 extern int g_attn_decode;
@@ -119,6 +122,17 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         tile = t256 >= 512 ? 256 : 128;
     }
     if (tile == 256) {
+        // bit 3: the 4-wave software-pipelined kernel for the layouts it is built for (DMA offsets must fit 31 bits)
+        if ((g_gemm_variant & 8) && !(g->trans_a && !g->trans_b)) {
+            const long spanA = g->trans_a ? (long)g->k * g->lda * 2 : 256L * g->lda * 2 + (long)g->k * 2;
+            const long spanB = g->trans_b ? (long)g->k * g->ldb * 2 : 256L * g->ldb * 2 + (long)g->k * 2;
+            if (spanA < 0x7fffffffL && spanB < 0x7fffffffL) {
+                p.strip = g_gemm_strip;
+                if (!g->trans_a && !g->trans_b) return dw_gemm_w4_nn_launch(p, s);
+                if (!g->trans_a && g->trans_b) return dw_gemm_w4_nt_launch(p, s);
+                return dw_gemm_w4_tt_launch(p, s);
+            }
+        }
         if (g_gemm_variant == 5 && !g->trans_a && g->trans_b) {
             p.strip = g_gemm_strip;
             return dw_gemm_phased_launch(p, g->trans_a, g->trans_b, s);

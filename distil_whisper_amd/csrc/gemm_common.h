@@ -88,6 +88,65 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, i
 }
 
 
+// One epilogue row group: 4 consecutive output columns of one row, all fused element-wise work of the GEMM (bias, Z
+// store, GELU, GELU' with the prefetched z, residual add with the prefetched r, C store).  `v` holds the fp32
+// accumulator values; the caller guarantees the 4 columns are in range and every pointer allows 4-wide accesses.
+__device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], const f32x4& b4, bool plain, bool have_side,
+                                              const bf16x4& zs, const f32x4& rs, float* cf, int m, int n) {
+    if (!plain) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        if (p.z_out) {
+            bf16x4 z4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
+            *(bf16x4*)(p.z_out + (long)m * p.ldz + n) = z4;
+        }
+        if (p.act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
+                const f32x2 g2 = gelu_fast2(x2);
+                v[e] = g2[0]; v[e + 1] = g2[1];
+            }
+        }
+        if (have_side) {
+            if (p.zgrad) {
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    f32x2 x2; x2[0] = bf2f(zs[e]); x2[1] = bf2f(zs[e + 1]);
+                    const f32x2 g2 = gelu_grad_fast2(x2);
+                    v[e] *= g2[0]; v[e + 1] *= g2[1];
+                }
+            }
+            if (p.r) {
+                float rv[4];
+                if (p.r_dtype == DW_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[e] = rs[e];
+                } else {
+                    const unsigned u0 = __float_as_uint(rs[0]), u1 = __float_as_uint(rs[1]);
+                    rv[0] = __uint_as_float(u0 << 16); rv[1] = __uint_as_float(u0 & 0xffff0000u);
+                    rv[2] = __uint_as_float(u1 << 16); rv[3] = __uint_as_float(u1 & 0xffff0000u);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
+            }
+        }
+    }
+    if (p.c_dtype == DW_F32) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e];
+        *(f32x4*)(cf + (long)m * p.ldc + n) = o;
+    } else {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+        *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
+    }
+}
+
 template <int FM, int FN, int TN, int PFDIST = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
                                               int m0, int wm0, int n0, int wn0, int ks) {
@@ -98,6 +157,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     // b128 writes), then walks it 4 rows x TN columns per instruction: every global access of the epilogue (C and Z
     // stores, residual and GELU' loads, atomics) is 4-wide per lane and contiguous along the row across 16 lanes.
     // (compile-time accumulator indices only: a runtime-indexed accumulator array would be demoted to scratch)
+    //
+    // Three copies of the walk, chosen per wave (wave-uniform):
+    //   * interior wave tiles (every row and column in range, 4-wide accesses allowed, no atomics) run a fully
+    //     unrolled branch-free walk, with or without prefetched side inputs;
+    //   * everything else (ragged edges, unaligned pointers, atomic split-K) runs ONE looped copy of the general
+    //     per-element code.  Keeping the general code out of the unrolled walk is what keeps the kernel's
+    //     instruction footprint small: unrolled, it was >90 % of a 600 KB kernel image and the 4-wave kernel spent
+    //     ~40 us per tile fetching instructions.
     constexpr int PLD = TN + 4;                    // patch row stride in floats (TN = 64 -> 68: 8 rows x 4 banks)
     constexpr int LPR = TN / 4;                    // lanes per row in the row-major walk
     constexpr int RPI = 64 / LPR;                  // rows per instruction
@@ -110,32 +177,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     const int n = n0 + wn0 + pc;
     const bool n_in = n < p.n;
     const bool full = p.vec && n + 3 < p.n;
-    // Side inputs of the epilogue (z for GELU', residual r) come from HBM.  They are fetched into registers PFD row
-    // groups ahead (the slot consumed at a row group is re-issued right away for the group PFD further on), with
-    // clamped addresses and no data-dependent branch around the loads: otherwise every row group is a serial
-    // load -> use -> store chain (the loads cannot be hoisted above the previous group's stores) and the whole
-    // memory latency is exposed 32 times per tile with the matrix pipe idle.
-    const bool pf_z = p.vec && p.n >= 4 && p.zgrad != nullptr, pf_r = p.vec && p.n >= 4 && p.r != nullptr;
-    const int npf = full ? n : 0;
-    // prefetch distance in row groups: a whole slab by default (2 waves per SIMD); the caller shortens it when four
-    // waves share a SIMD (128 registers per lane, and the other waves cover more of the latency)
-    constexpr int PFD = PFDIST > 0 ? (PFDIST < NIT ? PFDIST : NIT) : NIT;
-    bf16x4 zq[PFD];
-    f32x4 rq[PFD];                                 // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
-    auto side_load = [&](auto gc) {                // gc: linear row-group index = slab * NIT + group
-        constexpr int gi = decltype(gc)::value;
-        constexpr int slot = gi % PFD;
-        const int mm = min(m0 + wm0 + (gi / NIT) * 32 + (gi % NIT) * RPI + pr, p.m - 1);
-        if (pf_z) zq[slot] = *(const bf16x4*)(p.zgrad + (long)mm * p.ldzg + npf);
-        if (pf_r) {
-            const int rr = p.r_row_mod > 0 ? (mm % p.r_row_mod) : mm;
-            if (p.r_dtype == DW_F32) rq[slot] = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + npf);
-            else {
-                const f32x2 t = *(const f32x2*)((const bf16*)p.r + (long)rr * p.ldr + npf);
-                rq[slot][0] = t[0]; rq[slot][1] = t[1];
-            }
-        }
-    };
+    const bool interior = p.vec && !p.atomic && n0 + wn0 + TN <= p.n && m0 + wm0 + FM * 32 <= p.m;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && n_in) {
         if (full) b4 = *(const f32x4*)(p.bias + n);
@@ -144,17 +186,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             for (int e = 0; e < 4; ++e) if (n + e < p.n) b4[e] = p.bias[n + e];
         }
     }
-    // Two copies of the slab walk, with and without side inputs (block-uniform choice): the copy without them does
-    // not carry the prefetch registers through the GELU arithmetic.
-    auto walk = [&](auto side_c) {
-    constexpr bool SIDE = decltype(side_c)::value;
-    if constexpr (SIDE) static_for<0, PFD>([&](auto gc) { side_load(gc); });
-    __syncthreads();                               // every wave is done reading the operand tiles
-    static_for<0, FM>([&](auto ic) {
+    auto to_patch = [&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        static_for<0, FN>([&](auto jc) {
+        static_for<0, FN>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
-            static_for<0, 4>([&](auto gc) {
+            static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
                 constexpr int g = decltype(gc)::value;
                 f32x4 v4;
                 v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1];
@@ -162,84 +198,99 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                 *(f32x4*)(patch + ln * PLD + j * 32 + g * 8 + hi * 4) = v4;
             });
         });
-        // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads below)
-        static_for<0, NIT>([&](auto itc) {
-            constexpr int it = decltype(itc)::value;
+        // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads that follow)
+    };
+
+    if (interior) {
+        // Side inputs of the epilogue (z for GELU', residual r) come from HBM.  They are fetched into registers PFD
+        // row groups ahead (the slot consumed at a row group is re-issued right away for the group PFD further on):
+        // otherwise every row group is a serial load -> use -> store chain (the loads cannot be hoisted above the
+        // previous group's stores) and the whole memory latency is exposed 32 times per tile with the matrix pipe
+        // idle.  The prefetch distance is a whole slab by default (2 waves per SIMD); callers shorten it when four
+        // waves share a SIMD (128 registers per lane, and the other waves cover more of the latency).
+        const bool pf_z = p.zgrad != nullptr, pf_r = p.r != nullptr;
+        constexpr int PFD = PFDIST > 0 ? (PFDIST < NIT ? PFDIST : NIT) : NIT;
+        bf16x4 zq[PFD];
+        f32x4 rq[PFD];                             // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
+        auto side_load = [&](auto gc) __attribute__((always_inline)) {   // gc: linear row-group index = slab * NIT + group
+            constexpr int gi = decltype(gc)::value;
+            constexpr int slot = gi % PFD;
+            const int mm = m0 + wm0 + (gi / NIT) * 32 + (gi % NIT) * RPI + pr;
+            if (pf_z) zq[slot] = *(const bf16x4*)(p.zgrad + (long)mm * p.ldzg + n);
+            if (pf_r) {
+                const int rr = p.r_row_mod > 0 ? (mm % p.r_row_mod) : mm;
+                if (p.r_dtype == DW_F32) rq[slot] = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + n);
+                else {
+                    const f32x2 t = *(const f32x2*)((const bf16*)p.r + (long)rr * p.ldr + n);
+                    rq[slot][0] = t[0]; rq[slot][1] = t[1];
+                }
+            }
+        };
+        // Two copies of the slab walk, with and without side inputs (block-uniform choice): the copy without them
+        // does not carry the prefetch registers through the GELU arithmetic.
+        auto walk = [&](auto side_c) __attribute__((always_inline)) {
+            constexpr bool SIDE = decltype(side_c)::value;
+            if constexpr (SIDE) static_for<0, PFD>([&](auto gc) __attribute__((always_inline)) { side_load(gc); });
+            __syncthreads();                       // every wave is done reading the operand tiles
+            static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                to_patch(ic);
+                static_for<0, NIT>([&](auto itc) __attribute__((always_inline)) {
+                    constexpr int it = decltype(itc)::value;
+                    const int rl = it * RPI + pr;
+                    const int m = m0 + wm0 + i * 32 + rl;
+                    const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
+                    bf16x4 zs;
+                    f32x4 rs;
+                    if constexpr (SIDE) {
+                        constexpr int gi = i * NIT + it;
+                        zs = zq[gi % PFD]; rs = rq[gi % PFD];
+                        if constexpr (gi + PFD < FM * NIT) side_load(std::integral_constant<int, gi + PFD>{});
+                    }
+                    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                    gemm_epi_vec4(p, v, b4, plain, SIDE, zs, rs, cf, m, n);
+                });
+            });
+        };
+        if (pf_z || pf_r) walk(std::true_type{});
+        else walk(std::false_type{});
+        return;
+    }
+
+    // ---- general walk (ragged tile edges, unaligned pointers, atomic accumulation): looped, loads at use ----
+    __syncthreads();
+    static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        to_patch(ic);
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
             const int rl = it * RPI + pr;
             const int m = m0 + wm0 + i * 32 + rl;
             const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
-            bf16x4 zs;
-            f32x4 rs;
-            if constexpr (SIDE) {
-                constexpr int gi = i * NIT + it;
-                zs = zq[gi % PFD]; rs = rq[gi % PFD];
-                if constexpr (gi + PFD < FM * NIT) side_load(std::integral_constant<int, gi + PFD>{});
-            }
-            if (m >= p.m || !n_in) return;
+            if (m >= p.m || !n_in) continue;
             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
             if (p.atomic) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (n + e < p.n) atomicAdd(cf + (long)m * p.ldc + n + e, v[e]);
-                return;
+                continue;
             }
+            const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
             if (full) {
-                if (!plain) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                    if (p.z_out) {
-                        bf16x4 z4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
-                        *(bf16x4*)(p.z_out + (long)m * p.ldz + n) = z4;
-                    }
-                    if (p.act == 1) {
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
-                            const f32x2 g2 = gelu_fast2(x2);
-                            v[e] = g2[0]; v[e + 1] = g2[1];
-                        }
-                    }
-                    if constexpr (SIDE) {
-                    if (p.zgrad) {
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            f32x2 x2; x2[0] = bf2f(zs[e]); x2[1] = bf2f(zs[e + 1]);
-                            const f32x2 g2 = gelu_grad_fast2(x2);
-                            v[e] *= g2[0]; v[e + 1] *= g2[1];
-                        }
-                    }
-                    if (p.r) {
-                        float rv[4];
-                        if (p.r_dtype == DW_F32) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) rv[e] = rs[e];
-                        } else {
-                            const unsigned u0 = __float_as_uint(rs[0]), u1 = __float_as_uint(rs[1]);
-                            rv[0] = __uint_as_float(u0 << 16); rv[1] = __uint_as_float(u0 & 0xffff0000u);
-                            rv[2] = __uint_as_float(u1 << 16); rv[3] = __uint_as_float(u1 & 0xffff0000u);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
-                    }
+                bf16x4 zs = {};
+                f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+                if (p.zgrad) zs = *(const bf16x4*)(p.zgrad + (long)m * p.ldzg + n);
+                if (p.r) {
+                    if (p.r_dtype == DW_F32) rs = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + n);
+                    else {
+                        const f32x2 t = *(const f32x2*)((const bf16*)p.r + (long)rr * p.ldr + n);
+                        rs[0] = t[0]; rs[1] = t[1];
                     }
                 }
-                if (p.c_dtype == DW_F32) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = v[e];
-                    *(f32x4*)(cf + (long)m * p.ldc + n) = o;
-                } else {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-                    *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
-                }
+                gemm_epi_vec4(p, v, b4, plain, true, zs, rs, cf, m, n);
             } else {
                 // ragged / unaligned columns: scalar path
-                const int rr = p.r_row_mod > 0 ? (m % p.r_row_mod) : m;
-#pragma unroll
+#pragma unroll 1
                 for (int e = 0; e < 4; ++e) {
                     const int nn = n + e;
                     if (nn >= p.n) continue;
@@ -259,9 +310,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                     else ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x);
                 }
             }
-        });
+        }
     });
-    };
-    if (pf_z || pf_r) walk(std::true_type{});
-    else walk(std::false_type{});
 }

@@ -1,0 +1,247 @@
+// 4-wave software-pipelined main loop for the 256x256x64 bf16 MFMA GEMM: ONE wave per SIMD, 128x128 of output per wave.
+//
+// Same block tile, LDS image, k order and fused epilogue as the 16-wave kernel of gemm_kernel.h (results are
+// bit-identical: every output element is the same fp32 chain over k); what changes is the shape of a wave's work.
+//   * 4 waves as 2 x 2, each owns 128 x 128 = 4 x 4 accumulators of 32x32 (256 accumulator registers out of the
+//     512-entry file a single resident wave per SIMD may use).  A 64-deep K tile costs a wave 32 fragment reads for
+//     64 MFMAs -- half the LDS->register bytes per flop of the 64x64 wave tiles (the 16-wave kernel reads every
+//     operand fragment four times per workgroup, this one twice) -- and the whole workgroup meets at ONE barrier per
+//     K tile with 4 participants instead of 16.
+//   * With one wave per SIMD nothing else covers a stall, so the K loop is software pipelined by hand.  Per K tile t
+//     a wave runs four sub-steps of 16 MFMAs (one 16-deep k slice of all 16 accumulators); under the MFMAs of
+//     sub-step s it requests the fragments of sub-step s+1 into the other half of a register double buffer (sub-step
+//     3 requests sub-step 0 of tile t+1 from the other LDS buffer) and issues its share of the operand DMA
+//     (global_load_lds_dwordx4, 16 pieces of 1 KiB per wave per K tile):
+//         sub-step 0:  F(t,1)    DMA second half of tile t+1
+//         sub-step 1:  F(t,2)
+//         sub-step 2:  F(t,3)
+//         -- s_waitcnt vmcnt(0) (issued >= 2 sub-steps earlier), fragments of sub-step 3 in registers, s_barrier --
+//         sub-step 3:  F(t+1,0)  DMA first half of tile t+2 (into the buffer every wave has just finished reading)
+//     so a DMA piece has 2.5-3.5 sub-steps (>= 1300 cycles at full MFMA rate) to land, an LDS read a whole sub-step.
+//   * The instruction interleave inside a sub-step is pinned with sched_group_barrier (one memory instruction per
+//     MFMA gap); the loop is peeled into (steady, last-but-one, last) so the steady body has no branches.
+#pragma once
+#include "gemm_common.h"
+
+// Make a fragment set opaque at a program point: the sub-step's MFMAs depend on it (they cannot be hoisted into the
+// previous sub-step) and the compiler's lgkmcnt wait for the set lands here.
+#define PINF(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]), "+v"((f)[2]), "+v"((f)[3]))
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
+    constexpr int BM = 256, BN = 256, NW = 4, FM = 4, FN = 4, TN = 128;
+    constexpr int STAGE = (BM + BN) * 128;            // one K tile: A [256][64] | B [256][64] (or their k-major images)
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 128;
+
+    int job_first, job_count, job_step;
+    gemm_job_range(p, job_first, job_count, job_step);
+    for (int job = 0; job < job_count; ++job) {
+        int tm, tn, ks;
+        gemm_job_decode(p, job_first + job * job_step, tm, tn, ks);
+        const int m0 = tm * BM, n0 = tn * BN;
+
+        // ---- DMA sources: uniform base (advanced per K tile) + per-lane byte offset (loop invariant) ----
+        // piece c = wave + 4 i (i = 0..7) of each operand: rows 8c..8c+7 of the row-major image (8 lanes of 16 B per
+        // row, swizzled slot) or k rows 2c, 2c+1 of the k-major image [64][256] (32 lanes of 16 B per k row)
+        // (buffer addressing: descriptor = uniform tile origin, voffset = the per-lane part, soffset = the K advance,
+        // so a K tile costs no per-lane address arithmetic; all offsets stay below 2^31, checked by the launcher)
+        unsigned offA[8], offB[8];
+        const bf16* gA;
+        const bf16* gB;
+        int stepA, stepB;
+        if (!TA) {
+            gA = p.a + (long)m0 * p.lda;
+            stepA = 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (wave + i * NW) * 8 + (lane >> 3);
+                const int ls = (lane & 7) ^ swz7(row);
+                const int grow = m0 + row < p.m ? row : p.m - 1 - m0;
+                offA[i] = (unsigned)((grow * p.lda + ls * 8) * 2);
+            }
+        } else {
+            gA = p.a + m0;
+            stepA = 128 * (int)p.lda;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int krow = (wave + i * NW) * 2 + (lane >> 5);
+                const int ls = (lane & 31) ^ ((krow & 3) << 2);
+                const int gcol = m0 + ls * 8 < p.m ? ls * 8 : 0;
+                offA[i] = (unsigned)((krow * p.lda + gcol) * 2);
+            }
+        }
+        if (!TB) {
+            gB = p.b + (long)n0 * p.ldb;
+            stepB = 128;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (wave + i * NW) * 8 + (lane >> 3);
+                const int ls = (lane & 7) ^ swz7(row);
+                const int grow = n0 + row < p.n ? row : p.n - 1 - n0;
+                offB[i] = (unsigned)((grow * p.ldb + ls * 8) * 2);
+            }
+        } else {
+            gB = p.b + n0;
+            stepB = 128 * (int)p.ldb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int krow = (wave + i * NW) * 2 + (lane >> 5);
+                const int ls = (lane & 31) ^ ((krow & 3) << 2);
+                const int gcol = n0 + ls * 8 < p.n ? ls * 8 : 0;
+                offB[i] = (unsigned)((krow * p.ldb + gcol) * 2);
+            }
+        }
+        int nt = p.k >> 6;
+        {
+            const int base = nt / p.split_k, rem = nt - base * p.split_k;
+            const int first = ks * base + (ks < rem ? ks : rem);
+            nt = base + (ks < rem ? 1 : 0);
+            gA = (const bf16*)((const char*)gA + (long)first * stepA);
+            gB = (const bf16*)((const char*)gB + (long)first * stepB);
+        }
+        const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);
+        const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, 0x7fffffff, 0x00020000);
+        int kA = 0, kB = 0;                               // byte offset of the K tile the next DMA fetches
+
+        f32x16 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // this wave's pieces [4 half, 4 half + 4) of both operands of the K tile at (kA, kB) into LDS buffer `buf`
+        auto dma = [&](auto hc, int buf) {
+            constexpr int h = decltype(hc)::value;
+            char* tA = smem + buf * STAGE + wave * 1024;
+            char* tB = tA + BM * 128;
+#pragma unroll
+            for (int i = 4 * h; i < 4 * h + 4; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(tA + i * (NW * 1024)), 16, offA[i], kA, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(tB + i * (NW * 1024)), 16, offB[i], kB, 0, 0);
+            }
+        };
+        bf16x8 af[2][FM], bfr[2][FN];
+        auto frags = [&](auto sc, auto kc, int buf) {
+            constexpr int set = decltype(sc)::value, kk = decltype(kc)::value;
+            const char* tA = smem + buf * STAGE;
+            const char* tB = tA + BM * 128;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if (TA) af[set][i] = frag_kmajor<BM>(tA, wm0 + i * 32, kk, lane);
+                else af[set][i] = frag_rows(tA, (wm0 >> 5) + i, kk, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if (TB) bfr[set][j] = frag_kmajor<BN>(tB, wn0 + j * 32, kk, lane);
+                else bfr[set][j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane);
+            }
+        };
+        auto mfmas = [&](auto sc) {
+            constexpr int set = decltype(sc)::value;
+            static_for<0, FM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, FN>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][j], af[set][i], acc[i][j], 0, 0, 0);
+                });
+            });
+        };
+        // pinned interleave of a sub-step: one MFMA, then (first half of the sub-step) the LDS reads of one fragment,
+        // (second half) one DMA piece.  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read.
+        auto interleave = [&](auto rc, auto vc) {
+            constexpr int R = decltype(rc)::value;           // fragments requested in this sub-step (0 or 8)
+            constexpr int V = decltype(vc)::value;           // DMA pieces issued in this sub-step (0 or 8)
+            constexpr int RI = (TA ? 2 : 1) + (TB ? 2 : 1);  // DS instructions of one A + one B fragment ...
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                if (R && q < 8 && (q & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, RI, 0);   // ... every other gap
+                if (V && q >= 8) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
+        using I8 = std::integral_constant<int, 8>;
+
+        // ---- prologue: tile 0 whole, first half of tile 1, fragments of (0, 0) ----
+        dma(I0{}, 0); dma(I1{}, 0);
+        kA += stepA; kB += stepB;
+        if (nt > 1) dma(I0{}, 1);
+        if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_vm0();
+        __syncthreads();
+        frags(I0{}, I0{}, 0);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // one K tile; MORE1: tile t+1 exists, MORE2: tile t+2 exists.  (kA, kB) point at tile t+1 on entry.
+        auto body = [&](auto m1c, auto m2c, int t) {
+            constexpr bool MORE1 = decltype(m1c)::value, MORE2 = decltype(m2c)::value;
+            const int buf = t & 1;
+            // sub-step 0
+            PINF(af[0]); PINF(bfr[0]);
+            frags(I1{}, I1{}, buf);
+            if constexpr (MORE1) { dma(I1{}, buf ^ 1); kA += stepA; kB += stepB; }
+            mfmas(I0{});
+            if constexpr (MORE1) interleave(I8{}, I8{}); else interleave(I8{}, I0{});
+            // sub-step 1
+            PINF(af[1]); PINF(bfr[1]);
+            frags(I0{}, I2{}, buf);
+            mfmas(I1{});
+            interleave(I8{}, I0{});
+            // sub-step 2
+            PINF(af[0]); PINF(bfr[0]);
+            frags(I1{}, I3{}, buf);
+            mfmas(I0{});
+            interleave(I8{}, I0{});
+            // every wave: its DMA pieces of tile t+1 have landed, its last fragments of tile t are in registers
+            PINF(af[1]); PINF(bfr[1]);
+            if constexpr (MORE1) {
+                wait_vm0();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // sub-step 3
+            if constexpr (MORE1) frags(I0{}, I0{}, buf ^ 1);
+            if constexpr (MORE2) dma(I0{}, buf);
+            mfmas(I1{});
+            if constexpr (MORE2) interleave(I8{}, I8{});
+            else if constexpr (MORE1) interleave(I8{}, I0{});
+            else interleave(I0{}, I0{});
+        };
+        int t = 0;
+        for (; t + 2 < nt; ++t) body(std::true_type{}, std::true_type{}, t);
+        if (nt >= 2) { body(std::true_type{}, std::false_type{}, t); ++t; }
+        body(std::false_type{}, std::false_type{}, t);
+
+        gemm_epilogue<FM, FN, TN, 8>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
+        __syncthreads();   // the LDS patches are reused as operand buffers by the next job
+    }
+}
+
+template <bool TA, bool TB>
+static int launch_w4(const GemmP& p0, hipStream_t s) {
+    GemmP p = p0;
+    const int tiles_m = (p.m + 255) / 256;
+    p.tiles_n = (p.n + 255) / 256;
+    p.nwg = tiles_m * p.tiles_n;
+    {
+        const long tile_bytes = 256L * p.k * 2;
+        int sw = (int)((4L << 20) / tile_bytes);
+        if (sw < 3 || sw >= p.tiles_n) sw = p.tiles_n;
+        p.strip = p.strip > 0 ? p.strip : sw;
+    }
+    int nblk = p.nwg * p.split_k;
+    if (nblk > 256) nblk = 256;
+    hipLaunchKernelGGL((gemm_w4_kernel<TA, TB>), dim3(nblk), dim3(256), 0, s, p);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}

@@ -75,9 +75,10 @@ class LongFormTranscriber:
 
     def __init__(self, model, feature_extractor, batch_size=16, chunk_length_s=30.0, stride_length_s=None,
                  max_new_tokens=128, prompt_ids=None, eos_token_id=None, first_special_id=None, suppress_tokens=None,
-                 begin_suppress_tokens=None, use_graphs=None):
+                 begin_suppress_tokens=None, use_graphs=None, rank=0, world=1):
         self.model, self.fe = model, feature_extractor
         self.B = int(batch_size)
+        self.rank, self.world = int(rank), int(world)
         sr = feature_extractor.sampling_rate
         if stride_length_s is None:
             stride_length_s = chunk_length_s / 6
@@ -112,11 +113,31 @@ class LongFormTranscriber:
                 jobs.append((u, start, length))
         return jobs
 
-    def __call__(self, audios):
+    def __call__(self, audios, gather=False, group=None):
+        """With world > 1 each rank transcribes a contiguous shard of the utterances (whole utterances: stitching is
+        per utterance, there is no data-path collective); the others come back as None unless `gather=True`, which
+        exchanges the stitched id lists in rank order (the reference's pad_across_processes + gather_for_metrics,
+        run_distillation.py:1527, 1695-1697)."""
         model = self.model
         model._sync_shadow()
+        n_all = len(audios)
+        per = (n_all + self.world - 1) // self.world
+        lo, hi = min(self.rank * per, n_all), min((self.rank + 1) * per, n_all)
         audios = [torch.as_tensor(np.asarray(a, dtype=np.float32) if not torch.is_tensor(a) else a,
-                                  dtype=torch.float32).reshape(-1).to(self.dev) for a in audios]
+                                  dtype=torch.float32).reshape(-1).to(self.dev) for a in audios[lo:hi]]
+        mine = self._transcribe(audios)
+        if self.world == 1:
+            return mine
+        if gather:
+            from .gather import gather_token_lists
+            rows = gather_token_lists(mine, self.eos if self.eos is not None else 0, self.dev, group=group)
+            if len(rows) != n_all:
+                raise RuntimeError(f"gathered {len(rows)} transcripts for {n_all} utterances: ranks disagree on the input")
+            return rows
+        return [None] * lo + mine + [None] * (n_all - hi)
+
+    def _transcribe(self, audios):
+        model = self.model
         jobs = self.plan([a.numel() for a in audios])
         per_utt = [[] for _ in audios]
         prompt = self.prompt[None, :].expand(self.B, -1).contiguous()

@@ -62,7 +62,10 @@ class PseudoLabeller:
                                      use_graphs=use_graphs, timestamp_rules=timestamp_rules)
         self._wave = torch.zeros((self.B, feature_extractor.n_samples), dtype=torch.float32, device=dev)
 
-    def __call__(self, audios, speaker_ids=None):
+    def __call__(self, audios, speaker_ids=None, gather=False, group=None):
+        """`gather=True`: every rank returns the labels of ALL packs (rank-ordered exchange of the id lists, the
+        reference's pad_across_processes + gather_for_metrics, run_pseudo_labelling.py:893-895); otherwise packs of
+        other ranks' shards come back as None."""
         model = self.model
         model._sync_shadow()
         audios = [torch.as_tensor(np.asarray(a, dtype=np.float32) if not torch.is_tensor(a) else a,
@@ -88,4 +91,11 @@ class PseudoLabeller:
                 if self.eos is not None and self.eos in row:
                     row = row[:row.index(self.eos)]
                 out[pi] = [int(x) for x in row]
+        if gather and self.world > 1:
+            from .gather import gather_token_lists
+            fill = self.eos if self.eos is not None else 0
+            rows = gather_token_lists([out[i] for i in mine], fill, self.dev, group=group)
+            if len(rows) != len(packs):
+                raise RuntimeError(f"gathered {len(rows)} label rows for {len(packs)} packs: ranks disagree on the plan")
+            return rows, packs, cond
         return [out.get(i) for i in range(len(packs))], packs, cond

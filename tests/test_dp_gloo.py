@@ -72,3 +72,78 @@ def test_two_ranks_match_averaged_single_process(tmp_path):
     a, b = tr.student_store.P, r0["P"]
     rel = ((a - b).norm() / b.norm()).item()
     assert rel < 2e-6, rel
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# eval-side exchange: generated ids padded to a common width and concatenated in rank order
+def _gather_worker(rank, world, port, out_dir):
+    import numpy as np
+    from distil_whisper_amd.gather import gather_rows, gather_token_lists, pad_across_processes
+    from distil_whisper_amd.longform import LongFormTranscriber
+    from distil_whisper_amd.modeling import WhisperFeatureExtractor, WhisperForConditionalGeneration
+    from distil_whisper_amd.pseudo_label import PseudoLabeller
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # primitives: ragged widths and ragged row counts
+    mine = torch.arange(1, 1 + (3 - rank) * (4 + 2 * rank)).reshape(3 - rank, 4 + 2 * rank)     # rank0 [3,4], rank1 [2,6]
+    padded = pad_across_processes(mine, dim=1, pad_index=-7)
+    full = gather_rows(mine, pad_index=-7)
+    lists = gather_token_lists([[5] * (rank + 1), [], [9, 9, 0]][:3 - rank], 0, "cpu")
+    # the two generation front ends, sharded over the ranks and gathered
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 4)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    ops = RefOps("cpu", lowp=torch.float32)
+    model = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+    fe = WhisperFeatureExtractor(feature_size=cfg_s.n_mels, ops=ops)
+    rng = np.random.default_rng(10)
+    audios = [0.1 * rng.standard_normal(n).astype(np.float32) for n in (200_000, 150_000, 300_000, 100_000, 250_000)]
+    spk = [0, 0, 0, 1, 2]
+    eos = cfg_s.vocab - 3
+    pl = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=5, eos_token_id=eos, use_graphs=False, rank=rank, world=world)
+    labels = pl(audios, spk, gather=True)[0]
+    lf = LongFormTranscriber(model, fe, batch_size=2, max_new_tokens=4, first_special_id=cfg_s.vocab - 8, use_graphs=False,
+                             rank=rank, world=world)
+    texts = lf([audios[2], np.concatenate([audios[0], audios[2], audios[4]]), audios[3]], gather=True)
+    partial = lf([audios[2], audios[3], audios[4]])
+    torch.save({"padded": padded, "full": full, "lists": lists, "labels": labels, "texts": texts, "partial": partial},
+               os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_generated_ids_are_gathered_in_rank_order(tmp_path):
+    import numpy as np
+    from distil_whisper_amd.longform import LongFormTranscriber
+    from distil_whisper_amd.modeling import WhisperFeatureExtractor, WhisperForConditionalGeneration
+    from distil_whisper_amd.pseudo_label import PseudoLabeller
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "g0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "g1.pt"))
+    a, b = torch.arange(1, 13).reshape(3, 4), torch.arange(1, 13).reshape(2, 6)
+    assert r0["padded"].shape == (3, 6) and torch.equal(r0["padded"][:, :4], a) and bool((r0["padded"][:, 4:] == -7).all())
+    assert torch.equal(r1["padded"], b)
+    want = torch.cat([torch.cat([a, torch.full((3, 2), -7)], 1), b], 0)
+    assert torch.equal(r0["full"], want) and torch.equal(r1["full"], want)
+    assert r0["lists"] == r1["lists"] == [[5], [], [9, 9, 0], [5, 5], []]
+    # single-process answers
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 4)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    ops = RefOps("cpu", lowp=torch.float32)
+    model = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+    fe = WhisperFeatureExtractor(feature_size=cfg_s.n_mels, ops=ops)
+    rng = np.random.default_rng(10)
+    audios = [0.1 * rng.standard_normal(n).astype(np.float32) for n in (200_000, 150_000, 300_000, 100_000, 250_000)]
+    eos = cfg_s.vocab - 3
+    labels = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=5, eos_token_id=eos, use_graphs=False)(audios, [0, 0, 0, 1, 2])[0]
+    assert r0["labels"] == labels and r1["labels"] == labels and len(labels) == 4
+    lf = LongFormTranscriber(model, fe, batch_size=2, max_new_tokens=4, first_special_id=cfg_s.vocab - 8, use_graphs=False)
+    texts = lf([audios[2], np.concatenate([audios[0], audios[2], audios[4]]), audios[3]])
+    assert r0["texts"] == texts and r1["texts"] == texts
+    part = lf([audios[2], audios[3], audios[4]])
+    assert r0["partial"] == part[:2] + [None] and r1["partial"] == [None, None] + part[2:]

@@ -21,14 +21,14 @@ for name, M, N, K, ta, tb in shapes:
     a = rnd((K, M) if ta else (M, K)); b = rnd((K, N) if tb else (N, K), 0.05)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     res = {v: [] for v in variants}
-    ops.lib.dw_debug_set(0, 0); ops.lib.dw_debug_set(1, 1000)
+    ops.lib.dw_debug_set(0, 3)
     ref = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256).clone()
     for v in variants:
         ops.lib.dw_debug_set(KEY, v)
         for rep in range(3):
             o = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256)
             d = (o.float() - ref.float()).abs().max().item()
-            if d != 0.0 and (KEY == 1 or v < 8):
+            if d != 0.0:
                 print("MISMATCH variant", v, "rep", rep, "max abs diff", d, flush=True)
     for rnd_i in range(5):
         for v in variants:

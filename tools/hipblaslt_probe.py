@@ -1,0 +1,42 @@
+"""Calibration: this library's bf16 GEMM against the vendor library (torch.matmul -> hipBLASLt) on the step's shapes,
+interleaved in one process on the same buffers.  Not a product path: it only says how far the kernels are from what
+the vendor's tuned assembly reaches on this box (same power cap, same clocks)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distil_whisper_amd.ops_hip import HipOps
+
+ops = HipOps("cuda:0")
+B = 32
+def rnd(shape, s=1.0): return (torch.randn(shape, device="cuda") * s).bfloat16()
+# (name, M, N, K, trans_a, trans_b): C[M,N] = op(A) . op(B)^T in this library's convention (B stored [N,K] unless tb)
+shapes = [("fwd qkv N=3840 K=1280", B*1500, 3840, 1280, False, False), ("fwd fc1 N=5120 K=1280", B*1500, 5120, 1280, False, False),
+          ("fwd fc2 N=1280 K=5120", B*1500, 1280, 5120, False, False), ("fwd out N=1280 K=1280", B*1500, 1280, 1280, False, False),
+          ("dX fc2 N=5120 K=1280", B*1500, 5120, 1280, False, True), ("dX fc1 N=1280 K=5120", B*1500, 1280, 5120, False, True),
+          ("dW fc1 5120x1280 K=48000", 5120, 1280, B*1500, True, True), ("dW qkv 3840x1280 K=48000", 3840, 1280, B*1500, True, True),
+          ("dec fc1 M=14304", B*447, 5120, 1280, False, False), ("lm head", B*447, 51904, 1280, False, False)]
+
+def timed(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+for name, M, N, K, ta, tb in shapes:
+    a = rnd((K, M) if ta else (M, K)); b = rnd((K, N) if tb else (N, K), 0.05)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    A = a.t() if ta else a                  # [M, K] view
+    Bm = b if tb else b.t()                 # [K, N] view
+    mine = lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out, tile=256)
+    vend = lambda: torch.matmul(A, Bm, out=out2)
+    mine(); vend()
+    d = (out.float() - out2.float()).abs().max().item()
+    r = {"mine": [], "vendor": []}
+    for _ in range(5):
+        r["mine"].append(2.0 * M * N * K / (timed(mine) * 1e-3) / 1e12)
+        r["vendor"].append(2.0 * M * N * K / (timed(vend) * 1e-3) / 1e12)
+    med = {k: sorted(v)[len(v) // 2] for k, v in r.items()}
+    print(f"{name:28s} mine {med['mine']:6.0f} TF/s   vendor {med['vendor']:6.0f} TF/s   max|diff| {d:.3g}", flush=True)
