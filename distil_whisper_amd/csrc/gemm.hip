@@ -23,20 +23,24 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_phased_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_phased.hip
 int dw_gemm_tile256_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile256.hip: 16 waves, 4 x 4
 int dw_gemm_tile128_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile128.hip: 8 waves, 2 x 4
-int dw_gemm_w4_nn_launch(const GemmP& p, hipStream_t s);                    // gemm_w4_*.hip: 4 waves, 128 x 128 per wave
-int dw_gemm_w4_nt_launch(const GemmP& p, hipStream_t s);
-int dw_gemm_w4_tt_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp8_nn_launch(const GemmP& p, hipStream_t s);                   // gemm_wp8_*.hip: software-pipelined loop, 8 waves
+int dw_gemm_wp8_nt_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp8_tt_launch(const GemmP& p, hipStream_t s);
 
 extern int g_attn_bwd_stage;  // attention.hip
 extern int g_attn_decode;
 extern int g_logmel_mfma;     // logmel.hip
 int g_gemm_persistent = 1;
-// 3: 16-wave 256x256 tile + 8-wave 128x128 tile (the 8-wave 256-tile layouts and the 4-wave 128 tile of round 1 lost
-// to these and were removed, profiles/r1_gemm_pmc.md); 5: as 3, with the phase-pipelined kernel (gemm_phased.hip) for
-// every 256-tile dX GEMM (k-major B); 7 (default): as 3, with the phase-pipelined kernel where it measured faster on MI355X --
-// k-major B operand and a long contraction (dX = dY.W with K >= 3840: +7..10 %; it loses 5-20 % on the short-K and
-// row-major shapes, profiles/r2_gemm_variants.md)
-static int g_gemm_variant = 7;
+// Kernel selection for the 256x256 block tile (bit mask; dw_debug_set(0, v)):
+//   bits 0-1 (3): base = 16-wave tile kernel (gemm_kernel.h) for everything, 8-wave 128x128 tile for small grids;
+//   bit 2 (4):    phase-pipelined kernel (gemm_phased.hip) for dX GEMMs (k-major B) with K >= 3840 (+7..10 % there);
+//   bit 4 (16):   8-wave software-pipelined kernel (gemm_wp.h, 128x64 per wave) for row-major operands;
+//   bit 5 (32):   ... for dX GEMMs the phased kernel does not take;   bit 6 (64): ... for dW GEMMs (both k-major);
+//   bit 7 (128):  phased kernel for every dX GEMM (tests).
+// (gemm_wp.h also instantiates as 4 waves x 128x128 -- one wave per SIMD, half the LDS fragment traffic -- but a lone
+// wave cannot cover its own DMA issue slots: 4-10 % behind the 8-wave layout on every shape, not built.)
+// Every kernel produces bit-identical results (same fp32 chain over k per output element): tests/test_kernels_gpu.py.
+static int g_gemm_variant = 119;
 int g_gemm_strip = 0;
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
@@ -122,24 +126,22 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         tile = t256 >= 512 ? 256 : 128;
     }
     if (tile == 256) {
-        // bit 3: the 4-wave software-pipelined kernel for the layouts it is built for (DMA offsets must fit 31 bits)
-        if ((g_gemm_variant & 8) && !(g->trans_a && !g->trans_b)) {
-            const long spanA = g->trans_a ? (long)g->k * g->lda * 2 : 256L * g->lda * 2 + (long)g->k * 2;
-            const long spanB = g->trans_b ? (long)g->k * g->ldb * 2 : 256L * g->ldb * 2 + (long)g->k * 2;
-            if (spanA < 0x7fffffffL && spanB < 0x7fffffffL) {
-                p.strip = g_gemm_strip;
-                if (!g->trans_a && !g->trans_b) return dw_gemm_w4_nn_launch(p, s);
-                if (!g->trans_a && g->trans_b) return dw_gemm_w4_nt_launch(p, s);
-                return dw_gemm_w4_tt_launch(p, s);
-            }
-        }
-        if (g_gemm_variant == 5 && !g->trans_a && g->trans_b) {
-            p.strip = g_gemm_strip;
-            return dw_gemm_phased_launch(p, g->trans_a, g->trans_b, s);
-        }
-        if (g_gemm_variant == 7 && !g->trans_a && g->trans_b && g->k >= 3840 && p.split_k == 1) {
-            p.strip = g_gemm_strip;
-            return dw_gemm_phased_launch(p, 0, 1, s);
+        // the software-pipelined kernels address their operand DMA with 31-bit buffer offsets
+        const long spanA = g->trans_a ? (long)g->k * g->lda * 2 : 256L * g->lda * 2 + (long)g->k * 2;
+        const long spanB = g->trans_b ? (long)g->k * g->ldb * 2 : 256L * g->ldb * 2 + (long)g->k * 2;
+        const bool wp_ok = spanA < 0x7fffffffL && spanB < 0x7fffffffL;
+        const int v = g_gemm_variant;
+        p.strip = g_gemm_strip;
+        if (!g->trans_a && !g->trans_b) {
+            // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
+            // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
+            const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
+            if ((v & 16) && wp_ok && !epi_bound) return dw_gemm_wp8_nn_launch(p, s);
+        } else if (!g->trans_a && g->trans_b) {
+            if (((v & 4) && g->k >= 3840 && p.split_k == 1) || (v & 128)) return dw_gemm_phased_launch(p, 0, 1, s);
+            if ((v & 32) && wp_ok) return dw_gemm_wp8_nt_launch(p, s);
+        } else if (g->trans_a && g->trans_b) {
+            if ((v & 64) && wp_ok) return dw_gemm_wp8_tt_launch(p, s);
         }
         return dw_gemm_tile256_launch(p, g->trans_a, g->trans_b, s);
     }

@@ -1,42 +1,48 @@
-// 4-wave software-pipelined main loop for the 256x256x64 bf16 MFMA GEMM: ONE wave per SIMD, 128x128 of output per wave.
+// Software-pipelined main loop for the 256x256x64 bf16 MFMA GEMM (built as 8 waves = 2 x 4, 128 x 64 of output per wave).
 //
 // Same block tile, LDS image, k order and fused epilogue as the 16-wave kernel of gemm_kernel.h (results are
 // bit-identical: every output element is the same fp32 chain over k); what changes is the shape of a wave's work.
-//   * 4 waves as 2 x 2, each owns 128 x 128 = 4 x 4 accumulators of 32x32 (256 accumulator registers out of the
-//     512-entry file a single resident wave per SIMD may use).  A 64-deep K tile costs a wave 32 fragment reads for
-//     64 MFMAs -- half the LDS->register bytes per flop of the 64x64 wave tiles (the 16-wave kernel reads every
-//     operand fragment four times per workgroup, this one twice) -- and the whole workgroup meets at ONE barrier per
-//     K tile with 4 participants instead of 16.
-//   * With one wave per SIMD nothing else covers a stall, so the K loop is software pipelined by hand.  Per K tile t
-//     a wave runs four sub-steps of 16 MFMAs (one 16-deep k slice of all 16 accumulators); under the MFMAs of
-//     sub-step s it requests the fragments of sub-step s+1 into the other half of a register double buffer (sub-step
-//     3 requests sub-step 0 of tile t+1 from the other LDS buffer) and issues its share of the operand DMA
-//     (global_load_lds_dwordx4, 16 pieces of 1 KiB per wave per K tile):
+//   * WM x WN waves, each owns (256/WM) x (256/WN) of output as 32x32 accumulators.  With 2 x 4 waves a wave holds
+//     4 x 2 accumulators (128 registers), two waves share a SIMD: one wave's MFMAs run in the issue slots the other
+//     spends on LDS reads and operand DMA, a 64-deep K tile costs a wave 24 fragment reads for 32 MFMAs (the 64x64
+//     wave tiles of the 16-wave kernel: 16 reads for 16 MFMAs) and the workgroup's barrier has 8 participants, not 16.
+//     (2 x 2 waves of 128 x 128 -- ONE wave per SIMD, 16 reads for 32 MFMAs -- also instantiates, but a lone wave
+//     cannot cover its own DMA issue slots (~60+ cycles each against a 32-cycle MFMA): 4-10 % slower on every shape.)
+//   * The K loop is software pipelined by hand.  Per K tile t a wave runs four sub-steps (one 16-deep k slice of all
+//     its accumulators); under the MFMAs of sub-step s it requests the fragments of sub-step s+1 into the other half
+//     of a register double buffer (sub-step 3 requests sub-step 0 of tile t+1 from the other LDS buffer) and issues
+//     its share of the operand DMA (buffer_load_dwordx4 ... lds, 1 KiB pieces):
 //         sub-step 0:  F(t,1)    DMA second half of tile t+1
 //         sub-step 1:  F(t,2)
 //         sub-step 2:  F(t,3)
 //         -- s_waitcnt vmcnt(0) (issued >= 2 sub-steps earlier), fragments of sub-step 3 in registers, s_barrier --
 //         sub-step 3:  F(t+1,0)  DMA first half of tile t+2 (into the buffer every wave has just finished reading)
-//     so a DMA piece has 2.5-3.5 sub-steps (>= 1300 cycles at full MFMA rate) to land, an LDS read a whole sub-step.
-//   * The instruction interleave inside a sub-step is pinned with sched_group_barrier (one memory instruction per
-//     MFMA gap); the loop is peeled into (steady, last-but-one, last) so the steady body has no branches.
+//     ONE barrier per K tile; an LDS read has a whole sub-step to return, a DMA piece 2.5-3.5 sub-steps.
+//   * Operand DMA uses buffer addressing: descriptor = uniform tile origin, voffset = the per-lane part (loop
+//     invariant), soffset = the K advance: a K tile costs no per-lane address arithmetic.
+//   * The instruction interleave inside a sub-step is pinned with sched_group_barrier (one memory instruction group
+//     per MFMA gap); the loop is peeled into (steady, last-but-one, last) so the steady body has no branches.
+//   * A deeper variant (five 32-deep stages in a 160 KiB ring, counted vmcnt, 4 stages of prefetch) was built and
+//     measured: slower for row-major operands (one barrier per 32-deep stage), profiles/r2_gemm_variants.md.
 #pragma once
 #include "gemm_common.h"
 
 // Make a fragment set opaque at a program point: the sub-step's MFMAs depend on it (they cannot be hoisted into the
 // previous sub-step) and the compiler's lgkmcnt wait for the set lands here.
 #define PINF(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]), "+v"((f)[2]), "+v"((f)[3]))
+#define PINF2(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]))
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
-    constexpr int BM = 256, BN = 256, NW = 4, FM = 4, FN = 4, TN = 128;
+template <bool TA, bool TB, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(const GemmP p) {
+    constexpr int BM = 256, BN = 256, NW = WM * WN, FM = BM / WM / 32, FN = BN / WN / 32, TN = BN / WN;
+    constexpr int CP = 32 / NW;                       // DMA pieces (1 KiB) per wave per operand per K tile
     constexpr int STAGE = (BM + BN) * 128;            // one K tile: A [256][64] | B [256][64] (or their k-major images)
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 128, wn0 = (wave & 1) * 128;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * TN;
 
     int job_first, job_count, job_step;
     gemm_job_range(p, job_first, job_count, job_step);
@@ -50,7 +56,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
         // row, swizzled slot) or k rows 2c, 2c+1 of the k-major image [64][256] (32 lanes of 16 B per k row)
         // (buffer addressing: descriptor = uniform tile origin, voffset = the per-lane part, soffset = the K advance,
         // so a K tile costs no per-lane address arithmetic; all offsets stay below 2^31, checked by the launcher)
-        unsigned offA[8], offB[8];
+        unsigned offA[8], offB[8];              // (CP used; a dependent-size array captured by the lambdas below makes hipcc drop the host stub)
         const bf16* gA;
         const bf16* gB;
         int stepA, stepB;
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
             gA = p.a + (long)m0 * p.lda;
             stepA = 128;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < CP; ++i) {
                 const int row = (wave + i * NW) * 8 + (lane >> 3);
                 const int ls = (lane & 7) ^ swz7(row);
                 const int grow = m0 + row < p.m ? row : p.m - 1 - m0;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
             gA = p.a + m0;
             stepA = 128 * (int)p.lda;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < CP; ++i) {
                 const int krow = (wave + i * NW) * 2 + (lane >> 5);
                 const int ls = (lane & 31) ^ ((krow & 3) << 2);
                 const int gcol = m0 + ls * 8 < p.m ? ls * 8 : 0;
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
             gB = p.b + (long)n0 * p.ldb;
             stepB = 128;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < CP; ++i) {
                 const int row = (wave + i * NW) * 8 + (lane >> 3);
                 const int ls = (lane & 7) ^ swz7(row);
                 const int grow = n0 + row < p.n ? row : p.n - 1 - n0;
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
             gB = p.b + n0;
             stepB = 128 * (int)p.ldb;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < CP; ++i) {
                 const int krow = (wave + i * NW) * 2 + (lane >> 5);
                 const int ls = (lane & 31) ^ ((krow & 3) << 2);
                 const int gcol = n0 + ls * 8 < p.n ? ls * 8 : 0;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
             char* tA = smem + buf * STAGE + wave * 1024;
             char* tB = tA + BM * 128;
 #pragma unroll
-            for (int i = 4 * h; i < 4 * h + 4; ++i) {
+            for (int i = (CP / 2) * h; i < (CP / 2) * (h + 1); ++i) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(tA + i * (NW * 1024)), 16, offA[i], kA, 0, 0);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(tB + i * (NW * 1024)), 16, offB[i], kB, 0, 0);
             }
@@ -153,17 +159,20 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
                 });
             });
         };
-        // pinned interleave of a sub-step: one MFMA, then (first half of the sub-step) the LDS reads of one fragment,
-        // (second half) one DMA piece.  Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read.
+        // pinned interleave of a sub-step: one MFMA, then one memory instruction group.  The DMA writes LDS, so program
+        // order keeps it behind the sub-step's fragment reads: reads go to the first gaps, DMA pieces to the next ones.
+        // Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read.
         auto interleave = [&](auto rc, auto vc) {
-            constexpr int R = decltype(rc)::value;           // fragments requested in this sub-step (0 or 8)
-            constexpr int V = decltype(vc)::value;           // DMA pieces issued in this sub-step (0 or 8)
-            constexpr int RI = (TA ? 2 : 1) + (TB ? 2 : 1);  // DS instructions of one A + one B fragment ...
+            constexpr bool R = decltype(rc)::value != 0, V = decltype(vc)::value != 0;
+            constexpr int NMF = FM * FN;
+            constexpr int DSI = FM * (TA ? 2 : 1) + FN * (TB ? 2 : 1);   // DS instructions of the sub-step's fragments
+            constexpr int RG = V ? NMF / 4 : NMF / 2;                    // gaps that carry fragment reads
+            constexpr int PER = (DSI + RG - 1) / RG;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NMF; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                if (R && q < 8 && (q & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x100, RI, 0);   // ... every other gap
-                if (V && q >= 8) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+                if (R && q < RG) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+                if (V && q >= RG && q < RG + CP) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
         dma(I0{}, 0); dma(I1{}, 0);
         kA += stepA; kB += stepB;
         if (nt > 1) dma(I0{}, 1);
-        if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else wait_vm0();
+        if (nt > 1) { if (CP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else wait_vm0();
         __syncthreads();
         frags(I0{}, I0{}, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -187,23 +196,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
             constexpr bool MORE1 = decltype(m1c)::value, MORE2 = decltype(m2c)::value;
             const int buf = t & 1;
             // sub-step 0
-            PINF(af[0]); PINF(bfr[0]);
+            PINF(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
             frags(I1{}, I1{}, buf);
             if constexpr (MORE1) { dma(I1{}, buf ^ 1); kA += stepA; kB += stepB; }
             mfmas(I0{});
             if constexpr (MORE1) interleave(I8{}, I8{}); else interleave(I8{}, I0{});
             // sub-step 1
-            PINF(af[1]); PINF(bfr[1]);
+            PINF(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
             frags(I0{}, I2{}, buf);
             mfmas(I1{});
             interleave(I8{}, I0{});
             // sub-step 2
-            PINF(af[0]); PINF(bfr[0]);
+            PINF(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
             frags(I1{}, I3{}, buf);
             mfmas(I0{});
             interleave(I8{}, I0{});
             // every wave: its DMA pieces of tile t+1 have landed, its last fragments of tile t are in registers
-            PINF(af[1]); PINF(bfr[1]);
+            PINF(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
             if constexpr (MORE1) {
                 wait_vm0();
                 __builtin_amdgcn_s_barrier();
@@ -227,8 +236,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const GemmP p) {
     }
 }
 
-template <bool TA, bool TB>
-static int launch_w4(const GemmP& p0, hipStream_t s) {
+template <bool TA, bool TB, int WM, int WN>
+static int launch_wp(const GemmP& p0, hipStream_t s) {
     GemmP p = p0;
     const int tiles_m = (p.m + 255) / 256;
     p.tiles_n = (p.n + 255) / 256;
@@ -241,7 +250,7 @@ static int launch_w4(const GemmP& p0, hipStream_t s) {
     }
     int nblk = p.nwg * p.split_k;
     if (nblk > 256) nblk = 256;
-    hipLaunchKernelGGL((gemm_w4_kernel<TA, TB>), dim3(nblk), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

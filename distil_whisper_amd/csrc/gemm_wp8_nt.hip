@@ -1,0 +1,3 @@
+// gemm_wp.h: 8 waves (2 x 4), 128 x 64 per wave, row-major A, k-major B (dX = dY . W)
+#include "gemm_wp.h"
+int dw_gemm_wp8_nt_launch(const GemmP& p, hipStream_t s) { return launch_wp<false, true, 2, 4>(p, s); }

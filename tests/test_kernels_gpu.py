@@ -105,14 +105,14 @@ def test_gemm_epilogues(ops, ref, tile):
     assert relerr(c, rc) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [5])
-@pytest.mark.parametrize("ta,tb", [(False, True)])
-def test_gemm_phase_pipelined_variant_is_bit_identical(ops, ref, variant, ta, tb):
-    """gemm_phased.hip (counted-vmcnt, slot-staggered main loop, region-major LDS image) against the plain kernel:
-    same k order per accumulator, so every output bit must agree -- the dX layout it is built for (all four layouts
-    passed this test before the other three were dropped from the build), ragged M/N edges,
-    1..5 K tiles (prologue / tail wait counts), persistent job walk (> 256 tiles), fused epilogue, split-K slices,
-    repeated launches (race screen)."""
+@pytest.mark.parametrize("variant,ta,tb", [(131, False, True), (19, False, False), (35, False, True), (67, True, True)])
+def test_gemm_pipelined_variants_are_bit_identical(ops, ref, variant, ta, tb):
+    """gemm_phased.hip (variant bit 7: counted-vmcnt, slot-staggered main loop, region-major LDS image) and the 8-wave
+    software-pipelined kernels of gemm_wp.h (bits 4-6: register double-buffered fragments, pinned MFMA / LDS / DMA
+    interleave, buffer-addressed operand DMA) against the plain 16-wave kernel: same k order per accumulator, so every
+    output bit must agree -- each operand layout the kernels are built for, ragged M/N edges, 1..5 K tiles (prologue /
+    tail wait counts), persistent job walk (> 256 tiles), fused epilogue, split-K slices, repeated launches (race
+    screen)."""
     try:
         for M, N, K in ((520, 392, 64), (520, 392, 128), (304, 512, 192), (776, 1024, 320), (4096, 4608, 256),
                         (8 * 1500, 1280, 1280)):
@@ -139,7 +139,7 @@ def test_gemm_phase_pipelined_variant_is_bit_identical(ops, ref, variant, ta, tb
             ops.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32, out=got, atomic_acc=True, split_k=5)
             assert torch.equal(got, want)
     finally:
-        ops.lib.dw_debug_set(0, 7)
+        ops.lib.dw_debug_set(0, 119)
 
 
 @pytest.mark.parametrize("M", [1, 16, 17, 40, 64])

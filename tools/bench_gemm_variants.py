@@ -30,7 +30,7 @@ for name, M, N, K, ta, tb in shapes:
             d = (o.float() - ref.float()).abs().max().item()
             if d != 0.0:
                 print("MISMATCH variant", v, "rep", rep, "max abs diff", d, flush=True)
-    for rnd_i in range(5):
+    for rnd_i in range(int(os.environ.get("DW_ROUNDS", "5"))):
         for v in variants:
             ops.lib.dw_debug_set(KEY, v)
             for _ in range(2): ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out, tile=256)
@@ -41,4 +41,4 @@ for name, M, N, K, ta, tb in shapes:
             e.record(); torch.cuda.synchronize()
             res[v].append(2.0*M*N*K/(s.elapsed_time(e)/10*1e-3)/1e12)
     print(name, {v: f"med {sorted(r)[len(r)//2]:.0f} max {max(r):.0f}" for v, r in res.items()}, flush=True)
-ops.lib.dw_debug_set(0, 7)
+ops.lib.dw_debug_set(0, 119)
