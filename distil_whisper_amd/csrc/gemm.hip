@@ -132,18 +132,24 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         const bool wp_ok = spanA < 0x7fffffffL && spanB < 0x7fffffffL;
         const int v = g_gemm_variant;
         p.strip = g_gemm_strip;
-        if (!g->trans_a && !g->trans_b) {
-            // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
-            // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
-            const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
-            if ((v & 16) && wp_ok && !epi_bound) return dw_gemm_wp8_nn_launch(p, s);
-        } else if (!g->trans_a && g->trans_b) {
-            if (((v & 4) && g->k >= 3840 && p.split_k == 1) || (v & 128)) return dw_gemm_phased_launch(p, 0, 1, s);
-            if ((v & 32) && wp_ok) return dw_gemm_wp8_nt_launch(p, s);
-        } else if (g->trans_a && g->trans_b) {
-            if ((v & 64) && wp_ok) return dw_gemm_wp8_tt_launch(p, s);
-        }
-        return dw_gemm_tile256_launch(p, g->trans_a, g->trans_b, s);
+        auto launch256 = [&](const GemmP& q) -> int {
+            if (!g->trans_a && !g->trans_b) {
+                // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
+                // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
+                const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
+                if ((v & 16) && wp_ok && !epi_bound) return dw_gemm_wp8_nn_launch(q, s);
+            } else if (!g->trans_a && g->trans_b) {
+                if (((v & 4) && g->k >= 3840 && q.split_k == 1) || (v & 128)) return dw_gemm_phased_launch(q, 0, 1, s);
+                if ((v & 32) && wp_ok) return dw_gemm_wp8_nt_launch(q, s);
+            } else if (g->trans_a && g->trans_b) {
+                if ((v & 64) && wp_ok) return dw_gemm_wp8_tt_launch(q, s);
+            }
+            return dw_gemm_tile256_launch(q, g->trans_a, g->trans_b, s);
+        };
+        // (Measured and dropped: splitting the rows of a mostly empty last round off to the 128-tile kernel -- a launch
+        // costs ceil(tiles / 256) tile times, 940 tiles pay for 1024 -- made the step 8 ms SLOWER (444 -> 452 ms): the
+        // second launch cannot start before the slowest workgroup of the first one has drained.)
+        return launch256(p);
     }
     return dw_gemm_tile128_launch(p, g->trans_a, g->trans_b, s);
 }

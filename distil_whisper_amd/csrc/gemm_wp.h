@@ -35,6 +35,7 @@
 template <bool TA, bool TB, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(const GemmP p) {
     constexpr int BM = 256, BN = 256, NW = WM * WN, FM = BM / WM / 32, FN = BN / WN / 32, TN = BN / WN;
+    static_assert(NW * 32 * (TN + 4) * 4 <= 2 * (BM + BN) * 128, "epilogue patches must fit the operand buffers");
     constexpr int CP = 32 / NW;                       // DMA pieces (1 KiB) per wave per operand per K tile
     constexpr int STAGE = (BM + BN) * 128;            // one K tile: A [256][64] | B [256][64] (or their k-major images)
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
@@ -196,23 +197,23 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             constexpr bool MORE1 = decltype(m1c)::value, MORE2 = decltype(m2c)::value;
             const int buf = t & 1;
             // sub-step 0
-            PINF(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
+            if constexpr (FM == 4) PINF(af[0]); else PINF2(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
             frags(I1{}, I1{}, buf);
             if constexpr (MORE1) { dma(I1{}, buf ^ 1); kA += stepA; kB += stepB; }
             mfmas(I0{});
             if constexpr (MORE1) interleave(I8{}, I8{}); else interleave(I8{}, I0{});
             // sub-step 1
-            PINF(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
+            if constexpr (FM == 4) PINF(af[1]); else PINF2(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
             frags(I0{}, I2{}, buf);
             mfmas(I1{});
             interleave(I8{}, I0{});
             // sub-step 2
-            PINF(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
+            if constexpr (FM == 4) PINF(af[0]); else PINF2(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
             frags(I1{}, I3{}, buf);
             mfmas(I0{});
             interleave(I8{}, I0{});
             // every wave: its DMA pieces of tile t+1 have landed, its last fragments of tile t are in registers
-            PINF(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
+            if constexpr (FM == 4) PINF(af[1]); else PINF2(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
             if constexpr (MORE1) {
                 wait_vm0();
                 __builtin_amdgcn_s_barrier();

@@ -208,7 +208,8 @@ class HipOps:
         g.trans_a, g.trans_b = int(trans_a), int(trans_b)
         g.act = int(act)
         g.c_dtype = _dt(out)
-        g.tile = int(tile) if tile else (0 if M <= 64 else self.pick_tile(M, N))  # 0: library's choice (skinny-M)
+        g.tile = int(tile) if tile else 0      # 0: the library's choice (skinny-M kernel, tile rule, tail split)
+        tile_key = g.tile if tile or M <= 64 else self.pick_tile(M, N)
         ws = None
         if atomic_acc:
             # out (fp32, contiguous) += A^T.B : weight-gradient form.  Few output tiles and a very long K: cut K into
@@ -217,7 +218,7 @@ class HipOps:
             # slower beyond 2 slices).  A single slice accumulates directly with atomics.
             assert out.dtype == torch.float32 and bias is None and residual is None and not want_z and zgrad is None
             if not tile:
-                g.tile = 256
+                g.tile = tile_key = 256
             tiles = ((M + g.tile - 1) // g.tile) * ((N + g.tile - 1) // g.tile)
             nt = K // 64
             if split_k:
@@ -257,7 +258,7 @@ class HipOps:
         if ws is not None:
             self._chk(self.lib.dw_reduce_slices(ws.data_ptr(), M * N, g.split_k, out.data_ptr(), M * N, 1,
                                                 self._stream()), "reduce_slices")
-        key = f"gemm_t{g.tile}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}"
+        key = f"gemm_t{tile_key}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}"
         if self.profile_detail:
             key += (f" m{M} n{N} k{K} c{'f32' if out.dtype == torch.float32 else 'bf16'}"
                     f"{' bias' if bias is not None else ''}{' act%d' % act if act else ''}{' z' if want_z else ''}"

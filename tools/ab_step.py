@@ -20,12 +20,12 @@ def step():
     return tr.train_step(tr.features(audio), dec_in, labels)
 # (GEMM variant, strip[, attention-backward mode]); variant 3 = default, 4 = phase-pipelined kernel; strip 0 = auto rule;
 # attention mode = dw_debug_set key 3 (default 1)
-configs = eval(os.environ.get("DW_AB", "[(3,0,1),(7,0,5)]"))
+configs = eval(os.environ.get("DW_AB", "[(7,0,5),(119,0,5)]"))
 step(); torch.cuda.synchronize()
 res = {c: [] for c in configs}
 for r in range(4):
     for c in configs:
-        ops.lib.dw_debug_set(0, c[0]); ops.lib.dw_debug_set(1, c[1]); ops.lib.dw_debug_set(3, c[2] if len(c) > 2 else 1)
+        ops.lib.dw_debug_set(0, c[0]); ops.lib.dw_debug_set(1, c[1]); ops.lib.dw_debug_set(3, c[2] if len(c) > 2 else 5)
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(2): step()
