@@ -148,3 +148,88 @@ extern "C" int dw_greedy_select(const void* logits, int B, int V, int64_t ld, co
     DW_CHECK_LAUNCH();
     return DW_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One decoder pass of cached greedy decoding as ONE C call: every launch of `WhisperDecoder.forward` on the cache
+// branch (TF:modeling_whisper.py:690-795 with 312-335; reached from `generate`, run_eval.py:739,
+// run_distillation.py:1524-1528, run_pseudo_labelling.py:861-996) is enqueued on the caller's stream: embedding,
+// per layer LayerNorm -> fused QKV GEMM -> K/V appended to the cache in place -> self-attention over the cached prefix
+// -> out-proj + residual -> LayerNorm -> Q GEMM -> cross-attention over the static encoder K/V -> out-proj + residual
+// -> LayerNorm -> FC1 + GELU -> FC2 + residual, then the final LayerNorm and the tied LM head.  n_new = 1 is the
+// token step (skinny weight-streaming GEMMs, streaming single-query attention); n_new > 1 scores several new
+// positions against the cache with the bottom-right aligned causal mask (prompt prefill, the verify pass of assisted
+// decoding).  Nothing is allocated; no host synchronisation: the call can be captured into a HIP graph.
+
+__global__ __launch_bounds__(256) void kv_append_kernel(const bf16* qkv, bf16* cache, int n_new, int t, int max_len,
+                                                         int D, long nvec) {
+    // cache[b][t + j][0 .. 2D) = qkv[b * n_new + j][D .. 3D)   (8 bf16 per thread)
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const int per_row = (2 * D) >> 3;
+    const long row = i / per_row;
+    const int c = (int)(i - row * per_row) << 3;
+    const long b = row / n_new;
+    const int j = (int)(row - b * n_new);
+    *(bf16x8*)(cache + ((b * max_len + t + j) * 2L * D) + c) = *(const bf16x8*)(qkv + row * 3L * D + D + c);
+}
+
+extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
+    DW_CLEAR_ERR();
+    if (!d || !d->ids || !d->tok_emb || !d->pos_emb || !d->layers || !d->lm_head || !d->x || !d->h || !d->qkv || !d->o ||
+        !d->a || !d->logits)
+        return DW_EINVAL;
+    const int B = d->batch, n = d->n_new, D = d->d_model, H = d->heads, F = d->ffn, t = d->t;
+    if (B <= 0 || n <= 0 || D != H * 64 || (D & 63) || (F & 63) || d->n_layers <= 0 || d->src_len <= 0 || t < 0 ||
+        t + n > d->max_len || d->ldv < d->vocab || (d->ldv & 15))
+        return DW_EINVAL;
+    if (d->stream_dtype != DW_F32 && d->stream_dtype != DW_BF16) return DW_EINVAL;
+    const int rows = B * n;
+    const size_t es = d->stream_dtype == DW_F32 ? 4 : 2;
+    int rc = dw_embed_fwd(d->ids, d->tok_emb, (const char*)d->pos_emb + (size_t)t * D * es, d->stream_dtype, d->x,
+                          d->stream_dtype, B, n, D, stream);
+    if (rc != DW_OK) return rc;
+    auto gemm = [&](const void* a, long lda, const void* w, const float* bias, int N, int K, void* c, long ldc, int c_dtype,
+                    int act, const void* r) -> int {
+        DwGemm g = {};
+        g.a = a; g.b = w; g.c = c; g.bias = bias; g.r = r;
+        g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldc;
+        g.m = rows; g.n = N; g.k = K;
+        g.act = act; g.c_dtype = c_dtype; g.r_dtype = c_dtype; g.round_res = 1;
+        return dw_gemm_bf16(&g, stream);
+    };
+    for (int l = 0; l < d->n_layers; ++l) {
+        const DwDecoderLayer& L = d->layers[l];
+        if (!L.wqkv || !L.wo || !L.wq || !L.wo2 || !L.w1 || !L.w2 || !L.self_kv || !L.cross_kv) return DW_EINVAL;
+        // ---- self-attention over the cached prefix ----
+        if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, L.ln1_g, L.ln1_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
+                                   stream)) != DW_OK) return rc;
+        if ((rc = gemm(d->h, D, L.wqkv, L.bqkv, 3 * D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr)) != DW_OK) return rc;
+        {
+            const long nvec = (long)rows * ((2 * D) >> 3);
+            hipLaunchKernelGGL(kv_append_kernel, dim3((nvec + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16*)d->qkv, (bf16*)L.self_kv, n, t, d->max_len, D, nvec);
+            DW_CHECK_LAUNCH();
+        }
+        const bf16* kc = (const bf16*)L.self_kv;
+        if ((rc = dw_attn_fwd_ex(d->qkv, kc, kc + D, d->o, nullptr, B, H, n, t + n, 3 * D, 2 * D, 2 * D, D, n, d->max_len,
+                                 n > 1 ? 2 : 0, 0.125f, stream)) != DW_OK) return rc;
+        if ((rc = gemm(d->o, D, L.wo, L.bo, D, D, d->x, D, d->stream_dtype, 0, d->x)) != DW_OK) return rc;
+        // ---- cross-attention over the static encoder K/V ----
+        if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, L.ln2_g, L.ln2_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
+                                   stream)) != DW_OK) return rc;
+        if ((rc = gemm(d->h, D, L.wq, L.bq, D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr)) != DW_OK) return rc;
+        const bf16* kx = (const bf16*)L.cross_kv;
+        if ((rc = dw_attn_fwd_ex(d->qkv, kx, kx + D, d->o, nullptr, B, H, n, d->src_len, 3 * D, 2 * D, 2 * D, D, n,
+                                 d->src_len, 0, 0.125f, stream)) != DW_OK) return rc;
+        if ((rc = gemm(d->o, D, L.wo2, L.bo2, D, D, d->x, D, d->stream_dtype, 0, d->x)) != DW_OK) return rc;
+        // ---- feed-forward ----
+        if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, L.ln3_g, L.ln3_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
+                                   stream)) != DW_OK) return rc;
+        if ((rc = gemm(d->h, D, L.w1, L.b1, F, D, d->a, F, DW_BF16, 1, nullptr)) != DW_OK) return rc;
+        if ((rc = gemm(d->a, F, L.w2, L.b2, D, F, d->x, D, d->stream_dtype, 0, d->x)) != DW_OK) return rc;
+    }
+    if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, d->lnf_g, d->lnf_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
+                               stream)) != DW_OK) return rc;
+    return gemm(d->h, D, d->lm_head, nullptr, d->ldv, D, d->logits, d->ldv, DW_BF16, 0, nullptr);
+}

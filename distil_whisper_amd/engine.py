@@ -13,6 +13,8 @@ No autograd, no nn.Module here: modeling.py wraps this engine behind the referen
 """
 from dataclasses import dataclass
 
+import ctypes as C
+
 import torch
 
 
@@ -391,12 +393,72 @@ class WhisperEngine:
             cache["cross"][i] = ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=cache["cross"][i])
         return cache
 
+    # ---- single-call decoder pass (C entry dw_decode_step) ---------------------------------------------------------
+    use_c_decode = True     # HIP path: one library call per decoder pass instead of ~30 per-kernel calls
+
+    def _decode_desc(self, cache, n):
+        """DwDecodeStep for `n` new positions per row over `cache` (built once per (cache, n): weights, caches and the
+        workspace it points at are owned by this engine / the cache dict and stay alive with them)."""
+        key = ("desc", n)
+        if key in cache:
+            return cache[key]
+        from .ops_hip import DwDecodeStep, DwDecoderLayer, DW_BF16, DW_F32
+        ops, st, d = self.ops, self.st, self.dims
+        B, D, F = cache["B"], d.d_model, d.ffn
+        rows = B * n
+        f32 = self.stream == torch.float32
+        tab = st.p if f32 else st.s
+        ws = {"x": ops.empty((rows, D), self.stream), "h": ops.empty((rows, D), self.lowp),
+              "qkv": ops.empty((rows, 3 * D), self.lowp), "o": ops.empty((rows, D), self.lowp),
+              "a": ops.empty((rows, F), self.lowp), "logits": ops.empty((rows, self.ldv), self.lowp)}
+        layers = (DwDecoderLayer * d.dec_layers)()
+        keep = [ws]
+        for i in range(d.dec_layers):
+            p = f"model.decoder.layers.{i}"
+            av, cv = st.attn_views(f"{p}.self_attn"), st.attn_views(f"{p}.encoder_attn")
+            L = layers[i]
+            L.ln1_g, L.ln1_b = st.p[f"{p}.self_attn_layer_norm.weight"].data_ptr(), st.p[f"{p}.self_attn_layer_norm.bias"].data_ptr()
+            L.wqkv, L.bqkv = av["wqkv"].data_ptr(), av["bqkv"].data_ptr()
+            L.wo, L.bo = av["wo"].data_ptr(), av["bo"].data_ptr()
+            L.ln2_g, L.ln2_b = st.p[f"{p}.encoder_attn_layer_norm.weight"].data_ptr(), st.p[f"{p}.encoder_attn_layer_norm.bias"].data_ptr()
+            L.wq, L.bq = cv["wqkv"][:D].data_ptr(), cv["bqkv"][:D].data_ptr()
+            L.wo2, L.bo2 = cv["wo"].data_ptr(), cv["bo"].data_ptr()
+            L.ln3_g, L.ln3_b = st.p[f"{p}.final_layer_norm.weight"].data_ptr(), st.p[f"{p}.final_layer_norm.bias"].data_ptr()
+            L.w1, L.b1 = st.s[f"{p}.fc1.weight"].data_ptr(), st.p[f"{p}.fc1.bias"].data_ptr()
+            L.w2, L.b2 = st.s[f"{p}.fc2.weight"].data_ptr(), st.p[f"{p}.fc2.bias"].data_ptr()
+            L.self_kv, L.cross_kv = cache["self"][i].data_ptr(), cache["cross"][i].data_ptr()
+            keep += [av, cv]
+        eo = st.entries["model.decoder.embed_tokens.weight"][0]
+        desc = DwDecodeStep()
+        desc.batch, desc.n_new, desc.d_model, desc.heads, desc.ffn, desc.n_layers = B, n, D, d.heads, F, d.dec_layers
+        desc.src_len, desc.max_len, desc.vocab, desc.ldv = d.max_src, cache["max_len"], d.vocab, self.ldv
+        desc.stream_dtype = DW_F32 if f32 else DW_BF16
+        desc.tok_emb = tab["model.decoder.embed_tokens.weight"].data_ptr()
+        desc.pos_emb = tab["model.decoder.embed_positions.weight"].data_ptr()
+        desc.lnf_g, desc.lnf_b = st.p["model.decoder.layer_norm.weight"].data_ptr(), st.p["model.decoder.layer_norm.bias"].data_ptr()
+        desc.lm_head = st.S[eo:eo + self.ldv * D].data_ptr()
+        desc.layers = C.cast(layers, C.c_void_p)
+        for k, v in ws.items():
+            setattr(desc, k, v.data_ptr())
+        cache[key] = (desc, ws, layers, keep)
+        return cache[key]
+
+    def _decode_pass_c(self, ids, cache, n):
+        desc, ws, _, _ = self._decode_desc(cache, n)
+        ids = ids.contiguous()
+        desc.ids, desc.t = ids.data_ptr(), cache["t"]
+        self.ops.decode_pass(desc)
+        cache["t"] += n
+        return ws["logits"]     # (workspace of the cache: valid until the next pass with the same n)
+
     def decode_step(self, ids_t, cache):
         """One greedy-decoding step: ids_t int64 [B, 1] at position cache["t"] -> logits low-precision [B, ldv]."""
         ops, st, d = self.ops, self.st, self.dims
         B, t, ML = cache["B"], cache["t"], cache["max_len"]
         D, H, Lk = d.d_model, d.heads, d.max_src
         assert ids_t.shape == (B, 1) and t < ML and t < d.max_tgt
+        if self.use_c_decode and hasattr(ops, "decode_pass"):
+            return self._decode_pass_c(ids_t, cache, 1)
         f32 = self.stream == torch.float32
         tok = (st.p if f32 else st.s)["model.decoder.embed_tokens.weight"]
         pos = (st.p if f32 else st.s)["model.decoder.embed_positions.weight"][t:t + 1]
@@ -442,6 +504,8 @@ class WhisperEngine:
         n = ids.shape[1]
         D, H, Lk = d.d_model, d.heads, d.max_src
         assert ids.shape[0] == B and t + n <= ML and t + n <= d.max_tgt
+        if self.use_c_decode and hasattr(ops, "decode_pass"):
+            return self._decode_pass_c(ids, cache, n)
         f32 = self.stream == torch.float32
         tok = (st.p if f32 else st.s)["model.decoder.embed_tokens.weight"]
         pos = (st.p if f32 else st.s)["model.decoder.embed_positions.weight"][t:t + n]

@@ -30,8 +30,22 @@ class DwGemm(C.Structure):
     ]
 
 
+class DwDecoderLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_g", "ln1_b", "wqkv", "bqkv", "wo", "bo", "ln2_g", "ln2_b", "wq", "bq", "wo2", "bo2", "ln3_g", "ln3_b",
+        "w1", "b1", "w2", "b2", "self_kv", "cross_kv")]
+
+
+class DwDecodeStep(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "n_new", "d_model", "heads", "ffn", "n_layers", "src_len", "max_len", "t", "vocab", "ldv",
+        "stream_dtype")] + [(n, C.c_void_p) for n in (
+            "ids", "tok_emb", "pos_emb", "lnf_g", "lnf_b", "lm_head", "layers", "x", "h", "qkv", "o", "a", "logits")]
+
+
 _SIGS = {
     "dw_version": ([], C.c_int),
+    "dw_decode_step": ([C.POINTER(DwDecodeStep), C.c_void_p], C.c_int),
     "dw_logmel": ([C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                    C.c_void_p], C.c_int),
     "dw_gemm_bf16": ([C.POINTER(DwGemm), C.c_void_p], C.c_int),
@@ -267,6 +281,13 @@ class HipOps:
                     f"{' sk%d' % g.split_k if g.split_k else ''}")
         self._t1(e0, key, 2.0 * M * N * K)
         return (out, z) if want_z else out
+
+    def decode_pass(self, desc):
+        """One decoder pass of cached greedy decoding through the single C entry point dw_decode_step (every launch of
+        the pass enqueued by the library; `desc` is a DwDecodeStep whose buffers the caller keeps alive)."""
+        e0 = self._t0()
+        self._chk(self.lib.dw_decode_step(C.byref(desc), self._stream()), "decode_step")
+        self._t1(e0, "decode_step", 0.0)
 
     def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):
         rows, cols = x.shape

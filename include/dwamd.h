@@ -180,6 +180,45 @@ int dw_greedy_select(const void* logits, int B, int V, int64_t ld, const uint8_t
                      int64_t* tokens, int64_t tok_ld, int n, int begin_index, int eos, int fill, uint8_t* done,
                      int64_t* cur, void* stream);
 
+/* ---- a11: one decoder pass of cached greedy decoding as ONE call (the `decode_step` entry of SURVEY.md 8b).
+ * Replaces `WhisperDecoder.forward` + `proj_out` on the cache branch (TF:modeling_whisper.py:690-795, 312-335, 1080)
+ * as reached from `generate` (run_eval.py:739, run_distillation.py:1524-1528, run_pseudo_labelling.py:861-996).
+ * Every launch of the pass is enqueued on `stream`; nothing is allocated, nothing synchronises (HIP-graph capturable).
+ * All matrices bf16 in nn.Linear layout [out][in]; biases and LayerNorm parameters f32; q scaling 0.125 is applied
+ * inside attention.  The caller owns every buffer (weights, caches, workspace). */
+typedef struct DwDecoderLayer {
+    const float *ln1_g, *ln1_b;  /* self_attn_layer_norm */
+    const void* wqkv;            /* [3D][D]: q_proj | k_proj | v_proj weights stacked */
+    const float* bqkv;           /* [3D] (the k part is zero: k_proj has no bias) */
+    const void* wo;  const float* bo;    /* self_attn.out_proj */
+    const float *ln2_g, *ln2_b;  /* encoder_attn_layer_norm */
+    const void* wq;  const float* bq;    /* encoder_attn.q_proj */
+    const void* wo2; const float* bo2;   /* encoder_attn.out_proj */
+    const float *ln3_g, *ln3_b;  /* final_layer_norm */
+    const void* w1;  const float* b1;    /* fc1 [ffn][D] */
+    const void* w2;  const float* b2;    /* fc2 [D][ffn] */
+    void* self_kv;               /* bf16 [batch][max_len][2D]: K | V of the generated prefix, appended in place */
+    const void* cross_kv;        /* bf16 [batch*src_len][2D]: K | V of the encoder states (projected once per batch) */
+} DwDecoderLayer;
+typedef struct DwDecodeStep {
+    int32_t batch, n_new;        /* n_new new positions per sequence (1 = token step; > 1 = prefill / verify pass) */
+    int32_t d_model, heads, ffn, n_layers;
+    int32_t src_len, max_len;    /* encoder positions (1500); capacity of the self-attention cache */
+    int32_t t;                   /* position of the first new token = number of cached positions */
+    int32_t vocab, ldv;          /* LM-head rows used / padded (multiple of 16) = row pitch of logits */
+    int32_t stream_dtype;        /* residual stream and embedding tables: DW_F32 (autocast student) or DW_BF16 */
+    const int64_t* ids;          /* [batch][n_new] */
+    const void* tok_emb;         /* [vocab..][D] */
+    const void* pos_emb;         /* [max_target_positions][D] (row t .. t+n_new-1 are used) */
+    const float *lnf_g, *lnf_b;  /* decoder.layer_norm */
+    const void* lm_head;         /* bf16 [ldv][D] (tied embedding, zero-padded rows) */
+    const DwDecoderLayer* layers;
+    void *x, *h, *qkv, *o, *a;   /* workspace, rows = batch*n_new: x [rows][D] stream dtype; h, o [rows][D], qkv
+                                    [rows][3D], a [rows][ffn] bf16 */
+    void* logits;                /* out: bf16 [rows][ldv] */
+} DwDecodeStep;
+int dw_decode_step(const DwDecodeStep* d, void* stream);
+
 /* ---- self tests (diagnostics for bring-up; not on the hot path) --------------------------------------------------
  * Runs ds_read_b64_tr_b16 on a known LDS image: out int32 [64][4] = element ids received by each lane. */
 int dw_selftest_tr16(int32_t* out, void* stream);

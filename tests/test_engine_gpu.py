@@ -272,3 +272,43 @@ def test_device_resident_input_pipeline(ops):
     feats = tr.features(audio)
     losses = tr.train_step(feats, out["decoder_input_ids"], out["labels"])
     assert feats.is_cuda and torch.isfinite(losses).all() and losses[3].item() == float((labels != -100).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decode_step_c_entry_equals_per_kernel_path(ops, dtype):
+    """dw_decode_step (ONE library call per decoder pass: include/dwamd.h) against the same pass issued kernel by kernel
+    from Python: same kernels in the same order on the same buffers' contents, so logits and caches must agree bit for
+    bit -- token steps (n_new = 1), a multi-token pass against the cache (prefill / verify, bottom-right causal mask),
+    fp32 (autocast student) and bf16 (teacher) residual streams; then generate() end to end through the entry."""
+    from distil_whisper_amd.modeling import WhisperForConditionalGeneration
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 81)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 2)
+    model = WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd, dtype=dtype)
+    eng = model.engine
+    model._sync_shadow()
+    g = torch.Generator().manual_seed(5)
+    feats = (torch.randn(3, cfg_s.n_mels, 3000, generator=g) * 0.5).cuda()
+    enc, _ = eng.encode(feats, save=False)
+    ids = torch.randint(0, cfg_s.vocab, (3, 6), generator=g).cuda()
+    out = {}
+    for use_c in (False, True):
+        eng.use_c_decode = use_c
+        cache = eng.decode_init(enc, 3, 16)
+        logits = [eng.decode_multi(ids[:, :3], cache).clone()]
+        for j in range(3, 6):
+            logits.append(eng.decode_step(ids[:, j:j + 1], cache).clone())
+        out[use_c] = (logits, [c.clone() for c in cache["self"]], cache["t"])
+    eng.use_c_decode = True
+    assert out[True][2] == out[False][2] == 6
+    for a, b in zip(out[True][0], out[False][0]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    for a, b in zip(out[True][1], out[False][1]):
+        assert torch.equal(a, b)
+    kw = dict(max_new_tokens=9, suppress_tokens=[3, 4])
+    a = _seq(model, feats, use_cache=True, use_graphs=True, **kw)
+    eng.use_c_decode = False
+    b = _seq(model, feats, use_cache=True, use_graphs=False, **kw)
+    eng.use_c_decode = True
+    assert torch.equal(a, b)
