@@ -42,6 +42,7 @@ int g_gemm_persistent = 1;
 // Every kernel produces bit-identical results (same fp32 chain over k per output element): tests/test_kernels_gpu.py.
 static int g_gemm_variant = 119;
 int g_gemm_strip = 0;
+int g_gemm_strip_budget = 8;   // x 512 KiB of L2 for the resident strip of B tiles
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
     if (key == 1) { g_gemm_strip = value; return DW_OK; }
@@ -49,6 +50,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 3) { g_attn_bwd_stage = value; return DW_OK; }
     if (key == 4) { g_attn_decode = value; return DW_OK; }
     if (key == 5) { g_logmel_mfma = value; return DW_OK; }
+    if (key == 6) { g_gemm_strip_budget = value; return DW_OK; }
     return DW_EINVAL;
 }
 

@@ -67,6 +67,18 @@ __device__ __forceinline__ void gemm_job_decode(const GemmP& p, int id, int& tm,
     tn = strip * sw + (within - tm * width);
 }
 
+// Rasterisation strip width (in 256-wide column tiles) for the persistent 256x256 kernels: as many B tiles as fit a
+// budget of the XCD's 4 MiB L2 (g_gemm_strip_budget, units of 512 KiB), the whole row when fewer than 2 fit or the row is
+// not wider than that.  `override` > 0 (dw_debug_set key 1) forces a width.
+extern int g_gemm_strip_budget;
+inline int gemm_strip_width(int k, int tiles_n, int override_) {
+    if (override_ > 0) return override_;
+    const long tile_bytes = 256L * k * 2;
+    int sw = (int)(((long)g_gemm_strip_budget << 19) / tile_bytes);
+    if (sw < 2 || sw >= tiles_n) sw = tiles_n;
+    return sw;
+}
+
 // transposed (k-major) tile [64][BX]: fragment X^T[i = x + ...][k-slots] for one 16-deep k step
 template <int BX>
 __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, int lane) {

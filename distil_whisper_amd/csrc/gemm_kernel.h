@@ -213,14 +213,7 @@ static int launch_tile(const GemmP& p0, int ta, int tb, hipStream_t s) {
     const int tiles_m = (p.m + BM - 1) / BM;
     p.tiles_n = (p.n + BN - 1) / BN;
     p.nwg = tiles_m * p.tiles_n;
-    {
-        // strip width: as many B tiles as fit ~4 MB (6 at K = 1280: measured best in the step, 452 vs 455 ms for 4
-        // and 462 for 2); row-major when fewer than 3 fit
-        const long tile_bytes = (long)BN * p.k * 2;
-        int sw = (int)((4L << 20) / tile_bytes);
-        if (sw < 3 || sw >= p.tiles_n) sw = p.tiles_n;
-        p.strip = g_gemm_strip > 0 ? g_gemm_strip : sw;
-    }
+    p.strip = gemm_strip_width(p.k, p.tiles_n, g_gemm_strip);
     // persistent launch for the 256-tile (one workgroup per CU, 256 CUs): only when there are more jobs than CUs
     int nblk = p.nwg * p.split_k;
     if (BM == 256 && nblk > 256 && g_gemm_persistent) nblk = 256;

@@ -256,12 +256,7 @@ int dw_gemm_phased_launch(const GemmP& p0, int ta, int tb, hipStream_t s) {
     const int tiles_m = (p.m + 255) / 256;
     p.tiles_n = (p.n + 255) / 256;
     p.nwg = tiles_m * p.tiles_n;
-    {
-        const long tile_bytes = 256L * p.k * 2;
-        int sw = (int)((4L << 20) / tile_bytes);
-        if (sw < 3 || sw >= p.tiles_n) sw = p.tiles_n;
-        p.strip = p.strip > 0 ? p.strip : sw;
-    }
+    p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
     if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL((gemm_phased_kernel<false, true, 0, 1>), dim3(nblk), dim3(512), 0, s, p);

@@ -243,12 +243,7 @@ static int launch_wp(const GemmP& p0, hipStream_t s) {
     const int tiles_m = (p.m + 255) / 256;
     p.tiles_n = (p.n + 255) / 256;
     p.nwg = tiles_m * p.tiles_n;
-    {
-        const long tile_bytes = 256L * p.k * 2;
-        int sw = (int)((4L << 20) / tile_bytes);
-        if (sw < 3 || sw >= p.tiles_n) sw = p.tiles_n;
-        p.strip = p.strip > 0 ? p.strip : sw;
-    }
+    p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
     if (nblk > 256) nblk = 256;
     hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
