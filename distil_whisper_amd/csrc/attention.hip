@@ -177,7 +177,11 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 // wave partials meet through shuffles and LDS.  All (batch, head) workgroups are resident at once (320 for the
 // long-form batch of 16), unlike the 128-query tile kernel which would run 1.25 rounds of mostly idle tiles.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW>
+// PRE: every lane requests ALL its K and V chunks at kernel entry (Lk <= NW * 8 * 12 keys: 12 + 12 16-byte loads per
+// lane, 96 registers), so the whole K/V stream of the (batch, head) pair is in flight at once and the two passes run out
+// of registers -- the same idea as the weight-streaming GEMV; without it the second pass (V) cannot start its loads
+// before the maximum of the first pass is known.
+template <int NW, bool PRE>
 __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];   // [Lk scores | NW x 64 partial outputs | NW | NW]
     const int lane = threadIdx.x & 63;
@@ -198,8 +202,39 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qv[e] = bf2f(q8[e]) * c;
     }
+    constexpr int NIT = 12;
+    bf16x8 kr[PRE ? NIT : 1], vr[PRE ? NIT : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int k = wave * 8 + it * (NW * 8) + sub;
+            k = k < p.Lk ? k : p.Lk - 1;
+            kr[it] = *(const bf16x8*)(K + (long)k * p.ldk);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int k = wave * 8 + it * (NW * 8) + sub;
+            k = k < p.Lk ? k : p.Lk - 1;
+            vr[it] = *(const bf16x8*)(V + (long)k * p.ldv);
+        }
+    }
     // ---- pass 1: scores (in log2 units) and their maximum ----
     float mx = NEG_BIG;
+    float sreg[PRE ? NIT : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = wave * 8 + it * (NW * 8) + sub;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qv[e], bf2f(kr[it][e]), s);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            sreg[it] = s;
+            if (k < p.Lk) mx = fmaxf(mx, s);
+        }
+    } else {
     for (int k0 = wave * 8; k0 < p.Lk; k0 += NW * 8) {
         const int k = k0 + sub;
         float s = 0.f;
@@ -216,6 +251,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
             mx = fmaxf(mx, s);
         }
     }
+    }
     mx = wave_max(mx);
     if (lane == 0) redm[wave] = mx;
     __syncthreads();
@@ -225,6 +261,19 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
     // ---- pass 2: probabilities, normaliser and the weighted sum of V ----
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float l = 0.f;
+    if constexpr (PRE) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = wave * 8 + it * (NW * 8) + sub;
+            if (k < p.Lk) {
+                const float pv = __builtin_amdgcn_exp2f(sreg[it] - mx);
+                l += pv;
+                const float pb = round_bf16(pv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaf(pb, bf2f(vr[it][e]), o[e]);
+            }
+        }
+    } else {
     for (int k0 = wave * 8; k0 < p.Lk; k0 += NW * 8) {
         const int k = k0 + sub;
         if (k < p.Lk) {
@@ -235,6 +284,7 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = fmaf(pb, bf2f(v8[e]), o[e]);
         }
+    }
     }
     // the 8 lanes of a key group hold the same l contribution: count it once (lane & 7 == 0), then reduce
     l = (lane & 7) == 0 ? l : 0.f;
@@ -535,8 +585,10 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     if (Lq == 1 && g_attn_decode && Lk <= 8192) {
         // one query per (batch, head): the streaming decode kernel (the causal mask is void for a single last query)
         const size_t smem = (((size_t)Lk + 3) & ~(size_t)3) * 4 + 16 * 64 * 4 + 2 * 16 * 4;
-        if (Lk >= 512) hipLaunchKernelGGL(attn_decode_kernel<16>, dim3(1, H, B), dim3(1024), smem, s, p);
-        else hipLaunchKernelGGL(attn_decode_kernel<4>, dim3(1, H, B), dim3(256), smem, s, p);
+        if (Lk >= 512 && Lk <= 16 * 8 * 12 && (g_attn_decode & 2))   // (measured slower: 111 registers -> one workgroup per CU)
+            hipLaunchKernelGGL((attn_decode_kernel<16, true>), dim3(1, H, B), dim3(1024), smem, s, p);
+        else if (Lk >= 512) hipLaunchKernelGGL((attn_decode_kernel<16, false>), dim3(1, H, B), dim3(1024), smem, s, p);
+        else hipLaunchKernelGGL((attn_decode_kernel<4, false>), dim3(1, H, B), dim3(256), smem, s, p);
         DW_CHECK_LAUNCH();
         return DW_OK;
     }

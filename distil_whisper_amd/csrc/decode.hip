@@ -16,6 +16,8 @@
 #include "common.h"
 #include "../../include/dwamd.h"
 
+int g_decode_fuse_off = 0;   // dw_debug_set key 7 (A/B): bit 0 LayerNorm-on-load off, bit 1 K/V append fusion off
+
 #define SEL_NT 1024
 
 struct Best { float v; int i; };
@@ -74,35 +76,96 @@ __global__ __launch_bounds__(SEL_NT) void greedy_select_kernel(
             ts_last = (last_ts && !pen_ts) ? last_val : last_val + 1;
         }
     }
-    auto allowed = [&](int c) -> bool {
+    // Every rule is a predicate on the column alone once the row state is known: two allowed id intervals (text /
+    // special ids below the first timestamp, timestamp ids), two single banned ids, and the byte masks.
+    int tlo = 0, thi = ts_mode ? tsb : V, slo = V, shi = V;       // allowed: [tlo, thi) and [slo, shi)
+    const int ban_eos = no_eos ? eos : -1, ban_nots = ts_mode ? tsb - 1 : -1;
+    if (ts_mode) {
+        if (L >= 1) {
+            if (last_ts && pen_ts) { slo = shi = V; }                           // after a closed pair: text only
+            else {
+                slo = any_ts ? max(tsb, ts_last) : tsb;                          // timestamps never decrease
+                if (last_ts) tlo = eos;                                         // after text + timestamp: timestamp / EOS
+            }
+        } else {
+            tlo = thi = 0;                                                      // the first sampled token is a timestamp
+            slo = tsb;
+            shi = max_initial >= 0 ? min(V, tsb + max_initial + 1) : V;
+        }
+    }
+    auto allowed = [&](int c) -> bool {               // (used by the probability-mass pass below)
         if (suppress && suppress[c]) return false;
         if (first && begin_suppress && begin_suppress[c]) return false;
-        if (no_eos && c == eos) return false;
-        if (ts_mode) {
-            if (c == tsb - 1) return false;                                  // <|notimestamps|> is never sampled
-            if (L >= 1) {
-                if (last_ts && pen_ts && c >= tsb) return false;             // after a closed pair: text only
-                if (last_ts && !pen_ts && c < eos) return false;             // after text + timestamp: timestamp / EOS
-                if (any_ts && c >= tsb && c < ts_last) return false;         // timestamps never decrease
-            } else {
-                if (c < tsb) return false;                                   // the first sampled token is a timestamp
-                if (max_initial >= 0 && c > tsb + max_initial) return false;
-            }
-        }
-        return true;
+        return ((c >= tlo && c < thi) || (c >= slo && c < shi)) && c != ban_eos && c != ban_nots;
     };
     // ---- pass 1: best allowed text token and best allowed timestamp token ----
+    // (the byte masks are fetched four columns at a time; the next chunk is requested before the current one is judged)
+    const bool word_masks = (((uintptr_t)suppress | (uintptr_t)begin_suppress) & 3) == 0;
     Best bt = {-INFINITY, 0x7fffffff}, bs = {-INFINITY, 0x7fffffff};
-    for (int c0 = tid * 4; c0 < V; c0 += SEL_NT * 4) {
-        const bf16x4 x = *(const bf16x4*)(row + c0);                          // (ld is a multiple of 4; pad columns are never used)
+    auto masks_of = [&](int c0) -> unsigned {          // byte e != 0: column c0 + e is suppressed
+        unsigned mask = 0;
+        if (word_masks && c0 + 3 < V) {                 // (uniform except in the last chunk of a row)
+            if (suppress) mask |= *(const unsigned*)(suppress + c0);
+            if (first && begin_suppress) mask |= *(const unsigned*)(begin_suppress + c0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < V && ((suppress && suppress[c0 + e]) || (first && begin_suppress && begin_suppress[c0 + e])))
+                    mask |= 0xffu << (8 * e);
+        }
+        return mask;
+    };
+    // A row lives on ONE CU (one workgroup), so the kernel is bound by instructions per column, not by bytes: a chunk of
+    // four columns that lies inside one allowed interval with no mask bit and no banned id (almost every chunk) takes
+    // the short path -- a compare and two selects per column; ascending order within a thread makes the strict compare
+    // keep the smallest index among equal values.
+    auto judge = [&](int c0, const bf16x4& x, unsigned mask, bool live) {
+        const int c3 = c0 + 3;
+        const bool in_text = c0 >= tlo && c3 < thi, in_ts = c0 >= slo && c3 < shi;
+        const bool clean = live && mask == 0 && c3 < V && (in_text || in_ts) && !(ban_eos >= c0 && ban_eos <= c3) &&
+                           !(ban_nots >= c0 && ban_nots <= c3);
+        if (clean) {
+            float bv = in_text ? bt.v : bs.v;
+            int bi = in_text ? bt.i : bs.i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = bf2f(x[e]);
+                if (v > bv) { bv = v; bi = c0 + e; }
+            }
+            if (in_text) { bt.v = bv; bt.i = bi; } else { bs.v = bv; bs.i = bi; }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = c0 + e;
-            if (c < V && allowed(c)) {
+            const bool ok = live && c < V && !((mask >> (8 * e)) & 0xffu) &&
+                            ((c >= tlo && c < thi) || (c >= slo && c < shi)) && c != ban_eos && c != ban_nots;
+            if (ok) {
                 const Best cand = {bf2f(x[e]), c};
                 if (c < tsb) bt = better(bt, cand); else bs = better(bs, cand);
             }
         }
+    };
+    constexpr int NPRE = 13;                           // 13 x 4096 columns cover every Whisper vocabulary (51 866)
+    if (V <= NPRE * SEL_NT * 4) {
+        // The whole row is requested before anything is judged, with clamped addresses instead of branches around the
+        // loads: as a loop, a thread's 13 chunks were 13 dependent L2 round trips (10 of the kernel's 19 us).
+        const int clast = (V - 1) & ~3;
+        bf16x4 xr[NPRE];
+        unsigned mr[NPRE];
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int c0 = min(tid * 4 + i * SEL_NT * 4, clast);
+            xr[i] = *(const bf16x4*)(row + c0);
+            mr[i] = masks_of(c0);
+        }
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int c0 = tid * 4 + i * SEL_NT * 4;
+            judge(min(c0, clast), xr[i], mr[i], c0 < V);
+        }
+    } else {
+        for (int c0 = tid * 4; c0 < V; c0 += SEL_NT * 4) judge(c0, *(const bf16x4*)(row + c0), masks_of(c0), true);
     }
     bt = block_best(bt, red);
     bs = block_best(bs, red);
@@ -189,23 +252,43 @@ extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
     int rc = dw_embed_fwd(d->ids, d->tok_emb, (const char*)d->pos_emb + (size_t)t * D * es, d->stream_dtype, d->x,
                           d->stream_dtype, B, n, D, stream);
     if (rc != DW_OK) return rc;
+    // With few rows the LayerNorm in front of a projection is computed inside the weight-streaming GEMM and the new
+    // K/V go straight into the cache (DwGemm.ln_x / kv_out): 9 launches per layer instead of 13.
+    const bool fuse_ln = rows <= 32 && D <= 1280 && !(g_decode_fuse_off & 1), fuse_kv = rows <= 64 && !(g_decode_fuse_off & 2);
     auto gemm = [&](const void* a, long lda, const void* w, const float* bias, int N, int K, void* c, long ldc, int c_dtype,
-                    int act, const void* r) -> int {
+                    int act, const void* r, const float* ln_g, const float* ln_b, void* kv) -> int {
         DwGemm g = {};
         g.a = a; g.b = w; g.c = c; g.bias = bias; g.r = r;
         g.lda = lda; g.ldb = K; g.ldc = ldc; g.ldr = ldc;
         g.m = rows; g.n = N; g.k = K;
         g.act = act; g.c_dtype = c_dtype; g.r_dtype = c_dtype; g.round_res = 1;
+        if (ln_g) {                                   // a = the residual stream x, normalised on load
+            g.a = nullptr; g.ln_x = a; g.ld_lnx = lda; g.ln_x_dtype = d->stream_dtype;
+            g.ln_gamma = ln_g; g.ln_beta = ln_b; g.ln_eps = 1e-5f;
+        }
+        if (kv) {
+            g.kv_out = kv; g.kv_ld = 2 * D; g.kv_split = D; g.kv_rows_per_batch = n; g.kv_batch_pitch = d->max_len;
+            g.kv_row0 = t;
+        }
         return dw_gemm_bf16(&g, stream);
+    };
+    auto ln = [&](const float* gam, const float* bet) -> int {
+        return dw_layernorm_fwd(d->x, d->stream_dtype, gam, bet, d->h, nullptr, nullptr, rows, D, 1e-5f, stream);
     };
     for (int l = 0; l < d->n_layers; ++l) {
         const DwDecoderLayer& L = d->layers[l];
         if (!L.wqkv || !L.wo || !L.wq || !L.wo2 || !L.w1 || !L.w2 || !L.self_kv || !L.cross_kv) return DW_EINVAL;
         // ---- self-attention over the cached prefix ----
-        if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, L.ln1_g, L.ln1_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
-                                   stream)) != DW_OK) return rc;
-        if ((rc = gemm(d->h, D, L.wqkv, L.bqkv, 3 * D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr)) != DW_OK) return rc;
-        {
+        if (fuse_ln) {
+            rc = gemm(d->x, D, L.wqkv, L.bqkv, 3 * D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr, L.ln1_g, L.ln1_b,
+                      fuse_kv ? L.self_kv : nullptr);
+        } else {
+            if ((rc = ln(L.ln1_g, L.ln1_b)) != DW_OK) return rc;
+            rc = gemm(d->h, D, L.wqkv, L.bqkv, 3 * D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr, nullptr, nullptr,
+                      fuse_kv ? L.self_kv : nullptr);
+        }
+        if (rc != DW_OK) return rc;
+        if (!fuse_kv) {
             const long nvec = (long)rows * ((2 * D) >> 3);
             hipLaunchKernelGGL(kv_append_kernel, dim3((nvec + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                                (const bf16*)d->qkv, (bf16*)L.self_kv, n, t, d->max_len, D, nvec);
@@ -214,22 +297,33 @@ extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
         const bf16* kc = (const bf16*)L.self_kv;
         if ((rc = dw_attn_fwd_ex(d->qkv, kc, kc + D, d->o, nullptr, B, H, n, t + n, 3 * D, 2 * D, 2 * D, D, n, d->max_len,
                                  n > 1 ? 2 : 0, 0.125f, stream)) != DW_OK) return rc;
-        if ((rc = gemm(d->o, D, L.wo, L.bo, D, D, d->x, D, d->stream_dtype, 0, d->x)) != DW_OK) return rc;
+        if ((rc = gemm(d->o, D, L.wo, L.bo, D, D, d->x, D, d->stream_dtype, 0, d->x, nullptr, nullptr, nullptr)) != DW_OK)
+            return rc;
         // ---- cross-attention over the static encoder K/V ----
-        if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, L.ln2_g, L.ln2_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
-                                   stream)) != DW_OK) return rc;
-        if ((rc = gemm(d->h, D, L.wq, L.bq, D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr)) != DW_OK) return rc;
+        if (fuse_ln) {
+            rc = gemm(d->x, D, L.wq, L.bq, D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr, L.ln2_g, L.ln2_b, nullptr);
+        } else {
+            if ((rc = ln(L.ln2_g, L.ln2_b)) != DW_OK) return rc;
+            rc = gemm(d->h, D, L.wq, L.bq, D, D, d->qkv, 3 * D, DW_BF16, 0, nullptr, nullptr, nullptr, nullptr);
+        }
+        if (rc != DW_OK) return rc;
         const bf16* kx = (const bf16*)L.cross_kv;
         if ((rc = dw_attn_fwd_ex(d->qkv, kx, kx + D, d->o, nullptr, B, H, n, d->src_len, 3 * D, 2 * D, 2 * D, D, n,
                                  d->src_len, 0, 0.125f, stream)) != DW_OK) return rc;
-        if ((rc = gemm(d->o, D, L.wo2, L.bo2, D, D, d->x, D, d->stream_dtype, 0, d->x)) != DW_OK) return rc;
+        if ((rc = gemm(d->o, D, L.wo2, L.bo2, D, D, d->x, D, d->stream_dtype, 0, d->x, nullptr, nullptr, nullptr)) != DW_OK)
+            return rc;
         // ---- feed-forward ----
-        if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, L.ln3_g, L.ln3_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
-                                   stream)) != DW_OK) return rc;
-        if ((rc = gemm(d->h, D, L.w1, L.b1, F, D, d->a, F, DW_BF16, 1, nullptr)) != DW_OK) return rc;
-        if ((rc = gemm(d->a, F, L.w2, L.b2, D, F, d->x, D, d->stream_dtype, 0, d->x)) != DW_OK) return rc;
+        if (fuse_ln) {
+            rc = gemm(d->x, D, L.w1, L.b1, F, D, d->a, F, DW_BF16, 1, nullptr, L.ln3_g, L.ln3_b, nullptr);
+        } else {
+            if ((rc = ln(L.ln3_g, L.ln3_b)) != DW_OK) return rc;
+            rc = gemm(d->h, D, L.w1, L.b1, F, D, d->a, F, DW_BF16, 1, nullptr, nullptr, nullptr, nullptr);
+        }
+        if (rc != DW_OK) return rc;
+        if ((rc = gemm(d->a, F, L.w2, L.b2, D, F, d->x, D, d->stream_dtype, 0, d->x, nullptr, nullptr, nullptr)) != DW_OK)
+            return rc;
     }
     if ((rc = dw_layernorm_fwd(d->x, d->stream_dtype, d->lnf_g, d->lnf_b, d->h, nullptr, nullptr, rows, D, 1e-5f,
                                stream)) != DW_OK) return rc;
-    return gemm(d->h, D, d->lm_head, nullptr, d->ldv, D, d->logits, d->ldv, DW_BF16, 0, nullptr);
+    return gemm(d->h, D, d->lm_head, nullptr, d->ldv, D, d->logits, d->ldv, DW_BF16, 0, nullptr, nullptr, nullptr, nullptr);
 }

@@ -30,6 +30,8 @@ int dw_gemm_wp8_tt_launch(const GemmP& p, hipStream_t s);
 extern int g_attn_bwd_stage;  // attention.hip
 extern int g_attn_decode;
 extern int g_logmel_mfma;     // logmel.hip
+extern int g_decode_fuse_off; // decode.hip
+extern int g_skinny_wide;     // gemm_skinny.hip
 int g_gemm_persistent = 1;
 // Kernel selection for the 256x256 block tile (bit mask; dw_debug_set(0, v)):
 //   bits 0-1 (3): base = 16-wave tile kernel (gemm_kernel.h) for everything, 8-wave 128x128 tile for small grids;
@@ -51,6 +53,8 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 4) { g_attn_decode = value; return DW_OK; }
     if (key == 5) { g_logmel_mfma = value; return DW_OK; }
     if (key == 6) { g_gemm_strip_budget = value; return DW_OK; }
+    if (key == 7) { g_decode_fuse_off = value; return DW_OK; }
+    if (key == 8) { g_skinny_wide = value; return DW_OK; }
     return DW_EINVAL;
 }
 
@@ -82,10 +86,10 @@ extern "C" int dw_reduce_slices(const float* part, int64_t stride, int slices, f
 
 extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     DW_CLEAR_ERR();
-    if (!g || !g->a || !g->b || !g->c) return DW_EINVAL;
+    if (!g || (!g->a && !g->ln_x) || !g->b || !g->c) return DW_EINVAL;
     if (g->m <= 0 || g->n <= 0 || g->k <= 0 || (g->k & 63)) return DW_EINVAL;
     if ((g->lda & 7) || (g->ldb & 7)) return DW_EINVAL;
-    if (((uintptr_t)g->a & 15) || ((uintptr_t)g->b & 15)) return DW_EINVAL;
+    if ((g->a && ((uintptr_t)g->a & 15)) || ((uintptr_t)g->b & 15)) return DW_EINVAL;
     // k-major operands are fetched in 16-byte column slots: a slot whose first column is valid is read whole, so the
     // row must be readable up to the next multiple of 8 columns (true whenever ld covers the padded width)
     if (g->trans_a && g->lda < ((g->m + 7) & ~7)) return DW_EINVAL;
@@ -101,6 +105,18 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.atomic = g->atomic_acc ? 1 : 0;
     if (p.split_k > (g->k >> 6)) p.split_k = g->k >> 6;
     p.slice_stride = 0;
+    p.ln_x = g->ln_x; p.ln_g = g->ln_gamma; p.ln_b = g->ln_beta; p.ld_lnx = g->ld_lnx; p.ln_x_dtype = g->ln_x_dtype;
+    p.ln_eps = g->ln_eps;
+    p.kv_out = (bf16*)g->kv_out; p.kv_ld = g->kv_ld; p.kv_split = g->kv_split; p.kv_rpb = g->kv_rows_per_batch;
+    p.kv_pitch = g->kv_batch_pitch; p.kv_row0 = g->kv_row0;
+    const bool fused = g->ln_x || g->kv_out;
+    if (g->ln_x && (!g->ln_gamma || !g->ln_beta || g->k > 1280 || g->m > 32 || (g->ld_lnx & 7) ||
+                    ((uintptr_t)g->ln_x & 15) || ((uintptr_t)g->ln_gamma & 15) || ((uintptr_t)g->ln_beta & 15)))
+        return DW_EINVAL;
+    if (g->kv_out && (g->c_dtype != DW_BF16 || g->act || g->r || g->z_out || g->zgrad_in || (g->kv_split & 15) ||
+                      g->kv_split <= 0 || g->kv_split >= g->n || g->kv_rows_per_batch <= 0 || (g->kv_ld & 3) ||
+                      ((uintptr_t)g->kv_out & 7)))
+        return DW_EINVAL;
     if (p.split_k > 1 && !p.atomic) {
         // K slices without atomics: every slice stores a plain fp32 partial at c + ks * slice_stride (the caller
         // reduces them, see dw_reduce_slices); only the bare epilogue makes sense here
@@ -123,6 +139,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     // decode regime (M = batch rows): weight-streaming kernel; tile = 16 requests it explicitly
     if (tile == 16 && !dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return DW_EINVAL;
     if ((tile == 0 || tile == 16) && dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return dw_gemm_skinny_launch(p, s);
+    if (fused) return DW_EINVAL;                  // the fusions exist in the skinny-M kernel only
     if (tile != 128 && tile != 256) {
         const long t256 = (long)((g->m + 255) / 256) * ((g->n + 255) / 256);
         tile = t256 >= 512 ? 256 : 128;

@@ -19,6 +19,16 @@ struct GemmP {
     int split_k, atomic;   // K slices per tile (grid = nwg * split_k); atomic: C (f32) += v with atomics
     int vec;               // all epilogue pointers / leading dimensions allow 4-wide vector access
     long slice_stride;     // split-K without atomics: slice ks stores its partial tile at c + ks * slice_stride
+    // decode-step fusions (skinny-M kernel only, see gemm_skinny.hip)
+    const void* ln_x;      // A = bf16(LayerNorm(ln_x)) built on load (a is ignored); f32 or bf16 per ln_x_dtype
+    const float* ln_g;
+    const float* ln_b;
+    long ld_lnx;
+    int ln_x_dtype;
+    float ln_eps;
+    bf16* kv_out;          // output columns >= kv_split of row m go to the K/V cache instead of C:
+    long kv_ld;            //   kv_out[((m / kv_rpb) * kv_pitch + kv_row0 + m % kv_rpb) * kv_ld + (n - kv_split)]
+    int kv_split, kv_rpb, kv_pitch, kv_row0;
 };
 
 // Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.

@@ -14,15 +14,39 @@
 //     are 4-wide along N;
 //   * the per-wave partial sums meet in LDS; the fused epilogue (bias, exact GELU, residual, fp32/bf16 store) is the
 //     same arithmetic as the tile kernel's (gemm_common.h).
+// Two fusions cut launches out of the token step (a kernel boundary costs 6-8 us there, more than most of these GEMVs):
+//   * LN != 0: the A operand is bf16(LayerNorm(x)) built on load.  A lane keeps its slice of the row (<= 10 k steps x 8
+//     values) in REGISTERS, so x is read once; mean and centred variance (two passes, like csrc/norm.hip) are combined
+//     across the waves through LDS while the weight loads issued at kernel entry are still in flight.  (The first
+//     attempt re-read x from L2 in three passes behind three barriers and was slower than the LayerNorm launch it saved.)
+//   * kv_out: output columns >= kv_split are stored straight into the K/V cache row of their sequence position (the
+//     append of TF:modeling_whisper.py:312-335) instead of a staging buffer + copy kernel.
 #include "gemm_common.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int SK_MAXS = 10;   // 32-deep k steps a wave keeps in registers (10 x 16 B of W + as much of A per lane)
 constexpr int SK_MAXW = 16;   // waves per workgroup
+int g_skinny_wide = 1;        // dw_debug_set key 8: wide (64 columns per workgroup) variant for the LM head
 
-template <int MB>
-__global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p, int nw, int steps_total) {
+// 8 consecutive elements of the LayerNorm input (f32 or bf16) as floats
+template <bool XBF>
+__device__ __forceinline__ void ld_x8(const void* x, long off, float (&v)[8]) {
+    if (XBF) {
+        const bf16x8 t = *(const bf16x8*)((const bf16*)x + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf2f(t[e]);
+    } else {
+        const f32x4_t a = *(const f32x4_t*)((const float*)x + off);
+        const f32x4_t b = *(const f32x4_t*)((const float*)x + off + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+}
+
+// LN: 0 = A is a ready bf16 operand; 1 / 2 = A = bf16(LayerNorm(ln_x)), ln_x in f32 / bf16 (k <= 1280: <= 4 waves, so
+// the kernel may use up to 512 registers per lane and keep the row slices resident)
+template <int MB, int LN>
+__global__ __launch_bounds__(LN ? 256 : 64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p, int nw, int steps_total) {
     extern __shared__ float red[];  // [nw][MB][64][4]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -44,6 +68,85 @@ __global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p
     f32x4_t acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN != 0) {
+        constexpr bool XBF = LN == 2;
+        // this lane's slices of rows mb*16 + r16: k = (s0 + s)*32 + g*8 + 0..7
+        float xs[MB][SK_MAXS][8];
+        float part[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            int arow = mb * 16 + r16;
+            arow = arow < p.m ? arow : p.m - 1;
+            float a1 = 0.f;
+#pragma unroll
+            for (int s = 0; s < SK_MAXS; ++s)
+                if (s < ns) {
+                    ld_x8<XBF>(p.ln_x, (long)arow * p.ld_lnx + (long)(s0 + s) * 32 + g * 8, xs[mb][s]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a1 += xs[mb][s][e];
+                }
+            a1 += __shfl_xor(a1, 16);
+            a1 += __shfl_xor(a1, 32);
+            part[mb] = a1;
+        }
+        // LayerNorm parameters of this lane's columns (independent of the statistics: requested now)
+        float gm[SK_MAXS][8], bt[SK_MAXS][8];
+#pragma unroll
+        for (int s = 0; s < SK_MAXS; ++s)
+            if (s < ns) {
+                ld_x8<false>(p.ln_g, (long)(s0 + s) * 32 + g * 8, gm[s]);
+                ld_x8<false>(p.ln_b, (long)(s0 + s) * 32 + g * 8, bt[s]);
+            }
+        if (g == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) red[(wave * MB + mb) * 16 + r16] = part[mb];
+        }
+        __syncthreads();
+        float mu[MB], rs[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float t = 0.f;
+            for (int w = 0; w < nw; ++w) t += red[(w * MB + mb) * 16 + r16];
+            mu[mb] = t / (float)p.k;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float a2 = 0.f;
+#pragma unroll
+            for (int s = 0; s < SK_MAXS; ++s)
+                if (s < ns) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float d = xs[mb][s][e] - mu[mb]; a2 += d * d; }
+                }
+            a2 += __shfl_xor(a2, 16);
+            a2 += __shfl_xor(a2, 32);
+            part[mb] = a2;
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) red[(wave * MB + mb) * 16 + r16] = part[mb];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float t = 0.f;
+            for (int w = 0; w < nw; ++w) t += red[(w * MB + mb) * 16 + r16];
+            rs[mb] = rsqrtf(t / (float)p.k + p.ln_eps);
+        }
+        __syncthreads();                               // `red` is reused for the accumulator exchange below
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int s = 0; s < SK_MAXS; ++s)
+                if (s < ns) {
+                    bf16x8 af;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[e] = f2bf((xs[mb][s][e] - mu[mb]) * rs[mb] * gm[s][e] + bt[s][e]);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af, acc[mb], 0, 0, 0);
+                }
+        }
+    } else {
     static_for<0, MB>([&](auto mc) {
         constexpr int mb = decltype(mc)::value;
         int arow = mb * 16 + r16;
@@ -57,6 +160,7 @@ __global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p
         for (int s = 0; s < SK_MAXS; ++s)
             if (s < ns) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[s], acc[mb], 0, 0, 0);
     });
+    }
     // acc[mb][r] = partial C[m = mb*16 + (lane & 15)][n = n0 + 4*(lane >> 4) + r]
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) *(f32x4_t*)(red + ((wave * MB + mb) * 64 + lane) * 4) = acc[mb];
@@ -100,7 +204,13 @@ __global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
         }
-        if (p.c_dtype == DW_F32) {
+        if (p.kv_out && n >= p.kv_split) {           // K/V columns: straight into the cache row of this position
+            const int bq = m / p.kv_rpb;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            *(bf16x4*)(p.kv_out + ((long)bq * p.kv_pitch + p.kv_row0 + (m - bq * p.kv_rpb)) * p.kv_ld + (n - p.kv_split)) = o;
+        } else if (p.c_dtype == DW_F32) {
             f32x4_t o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = v[e];
@@ -114,10 +224,81 @@ __global__ __launch_bounds__(64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p
     }
 }
 
+// Wide variant for the tied LM head (N = 51 904 columns, plain epilogue): a workgroup owns 16 * NB output columns, so the
+// activation fragments (fetched once per wave) serve NB weight blocks -- with one block per workgroup the L2 traffic of
+// the activations (40 KB per workgroup) equals the HBM traffic of the weights it streams.  k <= 1280 (<= 4 waves,
+// registers for NB x 10 weight fragments per lane).
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void gemm_skinny_wide_kernel(const GemmP p, int nw, int steps_total) {
+    extern __shared__ float red[];  // [nw][NB][MB][64][4]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.x * 16 * NB;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int base = steps_total / nw, rem = steps_total - base * nw;
+    const int s0 = wave * base + (wave < rem ? wave : rem);
+    const int ns = base + (wave < rem ? 1 : 0);
+    bf16x8 wf[NB][SK_MAXS];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        int wrow = n0 + nb * 16 + r16;
+        wrow = wrow < p.n ? wrow : p.n - 1;
+        const bf16* wp = p.b + (long)wrow * p.ldb + (long)s0 * 32 + g * 8;
+#pragma unroll
+        for (int s = 0; s < SK_MAXS; ++s)
+            if (s < ns) wf[nb][s] = *(const bf16x8*)(wp + s * 32);
+    }
+    f32x4_t acc[NB][MB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    static_for<0, MB>([&](auto mc) {
+        constexpr int mb = decltype(mc)::value;
+        int arow = mb * 16 + r16;
+        arow = arow < p.m ? arow : p.m - 1;
+        const bf16* ap = p.a + (long)arow * p.lda + (long)s0 * 32 + g * 8;
+        bf16x8 af[SK_MAXS];
+#pragma unroll
+        for (int s = 0; s < SK_MAXS; ++s)
+            if (s < ns) af[s] = *(const bf16x8*)(ap + s * 32);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int s = 0; s < SK_MAXS; ++s)
+                if (s < ns) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], af[s], acc[nb][mb], 0, 0, 0);
+    });
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) *(f32x4_t*)(red + (((wave * NB + nb) * MB + mb) * 64 + lane) * 4) = acc[nb][mb];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NB * MB * 64; idx += blockDim.x) {
+        const int nb = idx / (MB * 64), mb = (idx / 64) % MB, l = idx & 63;
+        f32x4_t v4 = {0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < nw; ++w) {
+            const f32x4_t t = *(const f32x4_t*)(red + (((w * NB + nb) * MB + mb) * 64 + l) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v4[e] += t[e];
+        }
+        const int m = mb * 16 + (l & 15);
+        const int n = n0 + nb * 16 + 4 * (l >> 4);
+        if (m >= p.m || n >= p.n) continue;
+        if (p.c_dtype == DW_F32) *(f32x4_t*)((float*)p.c + (long)m * p.ldc + n) = v4;
+        else {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v4[e]);
+            *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
+        }
+    }
+}
+
 // true when the problem fits this kernel (the caller falls back to the tile kernel otherwise)
 bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b) {
     if (trans_a || trans_b || p.m > 64 || p.split_k > 1 || p.atomic || p.z_out || p.zgrad || p.r_row_mod > 0) return false;
     if (!p.vec || (p.n & 15) || (p.k & 31) || p.k > SK_MAXS * SK_MAXW * 32) return false;
+    if (p.ln_x && (p.m > 32 || p.k > SK_MAXS * 4 * 32)) return false;
     return true;
 }
 
@@ -127,11 +308,26 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s) {
     if (nw > SK_MAXW) nw = SK_MAXW;
     if ((steps + nw - 1) / nw > SK_MAXS) return DW_EINVAL;
     const int mb = (p.m + 15) / 16;
+    if (g_skinny_wide && !p.bias && !p.act && !p.r && !p.ln_x && !p.kv_out && nw <= 4 && p.n >= 16384 && mb <= 2) {
+        constexpr int NB = 4;
+        dim3 grid((p.n + 16 * NB - 1) / (16 * NB)), block(64 * nw);
+        const size_t lds = (size_t)nw * NB * mb * 64 * 4 * sizeof(float);
+        if (mb == 1) hipLaunchKernelGGL((gemm_skinny_wide_kernel<1, NB>), grid, block, lds, s, p, nw, steps);
+        else hipLaunchKernelGGL((gemm_skinny_wide_kernel<2, NB>), grid, block, lds, s, p, nw, steps);
+        DW_CHECK_LAUNCH();
+        return DW_OK;
+    }
     dim3 grid(p.n / 16), block(64 * nw);
     const size_t lds = (size_t)nw * (mb == 3 ? 4 : mb) * 64 * 4 * sizeof(float);
-    if (mb == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, lds, s, p, nw, steps);
-    else if (mb == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, lds, s, p, nw, steps);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, block, lds, s, p, nw, steps);
+    if (p.ln_x) {
+        const bool xbf = p.ln_x_dtype == DW_BF16;
+        if (mb == 1 && !xbf) hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), grid, block, lds, s, p, nw, steps);
+        else if (mb == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), grid, block, lds, s, p, nw, steps);
+        else if (!xbf) hipLaunchKernelGGL((gemm_skinny_kernel<2, 1>), grid, block, lds, s, p, nw, steps);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), grid, block, lds, s, p, nw, steps);
+    } else if (mb == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, 0>), grid, block, lds, s, p, nw, steps);
+    else if (mb == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 0>), grid, block, lds, s, p, nw, steps);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<4, 0>), grid, block, lds, s, p, nw, steps);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -451,6 +451,43 @@ class WhisperEngine:
         cache["t"] += n
         return ws["logits"]     # (workspace of the cache: valid until the next pass with the same n)
 
+    def _decoder_layers_cached(self, x, cache, n):
+        """The decoder layers of one cached pass over `n` new positions per row (x: [B*n, D] embedded inputs).  With
+        few rows (B*n <= 32 / 64) the LayerNorm in front of each projection is computed inside the weight-streaming
+        GEMM and the new K/V go straight into the cache (ops.gemm ln= / kv_append=); otherwise they are separate
+        launches.  dw_decode_step issues exactly the same sequence."""
+        ops, st, d = self.ops, self.st, self.dims
+        B, t, ML = cache["B"], cache["t"], cache["max_len"]
+        D, H, Lk = d.d_model, d.heads, d.max_src
+        rows = B * n
+        fuse_ln, fuse_kv = rows <= 32 and D <= 1280, rows <= 64
+        causal = 2 if n > 1 else False
+        for i in range(d.dec_layers):
+            p = f"model.decoder.layers.{i}"
+            av = st.attn_views(f"{p}.self_attn")
+            ln1 = (st.p[f"{p}.self_attn_layer_norm.weight"], st.p[f"{p}.self_attn_layer_norm.bias"], 1e-5)
+            kvc = cache["self"][i]
+            h = x if fuse_ln else ops.layernorm_fwd(x, *ln1, save_stats=False)[0]
+            qkv = ops.gemm(h, av["wqkv"], bias=av["bqkv"], ln=ln1[:2] if fuse_ln else None,
+                           kv_append=(kvc, D, n, ML, t) if fuse_kv else None)
+            if not fuse_kv:
+                kvc.view(B, ML, 2 * D)[:, t:t + n].copy_(qkv[:, D:].view(B, n, 2 * D))   # append this pass's K/V
+            o, _ = ops.attn_fwd(qkv[:, :D], kvc[:, :D], kvc[:, D:], B, H, n, t + n, causal, 0.125, kv_batch_rows=ML)
+            x = ops.gemm(o, av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            cv = st.attn_views(f"{p}.encoder_attn")
+            ln2 = (st.p[f"{p}.encoder_attn_layer_norm.weight"], st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5)
+            h = x if fuse_ln else ops.layernorm_fwd(x, *ln2, save_stats=False)[0]
+            q = ops.gemm(h, cv["wqkv"][:D], bias=cv["bqkv"][:D], ln=ln2[:2] if fuse_ln else None)
+            kv = cache["cross"][i]
+            o, _ = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, n, Lk, False, 0.125)
+            x = ops.gemm(o, cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            ln3 = (st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"], 1e-5)
+            h = x if fuse_ln else ops.layernorm_fwd(x, *ln3, save_stats=False)[0]
+            a = ops.gemm(h, st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1, ln=ln3[:2] if fuse_ln else None)
+            x = ops.gemm(a, st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
+                         out_dtype=self.stream)
+        return x
+
     def decode_step(self, ids_t, cache):
         """One greedy-decoding step: ids_t int64 [B, 1] at position cache["t"] -> logits low-precision [B, ldv]."""
         ops, st, d = self.ops, self.st, self.dims
@@ -463,28 +500,7 @@ class WhisperEngine:
         tok = (st.p if f32 else st.s)["model.decoder.embed_tokens.weight"]
         pos = (st.p if f32 else st.s)["model.decoder.embed_positions.weight"][t:t + 1]
         x = ops.embed_fwd(ids_t.contiguous(), tok, pos, torch.float32 if f32 else self.lowp)
-        for i in range(d.dec_layers):
-            p = f"model.decoder.layers.{i}"
-            av = st.attn_views(f"{p}.self_attn")
-            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.self_attn_layer_norm.weight"],
-                                        st.p[f"{p}.self_attn_layer_norm.bias"], 1e-5, save_stats=False)
-            qkv = ops.gemm(h, av["wqkv"], bias=av["bqkv"])
-            kvc = cache["self"][i]
-            kvc.view(B, ML, 2 * D)[:, t].copy_(qkv[:, D:])  # append this step's K/V (plumbing copy of B rows)
-            o, _ = ops.attn_fwd(qkv[:, :D], kvc[:, :D], kvc[:, D:], B, H, 1, t + 1, False, 0.125, kv_batch_rows=ML)
-            x = ops.gemm(o, av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
-            cv = st.attn_views(f"{p}.encoder_attn")
-            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
-                                        st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, save_stats=False)
-            q = ops.gemm(h, cv["wqkv"][:D], bias=cv["bqkv"][:D])
-            kv = cache["cross"][i]
-            o, _ = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, 1, Lk, False, 0.125)
-            x = ops.gemm(o, cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
-            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"],
-                                        1e-5, save_stats=False)
-            a = ops.gemm(h, st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
-            x = ops.gemm(a, st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
-                         out_dtype=self.stream)
+        x = self._decoder_layers_cached(x, cache, 1)
         hf, _, _ = ops.layernorm_fwd(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"],
                                      1e-5, save_stats=False)
         eo = st.entries["model.decoder.embed_tokens.weight"][0]
@@ -510,29 +526,7 @@ class WhisperEngine:
         tok = (st.p if f32 else st.s)["model.decoder.embed_tokens.weight"]
         pos = (st.p if f32 else st.s)["model.decoder.embed_positions.weight"][t:t + n]
         x = ops.embed_fwd(ids.contiguous(), tok, pos.contiguous(), torch.float32 if f32 else self.lowp)
-        for i in range(d.dec_layers):
-            p = f"model.decoder.layers.{i}"
-            av = st.attn_views(f"{p}.self_attn")
-            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.self_attn_layer_norm.weight"],
-                                        st.p[f"{p}.self_attn_layer_norm.bias"], 1e-5, save_stats=False)
-            qkv = ops.gemm(h, av["wqkv"], bias=av["bqkv"])
-            kvc = cache["self"][i]
-            kvc.view(B, ML, 2 * D)[:, t:t + n].copy_(qkv[:, D:].view(B, n, 2 * D))
-            o, _ = ops.attn_fwd(qkv[:, :D], kvc[:, :D], kvc[:, D:], B, H, n, t + n, 2 if n > 1 else False, 0.125,
-                                kv_batch_rows=ML)
-            x = ops.gemm(o, av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
-            cv = st.attn_views(f"{p}.encoder_attn")
-            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.encoder_attn_layer_norm.weight"],
-                                        st.p[f"{p}.encoder_attn_layer_norm.bias"], 1e-5, save_stats=False)
-            q = ops.gemm(h, cv["wqkv"][:D], bias=cv["bqkv"][:D])
-            kv = cache["cross"][i]
-            o, _ = ops.attn_fwd(q, kv[:, :D], kv[:, D:], B, H, n, Lk, False, 0.125)
-            x = ops.gemm(o, cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
-            h, _, _ = ops.layernorm_fwd(x, st.p[f"{p}.final_layer_norm.weight"], st.p[f"{p}.final_layer_norm.bias"],
-                                        1e-5, save_stats=False)
-            a = ops.gemm(h, st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1)
-            x = ops.gemm(a, st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
-                         out_dtype=self.stream)
+        x = self._decoder_layers_cached(x, cache, n)
         hf, _, _ = ops.layernorm_fwd(x, st.p["model.decoder.layer_norm.weight"], st.p["model.decoder.layer_norm.bias"],
                                      1e-5, save_stats=False)
         eo = st.entries["model.decoder.embed_tokens.weight"][0]

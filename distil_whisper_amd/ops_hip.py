@@ -27,6 +27,10 @@ class DwGemm(C.Structure):
         ("trans_a", C.c_int32), ("trans_b", C.c_int32), ("act", C.c_int32), ("c_dtype", C.c_int32),
         ("r_dtype", C.c_int32), ("r_row_mod", C.c_int32), ("round_res", C.c_int32), ("tile", C.c_int32),
         ("split_k", C.c_int32), ("atomic_acc", C.c_int32), ("slice_stride", C.c_int64),
+        ("ln_x", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("kv_out", C.c_void_p),
+        ("ld_lnx", C.c_int64), ("kv_ld", C.c_int64),
+        ("ln_x_dtype", C.c_int32), ("kv_split", C.c_int32), ("kv_rows_per_batch", C.c_int32),
+        ("kv_batch_pitch", C.c_int32), ("kv_row0", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -196,12 +200,16 @@ class HipOps:
         return out
 
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
-             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0):
+             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
+             kv_append=None):
         """C = op(a) @ op(b) with the fused epilogue of dw_gemm_bf16.  a: [M,K] (or [K,M] if trans_a);
         b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1.
         atomic_acc: out (fp32) += result via float atomics, with the K range split over several workgroups when the
-        output has too few tiles to fill the 256 CUs (weight-gradient GEMMs: small M x N, K = all tokens)."""
-        assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+        output has too few tiles to fill the 256 CUs (weight-gradient GEMMs: small M x N, K = all tokens).
+        Decode-step fusions (M <= 32 / 64, skinny kernel): ln=(gamma, beta[, eps]) makes the operand
+        bf16(LayerNorm(a)) with `a` the f32 / bf16 residual stream; kv_append=(cache, split, rows_per_batch,
+        batch_pitch, row0) stores output columns >= split into the K/V cache rows of their positions."""
+        assert b.dtype == torch.bfloat16 and (a.dtype == torch.bfloat16 or ln is not None)
         assert a.stride(1) == 1 and b.stride(1) == 1
         if trans_a:
             K, M = a.shape
@@ -252,6 +260,17 @@ class HipOps:
                 g.split_k, g.slice_stride = sk, M * N
             else:
                 g.atomic_acc, g.split_k = 1, 1
+        if ln is not None:
+            gamma, beta = ln[0], ln[1]
+            assert a.dtype in (torch.float32, torch.bfloat16) and not trans_a      # (m <= 32, k <= 1280: the library checks)
+            assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == K == beta.numel()
+            g.a, g.ln_x, g.ld_lnx, g.ln_x_dtype = None, a.data_ptr(), a.stride(0), _dt(a)
+            g.ln_gamma, g.ln_beta, g.ln_eps = gamma.data_ptr(), beta.data_ptr(), float(ln[2]) if len(ln) > 2 else 1e-5
+        if kv_append is not None:
+            cache, split, rpb, pitch, row0 = kv_append
+            assert cache.dtype == torch.bfloat16 and cache.stride(-1) == 1
+            g.kv_out, g.kv_ld, g.kv_split = cache.data_ptr(), N - split, int(split)
+            g.kv_rows_per_batch, g.kv_batch_pitch, g.kv_row0 = int(rpb), int(pitch), int(row0)
         z = None
         if bias is not None:
             assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()

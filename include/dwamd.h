@@ -77,6 +77,20 @@ typedef struct DwGemm {
                            storing fp32 partials at c + slice * slice_stride (then call dw_reduce_slices) */
     int32_t atomic_acc; /* 1: C (f32, plain epilogue) += result with float atomics (gradient accumulation) */
     int64_t slice_stride; /* elements between the partial outputs of consecutive K slices (split_k > 1, no atomics) */
+    /* Decode-step fusions, honoured by the skinny-M kernel only (m <= 32 for ln_x, m <= 64 for kv_out; any other launch
+     * with these fields set is rejected with DW_EINVAL).  All zero = off. */
+    const void* ln_x;        /* A = bf16(LayerNorm(ln_x)) computed on load over the K columns (`a` is ignored; k <= 1280):
+                                the LayerNorm in front of a projection (TF:modeling_whisper.py:459, 474, 491) */
+    const float* ln_gamma;   /* f32 [k] */
+    const float* ln_beta;    /* f32 [k] */
+    void* kv_out;            /* bf16 K/V cache: output columns >= kv_split of row m are stored at
+                                kv_out[((m / kv_rows_per_batch) * kv_batch_pitch + kv_row0 + m % kv_rows_per_batch) * kv_ld
+                                       + (n - kv_split)] instead of C (the in-place cache append of
+                                TF:modeling_whisper.py:312-335); requires a bf16 output without activation / residual */
+    int64_t ld_lnx, kv_ld;
+    int32_t ln_x_dtype;      /* DW_F32 / DW_BF16 */
+    int32_t kv_split, kv_rows_per_batch, kv_batch_pitch, kv_row0;
+    float ln_eps;
 } DwGemm;
 int dw_gemm_bf16(const DwGemm* g, void* stream);
 /* out[i] (+)= sum over slices of part[s*stride + i]; n, stride multiples of 4 (split-K combination, deterministic). */

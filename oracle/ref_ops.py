@@ -56,8 +56,11 @@ class RefOps:
 
     # nn.Linear under bf16 autocast: bf16 operands, fp32 accumulation (TF:modeling_whisper.py:279-282 etc.)
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
-             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0):
+             r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
+             kv_append=None):
         out_dtype = self.lowp if out_dtype is None else out_dtype
+        if ln is not None:                     # operand = bf16(LayerNorm(a)) (decode-step fusion of the HIP kernel)
+            a = self.layernorm_fwd(a, ln[0], ln[1], ln[2] if len(ln) > 2 else 1e-5, save_stats=False)[0]
         A = a.float().t() if trans_a else a.float()
         Bm = b.float() if trans_b else b.float().t()
         v = A @ Bm
@@ -78,6 +81,11 @@ class RefOps:
                 r = r[idx]
             v = (self._bf(v).float() if round_res else v) + r
         v = v.to(out_dtype)
+        if kv_append is not None:              # columns >= split go to the K/V cache rows of their positions
+            cache, split, rpb, pitch, row0 = kv_append
+            m = torch.arange(v.shape[0], device=v.device)
+            rows = (m // rpb) * pitch + row0 + (m % rpb)
+            cache.view(-1, v.shape[1] - split)[rows] = v[:, split:].to(cache.dtype)
         if out is not None:
             if atomic_acc:
                 out += v

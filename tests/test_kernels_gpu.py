@@ -142,6 +142,36 @@ def test_gemm_pipelined_variants_are_bit_identical(ops, ref, variant, ta, tb):
         ops.lib.dw_debug_set(0, 119)
 
 
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,n_new", [(1, 1), (16, 1), (12, 3), (32, 2)])
+def test_gemm_skinny_layernorm_on_load_and_kv_append(ops, ref, xdtype, M, n_new):
+    """Decode-step fusions of the weight-streaming kernel: A = bf16(LayerNorm(x)) built on load (x f32 or bf16) and the
+    K/V columns of the fused QKV projection stored straight into the cache rows of their positions -- against the
+    unfused launches (LayerNorm kernel + GEMM + strided copy) and the torch restatement."""
+    D, ML, t0 = 1280, 24, 5
+    B = M // n_new
+    x = rnd((M, D), 2.0, xdtype, seed=70) + 0.5
+    gamma, beta = rnd((D,), 0.5, torch.float32, seed=71) + 1.0, rnd((D,), 0.5, torch.float32, seed=72)
+    w, bias = rnd((3 * D, D), 0.03, seed=73), rnd((3 * D,), 0.5, torch.float32, seed=74)
+    cache = rnd((B * ML, 2 * D), 1.0, seed=75)
+    want_cache, ref_cache = cache.clone(), cache.clone()
+    h = ops.layernorm_fwd(x, gamma, beta, 1e-5, save_stats=False)[0]
+    want = ops.gemm(h, w, bias=bias)
+    want_cache.view(B, ML, 2 * D)[:, t0:t0 + n_new].copy_(want[:, D:].view(B, n_new, 2 * D))
+    got = ops.gemm(x, w, bias=bias, ln=(gamma, beta, 1e-5), kv_append=(cache, D, n_new, ML, t0))
+    r = ref.gemm(x, w, bias=bias, ln=(gamma, beta, 1e-5), kv_append=(ref_cache, D, n_new, ML, t0))
+    # the fused statistics sum in a different order than csrc/norm.hip: bf16 operands may differ in the last bit
+    assert relerr(got[:, :D], want[:, :D]) < 4e-3 and relerr(got[:, :D], r[:, :D]) < 4e-3
+    assert relerr(cache, want_cache) < 4e-3 and relerr(cache, ref_cache) < 4e-3
+    untouched = torch.ones(B, ML, dtype=torch.bool); untouched[:, t0:t0 + n_new] = False
+    assert torch.equal(cache.view(B, ML, 2 * D)[untouched.cuda()], want_cache.view(B, ML, 2 * D)[untouched.cuda()])
+    # GELU epilogue + LayerNorm on load (the fc1 launch of the token step)
+    w1, b1 = rnd((5120, D), 0.03, seed=76), rnd((5120,), 0.5, torch.float32, seed=77)
+    assert relerr(ops.gemm(x, w1, bias=b1, act=1, ln=(gamma, beta)), ops.gemm(h, w1, bias=b1, act=1)) < 6e-3
+    with pytest.raises(RuntimeError):        # the fusions exist in the skinny-M kernel only
+        ops.gemm(rnd((128, D), 1.0, xdtype, seed=78), w, bias=bias, ln=(gamma, beta))
+
+
 @pytest.mark.parametrize("M", [1, 16, 17, 40, 64])
 @pytest.mark.parametrize("N,K", [(1280, 1280), (5120, 1280), (1280, 5120), (48, 64), (51904, 1280)])
 def test_gemm_skinny_decode_shapes(ops, ref, M, N, K):

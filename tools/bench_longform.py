@@ -19,6 +19,20 @@ fe = WhisperFeatureExtractor(feature_size=128, ops=ops)
 CLIPS, NEW, B = int(os.environ.get("CLIPS", 4)), int(os.environ.get("NEW", 128)), int(os.environ.get("B", 16))
 audio = [0.1 * torch.randn(4_800_000, device=dev) for _ in range(CLIPS)]
 res = {"clips": CLIPS, "clip_s": 300, "batch": B, "new_tokens": NEW}
+if os.environ.get("DW_FUSE_AB"):              # decode-pass fusions (key 7): 3 = both off, 2 = LN on load only, 1 = K/V append only, 0 = both
+    for mode in (3, 2, 1, 0, 3, 0):
+        ops.lib.dw_debug_set(7, mode)
+        tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True)
+        feats = torch.randn(B, 128, 3000, device=dev) * 0.5
+        enc, _ = model.engine.encode(feats, save=False)
+        prompt = tr.prompt[None, :].expand(B, -1).contiguous()
+        for _ in range(2): tr.decoder.run(enc, prompt, NEW)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3): tr.decoder.run(enc, prompt, NEW)
+        torch.cuda.synchronize()
+        print(f"fuse_off={mode}: {(time.perf_counter() - t0) / 3 / NEW * 1e3:.4f} ms per decode step (graphs)", file=sys.stderr)
+    ops.lib.dw_debug_set(7, 0)
 if os.environ.get("DW_DECODE_AB"):            # streaming single-query attention kernel off (tile kernel) vs on
     for mode in (0, 1):
         ops.lib.dw_debug_set(4, mode)
