@@ -22,7 +22,8 @@ CLASS_OF = [  # kernel symbol -> the per-class key bench.py / ops_hip.py use
     (r"gemm_kernel<128, 128, \d+, \d+, false, false", "gemm_t128_NN"), (r"gemm_kernel<128, 128, \d+, \d+, false, true", "gemm_t128_NT"),
     (r"gemm_wp_kernel<false, false", "gemm_t256_NN"), (r"gemm_wp_kernel<false, true", "gemm_t256_NT"),
     (r"gemm_wp_kernel<true, true", "gemm_t256_TT"), (r"gemm_phased_kernel", "gemm_t256_NT"), (r"attn_fwd_kernel", "attn_fwd"), (r"attn_bwd_dkv", "attn_bwd_dkv"),
-    (r"attn_bwd_dq", "attn_bwd_dq"), (r"ln_fwd", "ln_fwd"), (r"ln_bwd", "ln_bwd"), (r"adamw", "adamw"),
+    (r"attn_bwd_dq", "attn_bwd_dq"), (r"ln_fwd", "ln_fwd"), (r"ln_bwd", "ln_bwd"), (r"adamw", "adamw"), (r"loss_row", "loss"),
+    (r"colsum", "colsum"), (r"logmel", "logmel"), (r"sumsq", "sumsq"), (r"reduce_slices", "reduce_slices"),
 ]
 
 
