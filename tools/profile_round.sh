@@ -6,7 +6,7 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/r2i/probe_prof -o p -- python too
 python tools/rocprof_summary.py gpurun_out/r2i/probe_prof/p_results.db gpurun_out/r2i/probe_kernels.md > /dev/null 2>&1
 rm -rf gpurun_out/r2i/probe_prof
 python bench.py > gpurun_out/r2i/bench.json 2> gpurun_out/r2i/bench.err
-rocprofv3 --kernel-trace --stats -d gpurun_out/r2i/prof -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/r2i/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/r2i/prof -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-overlap > gpurun_out/r2i/bench_prof.log 2>&1
 python tools/rocprof_summary.py gpurun_out/r2i/prof/bench_results.db gpurun_out/r2i/kernel_stats.md > /dev/null 2>&1
 rm -rf gpurun_out/r2i/prof
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/r2i/pmc_f -o b -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/r2i/pmc_f.log 2>&1
