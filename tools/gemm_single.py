@@ -3,6 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distil_whisper_amd.ops_hip import HipOps
 ops = HipOps("cuda:0")
+if os.environ.get("DW_V"): ops.lib.dw_debug_set(0, int(os.environ["DW_V"]))
 M, N, K = 48000, int(os.environ.get("N", 5120)), int(os.environ.get("K", 1280))
 ta = tb = bool(int(os.environ.get("TT", "0")))
 a = (torch.randn((K, M) if ta else (M, K), device="cuda")).bfloat16()
