@@ -17,6 +17,8 @@
 //     no transposed copies of activations or weights are ever materialised in HBM;
 //   * blockIdx is remapped so that each XCD (private 4 MiB L2) walks a contiguous range of output tiles.
 #include "gemm_common.h"
+#include <mutex>
+#include <unordered_map>
 
 bool dw_gemm_skinny_ok(const GemmP& p, int trans_a, int trans_b);   // gemm_skinny.hip
 int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
@@ -44,6 +46,25 @@ int g_gemm_persistent = 1;
 // Every kernel produces bit-identical results (same fp32 chain over k per output element): tests/test_kernels_gpu.py.
 static int g_gemm_variant = 119;
 int g_gemm_strip = 0;
+int g_gemm_cus = 256;
+static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
+
+// Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never
+// overlap and the last workgroup of a launch leaves them zeroed).  64 bytes are allocated the first time a stream
+// launches a persistent GEMM; a stream that is being captured at that moment keeps the static hand-out.
+static int* gemm_sched_slot(hipStream_t s) {
+    static std::mutex mu;
+    static std::unordered_map<hipStream_t, int*> slots;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = slots.find(s);
+    if (it != slots.end()) return it->second;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    int* ptr = nullptr;
+    if (hipMalloc((void**)&ptr, 64) != hipSuccess || hipMemset(ptr, 0, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    slots[s] = ptr;
+    return ptr;
+}
 int g_gemm_strip_budget = 8;   // x 512 KiB of L2 for the resident strip of B tiles
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
@@ -55,6 +76,8 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 6) { g_gemm_strip_budget = value; return DW_OK; }
     if (key == 7) { g_decode_fuse_off = value; return DW_OK; }
     if (key == 8) { g_skinny_wide = value; return DW_OK; }
+    if (key == 10) { g_gemm_dynamic = value; return DW_OK; }
+    if (key == 9) { if (value < 8 || value > 256 || (value & 7)) return DW_EINVAL; g_gemm_cus = value; return DW_OK; }
     return DW_EINVAL;
 }
 
@@ -105,6 +128,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.atomic = g->atomic_acc ? 1 : 0;
     if (p.split_k > (g->k >> 6)) p.split_k = g->k >> 6;
     p.slice_stride = 0;
+    p.sched = nullptr;
     p.ln_x = g->ln_x; p.ln_g = g->ln_gamma; p.ln_b = g->ln_beta; p.ld_lnx = g->ld_lnx; p.ln_x_dtype = g->ln_x_dtype;
     p.ln_eps = g->ln_eps;
     p.kv_out = (bf16*)g->kv_out; p.kv_ld = g->kv_ld; p.kv_split = g->kv_split; p.kv_rpb = g->kv_rows_per_batch;
@@ -151,6 +175,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         const bool wp_ok = spanA < 0x7fffffffL && spanB < 0x7fffffffL;
         const int v = g_gemm_variant;
         p.strip = g_gemm_strip;
+        if (g_gemm_dynamic) p.sched = gemm_sched_slot(s);
         auto launch256 = [&](const GemmP& q) -> int {
             if (!g->trans_a && !g->trans_b) {
                 // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at

@@ -29,6 +29,7 @@ struct GemmP {
     bf16* kv_out;          // output columns >= kv_split of row m go to the K/V cache instead of C:
     long kv_ld;            //   kv_out[((m / kv_rpb) * kv_pitch + kv_row0 + m % kv_rpb) * kv_ld + (n - kv_split)]
     int kv_split, kv_rpb, kv_pitch, kv_row0;
+    int* sched;            // persistent kernels: 9 device counters of this stream (dynamic job hand-out), or null
 };
 
 // Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.
@@ -50,6 +51,69 @@ __device__ __forceinline__ void gemm_job_range(const GemmP& p, int& job_first, i
         job_step = gridDim.x >> 3;
         job_first = start + local;
         job_count = local < cnt ? (cnt - local + job_step - 1) / job_step : 0;
+    }
+}
+
+// Job stream of a persistent workgroup.  Static mode (sched == null, or one job per workgroup): the k-th job of local
+// workgroup l of an XCD is job l + k * (workgroups per XCD) of the XCD's range.  Dynamic mode: the workgroups of an XCD
+// draw consecutive jobs of that range from a device counter (one agent-scope atomic per tile, requested a whole tile
+// ahead).  The order in which an XCD's CUs walk the strip is the same, but a workgroup that starts late -- because a
+// communication kernel or a kernel of another stream holds its CU -- no longer owns a fixed share of the tiles: with 8
+// of the 256 CUs taken the step went from 441 to 595 ms with the static hand-out (the 8 late workgroups run their 15
+// tiles after everybody else has finished), 441 -> ~455 ms with the dynamic one (tools/comm_contention.py).  The last
+// workgroup to leave resets the counters for the next launch on the stream.
+struct GemmJobs {
+    int start, cnt;        // this XCD's job range [start, start + cnt)
+    int step, local;       // static mode
+    int cur;               // offset of the current job in the range (>= cnt: none left)
+    int iter;
+    bool dynamic;
+};
+__device__ __forceinline__ int gemm_jobs_fetch(const GemmP& p) {
+    return __hip_atomic_fetch_add(p.sched + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// `slot`: two ints of LDS.  Returns with J.cur = the first job of this workgroup (one barrier in dynamic mode).
+__device__ __forceinline__ void gemm_jobs_begin(const GemmP& p, GemmJobs& J, int* slot) {
+    const int total = p.nwg * p.split_k;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int q = total >> 3, r = total & 7;
+    J.start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    J.iter = 0;
+    if ((int)gridDim.x == total) {           // one job per workgroup (small problems)
+        J.cnt = q + (xcd < r ? 1 : 0);
+        J.local = bid >> 3; J.step = J.cnt > 0 ? J.cnt : 1; J.cur = J.local; J.dynamic = false;
+        J.cnt = J.local < J.cnt ? J.local + 1 : 0;      // exactly one job: offsets [local, local + 1)
+        return;
+    }
+    J.cnt = q + (xcd < r ? 1 : 0);
+    J.step = gridDim.x >> 3;
+    J.local = bid >> 3;
+    J.dynamic = p.sched != nullptr;
+    if (J.dynamic) {
+        if (threadIdx.x == 0) slot[0] = gemm_jobs_fetch(p);
+        __syncthreads();
+        J.cur = slot[0];
+    } else {
+        J.cur = J.local;
+    }
+}
+// at the top of a tile: request the job after this one (dynamic mode; the answer is read a whole tile later)
+__device__ __forceinline__ void gemm_jobs_prefetch(const GemmP& p, GemmJobs& J, int* slot) {
+    if (J.dynamic && threadIdx.x == 0) slot[(J.iter + 1) & 1] = gemm_jobs_fetch(p);
+}
+// after the barrier that ends a tile
+__device__ __forceinline__ void gemm_jobs_advance(GemmJobs& J, const int* slot) {
+    ++J.iter;
+    J.cur = J.dynamic ? slot[J.iter & 1] : J.cur + J.step;
+}
+__device__ __forceinline__ void gemm_jobs_end(const GemmP& p, const GemmJobs& J) {
+    if (J.dynamic && threadIdx.x == 0) {
+        const int done = __hip_atomic_fetch_add(p.sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (int)gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(p.sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -81,6 +145,9 @@ __device__ __forceinline__ void gemm_job_decode(const GemmP& p, int id, int& tm,
 // budget of the XCD's 4 MiB L2 (g_gemm_strip_budget, units of 512 KiB), the whole row when fewer than 2 fit or the row is
 // not wider than that.  `override` > 0 (dw_debug_set key 1) forces a width.
 extern int g_gemm_strip_budget;
+// CUs the persistent 256-tile kernels occupy (multiple of 8, default all 256; dw_debug_set key 9).  With a communication
+// kernel resident on some CUs a 256-workgroup grid would need a second round for the workgroups that did not fit.
+extern int g_gemm_cus;
 inline int gemm_strip_width(int k, int tiles_n, int override_) {
     if (override_ > 0) return override_;
     const long tile_bytes = 256L * k * 2;

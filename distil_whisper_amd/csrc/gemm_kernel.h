@@ -22,11 +22,13 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 ? 2 : 1) * WM * WN / 4) vo
     const int wm0 = (wave / WN) * TM;
     const int wn0 = (wave % WN) * TN;
 
-    int job_first, job_count, job_step;
-    gemm_job_range(p, job_first, job_count, job_step);
-  for (int job = 0; job < job_count; ++job) {
-    int tm, tn, ks;
-    gemm_job_decode(p, job_first + job * job_step, tm, tn, ks);
+    __shared__ int job_slot[2];
+    GemmJobs jobs;
+    gemm_jobs_begin(p, jobs, job_slot);
+  while (jobs.cur < jobs.cnt) {
+      gemm_jobs_prefetch(p, jobs, job_slot);
+      int tm, tn, ks;
+      gemm_job_decode(p, jobs.start + jobs.cur, tm, tn, ks);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane source pointers of the staging loads (advance by one K-step per iteration) ----
@@ -200,7 +202,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 128 ? 2 : 1) * WM * WN / 4) vo
     }
     gemm_epilogue<FM, FN, TN, ((BM == 128 ? 2 : 1) * NW >= 16 ? 2 : 0)>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
     __syncthreads();  // the LDS patches are reused as operand buffers by the next job
+    gemm_jobs_advance(jobs, job_slot);
   }  // job loop
+  gemm_jobs_end(p, jobs);
 }
 
 // launch knobs owned by gemm.hip (dw_debug_set)
@@ -216,7 +220,7 @@ static int launch_tile(const GemmP& p0, int ta, int tb, hipStream_t s) {
     p.strip = gemm_strip_width(p.k, p.tiles_n, g_gemm_strip);
     // persistent launch for the 256-tile (one workgroup per CU, 256 CUs): only when there are more jobs than CUs
     int nblk = p.nwg * p.split_k;
-    if (BM == 256 && nblk > 256 && g_gemm_persistent) nblk = 256;
+    if (BM == 256 && nblk > g_gemm_cus && g_gemm_persistent) nblk = g_gemm_cus;
     dim3 grid(nblk), block(64 * WM * WN);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, VAR>), grid, block, 0, s, p);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, VAR>), grid, block, 0, s, p);

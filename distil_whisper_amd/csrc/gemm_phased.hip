@@ -72,11 +72,13 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmP p) {
         for (int kk = 0; kk < 4; ++kk) foff[kk] = row * 128 + ((((kk << 1) | (lane >> 5)) ^ swz7(row)) << 4);
     }
 
-    int job_first, job_count, job_step;
-    gemm_job_range(p, job_first, job_count, job_step);
-    for (int job = 0; job < job_count; ++job) {
+    __shared__ int job_slot[2];
+    GemmJobs jobs;
+    gemm_jobs_begin(p, jobs, job_slot);
+    while (jobs.cur < jobs.cnt) {
+        gemm_jobs_prefetch(p, jobs, job_slot);
         int tm, tn, ks;
-        gemm_job_decode(p, job_first + job * job_step, tm, tn, ks);
+        gemm_job_decode(p, jobs.start + jobs.cur, tm, tn, ks);
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- per-lane DMA sources: 2 pieces (1 KB) per region per wave, piece j = 2 * wave + i of the region ----
@@ -242,7 +244,9 @@ __global__ __launch_bounds__(512, 2) void gemm_phased_kernel(const GemmP p) {
         // (every DMA has landed: the last phases waited with vmcnt(0); gemm_epilogue starts with a full barrier)
         gemm_epilogue<FM, FN, TN, 2>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
         __syncthreads();   // the LDS patches are reused as operand buffers by the next job
+        gemm_jobs_advance(jobs, job_slot);
     }
+    gemm_jobs_end(p, jobs);
 }
 
 // One build is kept: row-major A, k-major B (the dX GEMMs), wave rows staggered, no s_setprio -- the measured best of the
@@ -258,7 +262,7 @@ int dw_gemm_phased_launch(const GemmP& p0, int ta, int tb, hipStream_t s) {
     p.nwg = tiles_m * p.tiles_n;
     p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
-    if (nblk > 256) nblk = 256;
+    if (nblk > g_gemm_cus) nblk = g_gemm_cus;
     hipLaunchKernelGGL((gemm_phased_kernel<false, true, 0, 1>), dim3(nblk), dim3(512), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;

@@ -45,11 +45,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * TN;
 
-    int job_first, job_count, job_step;
-    gemm_job_range(p, job_first, job_count, job_step);
-    for (int job = 0; job < job_count; ++job) {
+    __shared__ int job_slot[2];
+    GemmJobs jobs;
+    gemm_jobs_begin(p, jobs, job_slot);
+    while (jobs.cur < jobs.cnt) {
+        gemm_jobs_prefetch(p, jobs, job_slot);
         int tm, tn, ks;
-        gemm_job_decode(p, job_first + job * job_step, tm, tn, ks);
+        gemm_job_decode(p, jobs.start + jobs.cur, tm, tn, ks);
         const int m0 = tm * BM, n0 = tn * BN;
 
         // ---- DMA sources: uniform base (advanced per K tile) + per-lane byte offset (loop invariant) ----
@@ -234,7 +236,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
 
         gemm_epilogue<FM, FN, TN, 8>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
         __syncthreads();   // the LDS patches are reused as operand buffers by the next job
+        gemm_jobs_advance(jobs, job_slot);
     }
+    gemm_jobs_end(p, jobs);
 }
 
 template <bool TA, bool TB, int WM, int WN>
@@ -245,7 +249,7 @@ static int launch_wp(const GemmP& p0, hipStream_t s) {
     p.nwg = tiles_m * p.tiles_n;
     p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
-    if (nblk > 256) nblk = 256;
+    if (nblk > g_gemm_cus) nblk = g_gemm_cus;
     hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;

@@ -142,6 +142,33 @@ def test_gemm_pipelined_variants_are_bit_identical(ops, ref, variant, ta, tb):
         ops.lib.dw_debug_set(0, 119)
 
 
+def test_gemm_dynamic_job_handout_is_invisible(ops, ref):
+    """Persistent 256-tile kernels draw their tiles from per-XCD device counters (dw_debug_set key 10; the last
+    workgroup resets them): the tile -> workgroup assignment changes, the results must not -- three launches in a row
+    (the counters must come back to zero), every operand layout, a grid smaller than the CU count (key 9), and a side
+    stream with its own counters."""
+    M, N, K = 9000, 2048, 128      # 288 tiles on 256 workgroups
+    try:
+        for ta, tb in ((False, False), (False, True), (True, True)):
+            a = rnd((K, M) if ta else (M, K), 0.5, seed=81)
+            b = rnd((K, N) if tb else (N, K), 0.1, seed=82)
+            ops.lib.dw_debug_set(10, 0)
+            want = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, tile=256).clone()
+            ops.lib.dw_debug_set(10, 1)
+            for cus in (256, 64, 256):
+                ops.lib.dw_debug_set(9, cus)
+                for rep in range(3):
+                    assert torch.equal(ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, tile=256), want)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                got = ops.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32, tile=256)
+            torch.cuda.current_stream().wait_stream(side)
+            assert torch.equal(got, want)
+    finally:
+        ops.lib.dw_debug_set(9, 256); ops.lib.dw_debug_set(10, 1)
+
+
 @pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,n_new", [(1, 1), (16, 1), (12, 3), (32, 2)])
 def test_gemm_skinny_layernorm_on_load_and_kv_append(ops, ref, xdtype, M, n_new):
