@@ -258,3 +258,109 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
             ct["t"] = min(ct["t"], L + n_ok)
             ca["t"] = min(ca["t"], L + n_ok)
     return ids, drafted, accepted
+
+
+def beam_search_decode(engine, enc_out, prompt_ids, max_new_tokens, num_beams, eos_token_id, pad_token_id=None,
+                       suppress_tokens=None, begin_suppress_tokens=None, min_new_tokens=0, length_penalty=1.0,
+                       early_stopping=False, timestamp_rules=None):
+    """Beam search over the KV-cache decoder: `generate(num_beams=k)` of the reference (run_eval.py:143, 693;
+    run_distillation.py:1428-1436; TF:generation/utils.py `_beam_search`, the vectorised v5 algorithm) -- per step the
+    log-softmax of every live beam plus its running score, the top 2k continuations per utterance, the k best open ones
+    carried on (their K/V cache rows gathered in place), finished ones merged into the k best finished hypotheses
+    under the length penalty, and the early-stopping heuristic of `early_stopping` in {False, True, "never"}.
+    The decoder passes are the engine's cached passes over B * k rows (prompt prefill in one multi-token pass, then
+    token steps); the bookkeeping is index arithmetic on [B, 2k] tensors on the device.
+    prompt_ids int64 [B, P] -> sequences int64 [B, P + n] (best finished hypothesis per row, padded with pad_token_id)."""
+    dev = prompt_ids.device
+    d = engine.dims
+    B, P = prompt_ids.shape
+    nb, V = int(num_beams), d.vocab
+    max_length = P + int(max_new_tokens)
+    if eos_token_id is None:
+        raise ValueError("beam search needs eos_token_id")
+    eos = int(eos_token_id)
+    fill = int(pad_token_id) if pad_token_id is not None else eos
+    keep = 2 * nb                                       # (number of EOS ids + 1) * num_beams continuations per utterance
+    neg = -1.0e9
+
+    def mask_of(ids):
+        m = torch.zeros(V, dtype=torch.bool, device=dev)
+        if ids:
+            m[torch.as_tensor(list(ids), dtype=torch.long, device=dev)] = True
+        return m
+    sup, bsup = mask_of(suppress_tokens), mask_of(begin_suppress_tokens)
+
+    def gather(t, idx):                                  # t [B, n, ...], idx [B, m] -> [B, m, ...]
+        ix = idx
+        while ix.dim() < t.dim():
+            ix = ix.unsqueeze(-1)
+        return torch.gather(t, 1, ix.expand(*idx.shape, *t.shape[2:]))
+
+    Lk, D = d.max_src, d.d_model
+    enc_rep = enc_out[:B * Lk].view(B, Lk, D).repeat_interleave(nb, 0).reshape(B * nb * Lk, D).contiguous()
+    cache = engine.decode_init(enc_rep, B * nb, max_length)
+    running = torch.full((B, nb, max_length), fill, dtype=torch.long, device=dev)
+    running[:, :, :P] = prompt_ids[:, None, :]
+    sequences = running.clone()
+    run_scores = torch.zeros((B, nb), dtype=torch.float32, device=dev)
+    run_scores[:, 1:] = neg
+    beam_scores = torch.full((B, nb), neg, dtype=torch.float32, device=dev)
+    finished = torch.zeros((B, nb), dtype=torch.bool, device=dev)
+    lengths = torch.zeros((B, nb), dtype=torch.long, device=dev)          # generated tokens of the finished hypotheses
+    unsat = torch.ones((B, 1), dtype=torch.bool, device=dev)
+    top_mask = torch.cat([torch.ones(nb, dtype=torch.bool, device=dev), torch.zeros(keep - nb, dtype=torch.bool, device=dev)])
+    cur = P
+    logits = engine.decode_multi(running[:, :, :P].reshape(B * nb, P), cache).view(B * nb, P, -1)[:, -1, :V]
+    while True:
+        lp = torch.log_softmax(logits.float(), dim=-1)
+        flat = running[:, :, :cur].reshape(B * nb, cur)
+        if cur - P < int(min_new_tokens):
+            lp[:, eos] = float("-inf")
+        if cur == P and bool(bsup.any()):
+            lp = lp.masked_fill(bsup[None, :], float("-inf"))
+        if bool(sup.any()):
+            lp = lp.masked_fill(sup[None, :], float("-inf"))
+        if timestamp_rules is not None:
+            lp = apply_timestamp_rules(lp, flat, cur, timestamp_rules["begin_index"],
+                                       timestamp_rules["no_timestamps_token_id"], eos,
+                                       timestamp_rules.get("max_initial_timestamp_index"))
+        acc = (lp.view(B, nb, V) + run_scores[:, :, None]).reshape(B, nb * V)
+        top_lp, top_ix = torch.topk(acc, k=keep)
+        src_beam, tok = top_ix // V, top_ix % V
+        top_seq = gather(running, src_beam)
+        top_seq[:, :, cur] = tok
+        hits = (tok == eos) | (cur + 1 >= max_length)
+        # open beams carried to the next step
+        open_lp = top_lp + hits.float() * neg
+        nxt = torch.topk(open_lp, k=nb)[1]
+        running = gather(top_seq, nxt)
+        run_scores = gather(open_lp, nxt)
+        src_rows = (gather(src_beam, nxt) + torch.arange(B, device=dev)[:, None] * nb).reshape(-1)
+        # finished hypotheses: only the best num_beams continuations may finish
+        just = hits & top_mask[None, :]
+        fin_lp = top_lp / float((cur + 1 - P) ** length_penalty)
+        fin_lp = fin_lp + (finished.all(-1, keepdim=True) & (early_stopping is True)).float() * neg
+        fin_lp = fin_lp + (~unsat).float() * neg
+        fin_lp = fin_lp + (~just).float() * neg
+        m_seq = torch.cat([sequences, top_seq], 1)
+        m_sc = torch.cat([beam_scores, fin_lp], 1)
+        m_fin = torch.cat([finished, just], 1)
+        m_len = torch.cat([lengths, torch.full((B, keep), cur + 1 - P, dtype=torch.long, device=dev)], 1)
+        best = torch.topk(m_sc, k=nb)[1]
+        sequences, beam_scores, finished, lengths = gather(m_seq, best), gather(m_sc, best), gather(m_fin, best), gather(m_len, best)
+        # the carried beams' K/V rows (positions < cur are live: the next pass appends position cur)
+        for kvc in cache["self"]:
+            v = kvc.view(B * nb, max_length, -1)
+            v[:, :cur].copy_(v[src_rows, :cur])
+        cur += 1
+        # early-stopping heuristic and loop condition (TF `_check_early_stop_heuristic`, `_beam_search_has_unfinished_sequences`)
+        hyp_len = (max_length - P) if (early_stopping == "never" and length_penalty > 0.0) else (cur - P)
+        best_running = run_scores[:, :1] / float(hyp_len ** length_penalty)
+        worst_fin = torch.where(finished, beam_scores.min(1, keepdim=True)[0], torch.full_like(beam_scores, neg))
+        unsat = unsat & (best_running > worst_fin).any(-1, keepdim=True)
+        go_on = bool(unsat.any()) and not (bool(finished.all()) and early_stopping is True) and not bool(hits.all())
+        if not go_on:
+            break
+        logits = engine.decode_step(running[:, :, cur - 1].reshape(B * nb, 1).contiguous(), cache)[:, :V]
+    out_len = P + int(lengths[:, 0].max().item())
+    return sequences[:, 0, :out_len].contiguous()

@@ -46,7 +46,7 @@ _CONFIG_KEYS = ("max_length", "max_new_tokens", "min_new_tokens", "num_beams", "
                 "lang_to_id", "task_to_id", "is_multilingual", "return_timestamps", "language", "task",
                 "forced_decoder_ids", "num_return_sequences", "use_cache", "output_scores", "return_dict_in_generate",
                 "num_assistant_tokens", "prompt_condition_type", "length_penalty", "repetition_penalty",
-                "no_repeat_ngram_size", "temperature")
+                "no_repeat_ngram_size", "temperature", "early_stopping", "num_beam_groups")
 
 
 class GenerationConfig:

@@ -526,7 +526,8 @@ class WhisperForConditionalGeneration(nn.Module):
         min-new-tokens / timestamp logits rules, `assistant_model` (speculative decoding), `encoder_outputs`.
         The token loop is decoding.GreedyDecoder (KV cache; `use_graphs` replays the per-position launch sequence from
         HIP graphs; `use_cache=False` re-decodes the whole prefix every step and exists as a cross-check).
-        Arguments this path does not implement RAISE (nothing is silently ignored): beam search, sampling /
+        `num_beams > 1` runs decoding.beam_search_decode (TF `_beam_search`).
+        Arguments this path does not implement RAISE (nothing is silently ignored): group beam search, sampling /
         temperature fallback, inputs longer than 30 s (sequential long-form; use longform.LongFormTranscriber for the
         chunked algorithm of run_eval.py:566-576), token-level timestamps, custom logits processors.
         Returns what the reference returns: the generated tokens only (decoder prompt and EOS stripped, right-padded
@@ -559,15 +560,17 @@ class WhisperForConditionalGeneration(nn.Module):
         for k in G._CONFIG_KEYS:
             if k in kwargs and kwargs[k] is not None:
                 setattr(gc, k, kwargs[k])
-        if (getattr(gc, "num_beams", 1) or 1) != 1:
-            raise NotImplementedError(f"num_beams={gc.num_beams}: beam search is not implemented on the MI355X path")
+        num_beams = int(getattr(gc, "num_beams", 1) or 1)
+        if num_beams > 1 and (getattr(gc, "num_beam_groups", 1) or 1) != 1:
+            raise NotImplementedError("group beam search is not implemented on the MI355X path")
         if getattr(gc, "do_sample", False):
             raise NotImplementedError("do_sample=True is not implemented on the MI355X path")
         if (getattr(gc, "num_return_sequences", 1) or 1) != 1:
             raise NotImplementedError("num_return_sequences > 1 is not implemented on the MI355X path")
-        for k in ("repetition_penalty", "length_penalty"):
-            if getattr(gc, k, None) not in (None, 1.0):
-                raise NotImplementedError(f"{k} is not implemented on the MI355X path")
+        if getattr(gc, "repetition_penalty", None) not in (None, 1.0):
+            raise NotImplementedError("repetition_penalty is not implemented on the MI355X path")
+        if num_beams == 1 and getattr(gc, "length_penalty", None) not in (None, 1.0):
+            raise NotImplementedError("length_penalty without beam search is not implemented on the MI355X path")
         if getattr(gc, "no_repeat_ngram_size", 0):
             raise NotImplementedError("no_repeat_ngram_size is not implemented on the MI355X path")
         if gc.decoder_start_token_id is None:
@@ -635,7 +638,24 @@ class WhisperForConditionalGeneration(nn.Module):
             use_cache = True
         if use_graphs is None:
             use_graphs = False
-        if assistant_model is not None:
+        if num_beams > 1:
+            # beam search (run_eval.py:143, 693; run_distillation.py:1428-1436): TF `_beam_search` on the KV-cache decoder
+            from .decoding import beam_search_decode
+            if assistant_model is not None:
+                raise ValueError("assistant_model cannot be combined with beam search (TF raises the same)")
+            if eos is None:
+                raise ValueError("beam search needs eos_token_id in the generation config")
+            ts_rules = None
+            if gc.return_timestamps:
+                ts_rules = dict(begin_index=P, no_timestamps_token_id=int(gc.no_timestamps_token_id),
+                                max_initial_timestamp_index=getattr(gc, "max_initial_timestamp_index", None))
+            lp = getattr(gc, "length_penalty", None)
+            es = getattr(gc, "early_stopping", False)
+            seqs = beam_search_decode(eng, enc, ids, max_new, num_beams, eos, pad_token_id=pad, suppress_tokens=suppress,
+                                      begin_suppress_tokens=begin_suppress, min_new_tokens=min_new,
+                                      length_penalty=1.0 if lp is None else float(lp),
+                                      early_stopping=False if es is None else es, timestamp_rules=ts_rules)
+        elif assistant_model is not None:
             # speculative decoding (run_eval.py:578-599, 706-707): the assistant drafts, this model verifies.  An
             # assistant with this model's encoder dimensions re-uses the encoder output (the distilled student keeps
             # a frozen copy of the teacher's encoder); otherwise it encodes the features itself.

@@ -193,7 +193,25 @@ def test_generate_matches_transformers_live_and_rejects_unsupported_arguments():
         got = model.generate(feats, return_dict_in_generate=True, **kw).sequences
         assert got.tolist() == ref.tolist(), kw
         assert model.generate(feats, **kw).tolist() == ref_plain.tolist(), kw
-    for bad, exc in ((dict(num_beams=4), NotImplementedError), (dict(do_sample=True), NotImplementedError),
+    # beam search (TF `_beam_search`), live: finishing on EOS is forced by declaring a token the model likes to emit the
+    # EOS, so hypotheses finish at different lengths and the length penalty / early-stopping branches decide
+    hf = gd.hf_model(gd.CFG_T, sd_t, **fields)
+    with torch.no_grad():
+        first = hf.generate(feats, return_dict_in_generate=True, max_new_tokens=4, language="en").sequences
+    frequent = int(first[0, -2])
+    for kw in (dict(num_beams=2, max_new_tokens=6, language="en"),
+               dict(num_beams=4, max_new_tokens=8, language="de", eos_token_id=frequent),
+               dict(num_beams=3, max_new_tokens=8, language="en", eos_token_id=frequent, length_penalty=2.0,
+                    early_stopping=True),
+               dict(num_beams=3, max_new_tokens=7, language="en", eos_token_id=frequent, length_penalty=0.5,
+                    early_stopping="never")):
+        with torch.no_grad():
+            ref = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, return_dict_in_generate=True, **kw).sequences
+            ref_plain = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, **kw)
+        got = model.generate(feats, return_dict_in_generate=True, **kw).sequences
+        assert got.tolist() == ref.tolist(), (kw, got.tolist(), ref.tolist())
+        assert model.generate(feats, **kw).tolist() == ref_plain.tolist(), kw
+    for bad, exc in ((dict(num_beams=4, num_beam_groups=2), NotImplementedError), (dict(do_sample=True), NotImplementedError),
                      (dict(temperature=(0.2, 0.4)), NotImplementedError),
                      (dict(condition_on_prev_tokens=True), NotImplementedError),
                      (dict(no_speech_threshold=0.6), NotImplementedError),
