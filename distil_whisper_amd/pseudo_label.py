@@ -45,10 +45,12 @@ class PseudoLabeller:
 
     def __init__(self, model, feature_extractor, batch_size=16, max_new_tokens=255, prompt_ids=None, eos_token_id=None,
                  timestamp_rules=None, use_graphs=None, rank=0, world=1, suppress_tokens=None,
-                 begin_suppress_tokens=None):
+                 begin_suppress_tokens=None, num_beams=1):
         self.model, self.fe = model, feature_extractor
         self.B, self.max_new = int(batch_size), int(max_new_tokens)
         self.rank, self.world = rank, world
+        self.num_beams = int(num_beams)      # generation_num_beams of run_pseudo_labelling.py:835-843
+        self._beam_kw = dict(suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens)
         d = model.dims
         dev = model.ops.device
         self.dev = dev
@@ -56,6 +58,7 @@ class PseudoLabeller:
                                       dtype=torch.long, device=dev)
         if timestamp_rules is not None:
             timestamp_rules = dict(timestamp_rules, begin_index=len(self.prompt))
+        self._ts_rules = timestamp_rules
         self.eos = eos_token_id
         self.decoder = GreedyDecoder(model.engine, self.B, len(self.prompt) + self.max_new, eos_token_id=eos_token_id,
                                      suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens,
@@ -85,7 +88,12 @@ class PseudoLabeller:
                     pos += n
             feats = model.ops.logmel(self._wave, self.fe._filt)
             enc, _ = model.engine.encode(feats, save=False)
-            ids = self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
+            if self.num_beams > 1:
+                from .decoding import beam_search_decode
+                ids = beam_search_decode(model.engine, enc, prompt, self.max_new, self.num_beams, self.eos,
+                                         timestamp_rules=self._ts_rules, **self._beam_kw).cpu().numpy()
+            else:
+                ids = self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
             for r, pi in enumerate(batch):
                 row = ids[r, self.prompt.numel():].tolist()
                 if self.eos is not None and self.eos in row:

@@ -245,3 +245,22 @@ def test_pseudo_labeller_equals_generate_on_packed_audio():
     a = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=6, eos_token_id=eos, use_graphs=False, rank=0, world=2)(audios, spk)[0]
     b = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=6, eos_token_id=eos, use_graphs=False, rank=1, world=2)(audios, spk)[0]
     assert [x if x is not None else y for x, y in zip(a, b)] == toks and a[2] is None and b[0] is None
+
+
+def test_pseudo_labeller_with_beam_search_equals_generate():
+    """generation_num_beams > 1 of the pseudo-labelling script (run_pseudo_labelling.py:835-843): the pack decoder runs
+    decoding.beam_search_decode; same tokens as generate(num_beams=) on the packed audio."""
+    from distil_whisper_amd.pseudo_label import PseudoLabeller
+    cfg, model, fe = _model()
+    rng = np.random.default_rng(12)
+    audios = [0.1 * rng.standard_normal(n).astype(np.float32) for n in (200_000, 150_000, 300_000)]
+    eos = cfg.vocab - 3
+    pl = PseudoLabeller(model, fe, batch_size=2, max_new_tokens=5, eos_token_id=eos, use_graphs=False, num_beams=2)
+    toks, packs, _ = pl(audios, [0, 0, 1])
+    assert packs == [[0, 1], [2]]
+    for p, t in zip(packs, toks):
+        wave = np.concatenate([audios[i] for i in p])
+        f = fe(wave, sampling_rate=16000, return_tensors="pt").input_features
+        ref = _seq(model, f, max_new_tokens=5, num_beams=2, eos_token_id=eos)[0, 1:].tolist()
+        ref = ref[:ref.index(eos)] if eos in ref else ref
+        assert t == ref
