@@ -282,3 +282,39 @@ def strip_and_pad(sequences, prompt_len, eos_token_id, pad_token_id):
         if r:
             out[i, : len(r)] = torch.as_tensor(r, dtype=torch.long, device=sequences.device)
     return out
+
+
+def retrieve_segment(seq, timestamp_begin, seek_num_frames, time_offset=0.0, time_precision=0.02,
+                     time_precision_features=0.01, input_stride=2):
+    """`WhisperGenerationMixin._retrieve_segment` (TF:generation_whisper.py:1977-2075) on a list of token ids: split the
+    tokens generated for one window at consecutive timestamp pairs ("end of segment" predictions) and say how many mel
+    frames the window consumed.  -> (segments [{"start", "end", "tokens"}], segment_offset in frames)."""
+    n = len(seq)
+    ts = [t >= timestamp_begin for t in seq]
+    single_ending = ts[-2:] == [False, True]
+    pairs = [i + 1 for i in range(n - 1) if ts[i] and ts[i + 1]]
+    if pairs:
+        slices = list(pairs)
+        if single_ending:
+            slices.append(n)
+        else:
+            slices[-1] += 1            # keep the last timestamp in the last segment: it marks "no single ending"
+        segments, last = [], 0
+        for i, cur in enumerate(slices):
+            sl = seq[last:cur]
+            is_last = i == len(slices) - 1
+            end_tok = sl[-1] if (not is_last or single_ending) else sl[-2]
+            segments.append({"start": time_offset + (sl[0] - timestamp_begin) * time_precision,
+                             "end": time_offset + (end_tok - timestamp_begin) * time_precision, "tokens": sl})
+            last = cur
+        if single_ending:
+            offset = int(seek_num_frames)          # a single timestamp at the end: no speech after it
+        else:
+            offset = (seq[last - 2] - timestamp_begin) * input_stride   # resume at the last predicted end of segment
+        return segments, int(offset)
+    stamps = [t for t in seq if t >= timestamp_begin]
+    last_pos = int(seek_num_frames * time_precision_features / time_precision)
+    if stamps and stamps[-1] != timestamp_begin:
+        last_pos = stamps[-1] - timestamp_begin
+    return [{"start": time_offset, "end": time_offset + last_pos * time_precision, "tokens": list(seq)}], \
+        int(seek_num_frames)

@@ -526,10 +526,12 @@ class WhisperForConditionalGeneration(nn.Module):
         min-new-tokens / timestamp logits rules, `assistant_model` (speculative decoding), `encoder_outputs`.
         The token loop is decoding.GreedyDecoder (KV cache; `use_graphs` replays the per-position launch sequence from
         HIP graphs; `use_cache=False` re-decodes the whole prefix every step and exists as a cross-check).
-        `num_beams > 1` runs decoding.beam_search_decode (TF `_beam_search`).
+        `num_beams > 1` runs decoding.beam_search_decode (TF `_beam_search`).  `return_timestamps=True` (without
+        `force_unique_generate_call`) and inputs longer than 30 s run the reference's timestamp seek loop
+        (`_generate_seek_loop`, TF:784-903) at temperature 0.
         Arguments this path does not implement RAISE (nothing is silently ignored): group beam search, sampling /
-        temperature fallback, inputs longer than 30 s (sequential long-form; use longform.LongFormTranscriber for the
-        chunked algorithm of run_eval.py:566-576), token-level timestamps, custom logits processors.
+        temperature fallback and its thresholds, `condition_on_prev_tokens`, token-level timestamps, custom logits
+        processors.
         Returns what the reference returns: the generated tokens only (decoder prompt and EOS stripped, right-padded
         with pad_token_id), or with `return_dict_in_generate=True` / `force_unique_generate_call=True` the full
         sequences (prompt + generated, as GenerationMixin emits them)."""
@@ -545,9 +547,9 @@ class WhisperForConditionalGeneration(nn.Module):
             raise NotImplementedError("return_token_timestamps / return_segments are not implemented on the MI355X path")
         if condition_on_prev_tokens or compression_ratio_threshold is not None or logprob_threshold is not None or \
                 no_speech_threshold is not None:
-            raise NotImplementedError("the sequential long-form options (condition_on_prev_tokens, compression_ratio_"
-                                      "threshold, logprob_threshold, no_speech_threshold) are not implemented on the "
-                                      "MI355X path; use longform.LongFormTranscriber (chunked long-form)")
+            raise NotImplementedError("the temperature-fallback options of sequential long-form (condition_on_prev_tokens, "
+                                      "compression_ratio_threshold, logprob_threshold, no_speech_threshold) are not "
+                                      "implemented on the MI355X path: the seek loop runs at temperature 0")
         temps = list(temperature) if isinstance(temperature, (list, tuple)) else [temperature]
         if temps[0] is not None and temps[0] > 0.0:
             raise NotImplementedError("sampling (temperature > 0) is not implemented on the MI355X path")
@@ -590,10 +592,17 @@ class WhisperForConditionalGeneration(nn.Module):
             if input_features is None:
                 raise ValueError("input_features or encoder_outputs are required")
             frames = input_features.shape[-1]
-            if frames > 2 * d.max_src:
-                raise NotImplementedError(
-                    f"{frames} mel frames (> 30 s): sequential long-form generation is not implemented on the MI355X "
-                    "path; use longform.LongFormTranscriber (the chunked algorithm of run_eval.py:566-576)")
+            rt = return_timestamps if return_timestamps is not None else bool(getattr(gc, "return_timestamps", False))
+            if frames > 2 * d.max_src and not rt:
+                raise ValueError(
+                    "You have passed more than 3000 mel input features (> 30 seconds) which automatically enables "
+                    "long-form generation which requires the model to predict timestamp tokens. Please either pass "
+                    "`return_timestamps=True` or make sure to pass no more than 3000 mel input features.")
+            if frames > 2 * d.max_src or (rt and not force_unique_generate_call):
+                # the reference's seek loop (TF:784-903): with timestamps every window is decoded until its audio is
+                # consumed, also when the input is a single 30 s window (run_pseudo_labelling.py:861-996 calls it so)
+                return self._generate_seek_loop(input_features, attention_mask, gc, language, task, is_multilingual,
+                                                prompt_ids, kwargs, use_graphs, return_dict_in_generate, num_beams)
             if frames != 2 * d.max_src:
                 raise ValueError(f"Whisper expects the mel input features to be of length {2 * d.max_src}, but found "
                                  f"{frames}. Make sure to pad the input mel features to {2 * d.max_src}.")
@@ -705,6 +714,134 @@ class WhisperForConditionalGeneration(nn.Module):
         if force_unique_generate_call:
             return seqs
         return G.strip_and_pad(seqs, P, eos, pad)
+
+    def seek_decode(self, input_features, max_frames, init_tokens, lengths, eos, pad, no_timestamps_token_id,
+                    max_initial_timestamp_index=None, suppress_tokens=None, begin_suppress_tokens=None,
+                    detect_language=None):
+        """The seek loop itself (TF:generation_whisper.py:784-903, temperature 0): input_features [B, n_mels, frames],
+        max_frames[b] = valid mel frames of utterance b.  init_tokens: the decoder prompt rows (list of B lists) or a
+        callable(detect) building them (detect() = language ids from the first window); lengths(P) -> (max_new_tokens,
+        min_new_tokens) per pass.  Every pass encodes the next <= 30 s window of each unfinished utterance, decodes it
+        greedily with the timestamp rules and advances that utterance by what `retrieve_segment` says it consumed.
+        -> per utterance the list of segments {"start", "end", "tokens"}."""
+        from . import generation as G
+        from .decoding import GreedyDecoder
+        eng, d = self.engine, self.dims
+        B = input_features.shape[0]
+        dev = input_features.device
+        W = 2 * d.max_src
+        feats = input_features.to(torch.float32)
+        seek = [0] * B
+
+        def window(rows):
+            seg = torch.zeros((len(rows), feats.shape[1], W), dtype=torch.float32, device=dev)
+            for i, b in enumerate(rows):
+                n = min(max_frames[b] - seek[b], W)
+                seg[i, :, :n] = feats[b, :, seek[b]:seek[b] + n]
+            return seg
+        if callable(init_tokens):
+            init = init_tokens(lambda: detect_language(eng.encode(window(list(range(B))), save=False)[0]))
+        else:
+            init = init_tokens
+        P = len(init[0])
+        tb = int(no_timestamps_token_id) + 1
+        ts_rules = dict(begin_index=P, no_timestamps_token_id=int(no_timestamps_token_id),
+                        max_initial_timestamp_index=max_initial_timestamp_index)
+        segments = [[] for _ in range(B)]
+        decoders = {}
+        while any(seek[b] < max_frames[b] for b in range(B)):
+            rows = [b for b in range(B) if seek[b] < max_frames[b]]
+            snf = {b: min(max_frames[b] - seek[b], W) for b in rows}
+            enc, _ = eng.encode(window(rows), save=False)
+            ids = torch.as_tensor([init[b] for b in rows], dtype=torch.long, device=dev)
+            max_new, min_new = lengths(P)
+            key = (len(rows), P + max_new)
+            dec = decoders.get(key)
+            if dec is None:
+                dec = decoders[key] = GreedyDecoder(eng, len(rows), P + max_new, eos_token_id=eos,
+                                                    suppress_tokens=suppress_tokens,
+                                                    begin_suppress_tokens=begin_suppress_tokens, use_graphs=False,
+                                                    timestamp_rules=ts_rules, pad_token_id=pad)
+            out = dec.run(enc, ids, max_new, min_new)[:, P:].tolist()
+            for i, b in enumerate(rows):
+                seq = out[i]
+                if seq and seq[-1] == pad:         # TF:1064-1071: drop the padding (all of it but one EOS when pad == EOS)
+                    npad = sum(1 for x in seq if x == pad) - (1 if pad == eos else 0)
+                    if npad:
+                        seq = seq[:-npad]
+                if seq and seq[-1] == eos:
+                    seq = seq[:-1]
+                segs, offset = G.retrieve_segment(seq, tb, snf[b], time_offset=seek[b] * 0.01)
+                seek[b] += offset
+                segments[b] += segs
+        return segments
+
+    def _generate_seek_loop(self, input_features, attention_mask, gc, language, task, is_multilingual, prompt_ids, kwargs,
+                            use_graphs, return_dict_in_generate, num_beams):
+        """Timestamp-driven multi-pass transcription: `WhisperGenerationMixin.generate` steps 5-7 (TF:745-968) with
+        temperature 0 and no fallback thresholds -- every utterance keeps a `seek` position in mel frames; each pass
+        decodes the next <= 30 s window of every unfinished utterance with the timestamp rules, `retrieve_segment`
+        splits the tokens at consecutive timestamp pairs and advances `seek` to the last predicted end of segment (or
+        past the window).  Inputs of any length ([B, n_mels, frames]; batches of long inputs need `attention_mask`).
+        Returns the concatenated segment tokens per utterance, right-padded with pad_token_id (the reference's plain
+        return value), or a GenerateOutput with `.sequences` and `.segments`."""
+        from . import generation as G
+        eng, d = self.engine, self.dims
+        B, _, frames = input_features.shape
+        dev = input_features.device
+        W = 2 * d.max_src
+        if prompt_ids is not None or kwargs.get("decoder_input_ids") is not None:
+            raise NotImplementedError("prompt_ids / decoder_input_ids with the timestamp seek loop are not implemented on "
+                                      "the MI355X path (pass force_unique_generate_call=True for a single window)")
+        if kwargs.get("assistant_model") is not None or num_beams != 1 or kwargs.get("use_cache", True) is False:
+            raise NotImplementedError("the timestamp seek loop runs greedy search on the KV-cache decoder only")
+        if not hasattr(gc, "no_timestamps_token_id"):
+            raise ValueError("You are trying to return timestamps, but the generation config is not properly set. Make "
+                             "sure to initialize the generation config with the correct attributes that are needed "
+                             "such as `no_timestamps_token_id`.")
+        gc.return_timestamps = True
+        G.set_language_and_task(gc, language, task, is_multilingual)
+        if B > 1 and frames > W and attention_mask is None:
+            raise ValueError("When doing batched long-form audio transcription, make sure to pass an `attention_mask`. "
+                             "You can retrieve the `attention_mask` by doing `processor(audio, ..., "
+                             "return_attention_mask=True)` ")
+        if B > 1 and frames > W:
+            max_frames = [int(x) for x in attention_mask.sum(-1).tolist()]
+        else:
+            max_frames = [frames] * B
+        def detect_on(enc0):
+            return self._detect_language(enc0, B, gc)
+        eos, pad = gc.eos_token_id, gc.pad_token_id
+        if isinstance(eos, (list, tuple)):
+            eos = eos[0]
+        if eos is None:
+            raise ValueError("return_timestamps=True needs eos_token_id in the generation config")
+        if pad is None:
+            pad = eos
+        explicit_max_length = "max_length" in kwargs
+
+        def lengths(P):
+            max_new, min_new = G.resolve_lengths(gc, P, d.max_tgt, explicit_max_length)
+            if gc.max_new_tokens is None:          # TF:1932-1940 mutates max_length on every pass
+                gc.max_length = min(gc.max_length + min(d.max_tgt // 2 - 1, P), d.max_tgt)
+            return max_new, min_new
+        segments = self.seek_decode(input_features, max_frames, lambda det: G.retrieve_init_tokens(gc, B, det), lengths,
+                                    eos, pad, int(gc.no_timestamps_token_id),
+                                    getattr(gc, "max_initial_timestamp_index", None),
+                                    list(gc.suppress_tokens) if gc.suppress_tokens else None,
+                                    list(gc.begin_suppress_tokens) if gc.begin_suppress_tokens else None,
+                                    detect_language=detect_on)
+        rows_out = [[tok for sg in segments[b] for tok in sg["tokens"]] for b in range(B)]
+        width = max((len(r) for r in rows_out), default=0)
+        seqs = torch.full((B, width), pad, dtype=torch.long, device=dev)
+        for b, r in enumerate(rows_out):
+            if r:
+                seqs[b, :len(r)] = torch.as_tensor(r, dtype=torch.long, device=dev)
+        if return_dict_in_generate or getattr(gc, "return_dict_in_generate", False):
+            out = G.GenerateOutput(seqs)
+            out.segments = segments
+            return out
+        return seqs
 
     # -- helpers of generate ----------------------------------------------------------------------------------------
     @staticmethod

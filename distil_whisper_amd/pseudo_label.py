@@ -87,6 +87,17 @@ class PseudoLabeller:
                     self._wave[r, pos:pos + n].copy_(audios[si])
                     pos += n
             feats = model.ops.logmel(self._wave, self.fe._filt)
+            if self._ts_rules is not None and self.num_beams == 1:
+                # generate(..., return_timestamps=True) of the reference is a seek loop (TF:784-903): a pack is decoded
+                # in as many passes as its predicted end-of-segment timestamps require
+                nb = len(batch)
+                segs = model.seek_decode(feats[:nb], [feats.shape[-1]] * nb, [self.prompt.tolist()] * nb,
+                                         lambda P: (self.max_new, 0), self.eos,
+                                         self.eos, self._ts_rules["no_timestamps_token_id"],
+                                         self._ts_rules.get("max_initial_timestamp_index"), **self._beam_kw)
+                for r, pi in enumerate(batch):
+                    out[pi] = [int(t) for sg in segs[r] for t in sg["tokens"]]
+                continue
             enc, _ = model.engine.encode(feats, save=False)
             if self.num_beams > 1:
                 from .decoding import beam_search_decode

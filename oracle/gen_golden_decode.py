@@ -289,6 +289,53 @@ def scenario_beam(seeds, num_beams=3, B=2, max_new_tokens=6, noise=0.06):
                 sequences=rows, plain=plain.tolist(), diverse=True)
 
 
+def scenario_seek(seeds, frames=450, B=2, max_new_tokens=6, noise=0.06):
+    """generate(..., return_timestamps=True) WITHOUT force_unique_generate_call: the reference's seek loop (TF:784-903) --
+    each utterance is decoded window by window, `_retrieve_segment` advances it to the last predicted end of segment.
+    4.5 s inputs keep the number of passes (and of greedy decisions that must survive bf16) small.  Margin: empirical."""
+    from distil_whisper_amd.generation import GenerationConfig
+    from distil_whisper_amd.modeling import WhisperForConditionalGeneration as Ours
+    from oracle.ref_ops import RefOps
+    fields = generation_fields(multilingual=True, suppress=True, timestamps=True)
+    gen_kw = dict(max_new_tokens=max_new_tokens, return_timestamps=True, language="en")
+
+    def ours(sd_t, feats, lowp, sigma_noise, seed):
+        m = Ours(CFG_T, ops=RefOps("cpu", lowp=lowp), state_dict=sd_t)
+        m.generation_config = GenerationConfig.from_any(fields)
+        if sigma_noise:
+            g = torch.Generator().manual_seed(seed)
+            eng = m.engine
+            orig_step, orig_multi = eng.decode_step, eng.decode_multi
+
+            def noisy(fn):
+                def f(ids, cache):
+                    lg = fn(ids, cache).float()
+                    return lg + (torch.rand(lg.shape, generator=g) - 0.5) * sigma_noise
+                return f
+            eng.decode_step, eng.decode_multi = noisy(orig_step), noisy(orig_multi)
+        return m.generate(feats, **gen_kw).tolist()
+
+    for seed in seeds:
+        sd_t = weights(seed)
+        feats = features(seed + 1, B)[..., :frames].contiguous()
+        with torch.no_grad():
+            out = hf_model(CFG_T, sd_t, **fields).generate(feats, return_dict_in_generate=True, output_logits=True, **gen_kw)
+        plain = out["sequences"].tolist()
+        passes = [len(sg) for sg in out["segments"]]
+        if max(passes) < 2 or plain[0] == plain[1]:
+            continue
+        sigma = torch.stack(out["segments"][0][0]["result"]["logits"], 1).float().std().item()
+        ok = ours(sd_t, feats, torch.float32, 0.0, 0) == plain and ours(sd_t, feats, torch.bfloat16, 0.0, 0) == plain
+        for k in range(4):
+            ok = ok and ours(sd_t, feats, torch.float32, noise * sigma, 3000 + k) == plain
+        if ok:
+            return dict(name="timestamps_seek_loop", kind="short", model="teacher", B=B, seed=seed, gen_kwargs=gen_kw,
+                        generation_config=fields, use_encoder_outputs=False, assistant=False, margin=noise, frames=frames,
+                        margin_kind="empirical: invariant under +-noise/2 sigma uniform logit noise",
+                        sequences=None, plain=plain, segments_per_row=passes, diverse=True)
+    raise SystemExit("seek loop: no seed survived: widen the seed search")
+
+
 def scenario_longform(seeds, lengths=(500_000, 200_000), max_new_tokens=4, batch=2):
     """run_eval.py:566-576: ASR pipeline with chunk_length_s=30 -> chunk_iter windows (stride 5 s), feature extractor
     per window, batched generate, `_find_longest_common_sequence` stitching of the text tokens per utterance."""
@@ -328,28 +375,74 @@ def scenario_longform(seeds, lengths=(500_000, 200_000), max_new_tokens=4, batch
 
 
 def scenario_pseudo_label(seeds, lengths=(150_000, 200_000, 100_000, 300_000), speakers=(0, 0, 0, 1),
-                          max_new_tokens=5):
+                          max_new_tokens=5, noise=0.06):
     """run_pseudo_labelling.py:632-673 (packs of consecutive same-speaker samples up to 30 s) + 861-996 (teacher
-    `generate` with timestamps over the packed batch).  The packing rule is the reference function itself, exec'd from
-    the reference tree in tests/test_labels.py; here the packs of this fixed case are [[0, 1, 2], [3]]."""
+    `generate(..., return_timestamps=True)` over the packed batch -- the reference's timestamp SEEK LOOP, TF:784-903: a
+    pack is decoded in as many passes as its predicted end-of-segment timestamps require).  The packing rule is the
+    reference function itself, exec'd from the reference tree in tests/test_labels.py; here the packs of this fixed case
+    are [[0, 1, 2], [3]].  Margin: empirical, as for beam search -- the repo's PseudoLabeller must return the reference's
+    tokens on the CPU restatement in fp32, in bf16 and in fp32 with +-noise/2 sigma uniform logit noise (four draws)."""
     from transformers import WhisperFeatureExtractor
+    from distil_whisper_amd.generation import GenerationConfig
+    from distil_whisper_amd.modeling import WhisperFeatureExtractor as OurFE, WhisperForConditionalGeneration as Ours
+    from distil_whisper_amd.pseudo_label import PseudoLabeller
+    from oracle.ref_ops import RefOps
     fe = WhisperFeatureExtractor(feature_size=80)
     fields = generation_fields(multilingual=True, suppress=True, timestamps=True)
     packs = [[0, 1, 2], [3]]
+    prompt = [SOT, LANG["<|en|>"], TRANSCRIBE]
 
-    def run(seed, final):
+    def ours(sd_t, audios, lowp, sigma_noise, seed):
+        ops = RefOps("cpu", lowp=lowp)
+        m = Ours(CFG_T, ops=ops, state_dict=sd_t)
+        m.generation_config = GenerationConfig.from_any(fields)
+        if sigma_noise:
+            g = torch.Generator().manual_seed(seed)
+            eng = m.engine
+            orig_step, orig_multi = eng.decode_step, eng.decode_multi
+
+            def noisy(fn):
+                def f(ids, cache):
+                    lg = fn(ids, cache).float()
+                    return lg + (torch.rand(lg.shape, generator=g) - 0.5) * sigma_noise
+                return f
+            eng.decode_step, eng.decode_multi = noisy(orig_step), noisy(orig_multi)
+        lab = PseudoLabeller(m, OurFE(feature_size=80, ops=ops), batch_size=2, max_new_tokens=max_new_tokens,
+                             prompt_ids=prompt, eos_token_id=EOS, suppress_tokens=fields["suppress_tokens"],
+                             begin_suppress_tokens=fields["begin_suppress_tokens"],
+                             timestamp_rules=dict(no_timestamps_token_id=NOTIMESTAMPS,
+                                                  max_initial_timestamp_index=fields["max_initial_timestamp_index"]),
+                             use_graphs=False)
+        return lab(audios, list(speakers))[0]
+
+    for seed in seeds:
         sd_t = weights(seed)
         audios = [audio(seed * 10 + i, n) for i, n in enumerate(lengths)]
         packed = [np.concatenate([audios[i] for i in p]) for p in packs]
         feats = torch.as_tensor(np.asarray(fe(packed, sampling_rate=16000, return_tensors="np").input_features))
-        seq, plain, margin = hf_generate(CFG_T, sd_t, fields, feats, max_new_tokens=max_new_tokens,
-                                         return_timestamps=True, language="en", task="transcribe",
-                                         force_unique_generate_call=True)
-        return {"sequences": seq.tolist(), "diverse": diverse(seq.tolist(), 3)}, margin
-    seed, payload, margin = best_seed(run, seeds)
-    return dict(name="pseudo_label_packs", kind="pseudo_label", seed=seed, lengths=list(lengths),
-                speakers=list(speakers), packs=packs, max_new_tokens=max_new_tokens, generation_config=fields,
-                margin=margin, **payload)
+        with torch.no_grad():
+            out = hf_model(CFG_T, sd_t, **fields).generate(feats, max_new_tokens=max_new_tokens, return_timestamps=True,
+                                                            language="en", task="transcribe",
+                                                            return_dict_in_generate=True, output_logits=True)
+        plain = out["sequences"].tolist()
+        rows = []
+        for r in plain:
+            while r and r[-1] == EOS:
+                r = r[:-1]
+            rows.append(r)
+        passes = [len(sg) for sg in out["segments"]]
+        if max(passes) < 2:
+            continue                                  # keep a case in which at least one pack needs several segments
+        sigma = torch.stack(out["segments"][0][0]["result"]["logits"], 1).float().std().item()
+        ok = ours(sd_t, audios, torch.float32, 0.0, 0) == rows and ours(sd_t, audios, torch.bfloat16, 0.0, 0) == rows
+        for k in range(4):
+            ok = ok and ours(sd_t, audios, torch.float32, noise * sigma, 2000 + k) == rows
+        if ok:
+            return dict(name="pseudo_label_packs", kind="pseudo_label", seed=seed, lengths=list(lengths),
+                        speakers=list(speakers), packs=packs, max_new_tokens=max_new_tokens, generation_config=fields,
+                        margin=noise, margin_kind="empirical: invariant under +-noise/2 sigma uniform logit noise",
+                        sequences=rows, segments_per_pack=passes, diverse=True)
+    raise SystemExit("pseudo-label packs: no seed survived: widen the seed search")
 
 
 def main(n_seeds=300, only=None):
@@ -358,7 +451,7 @@ def main(n_seeds=300, only=None):
         path = os.path.join(ROOT, "tests", "golden", "decode.json")
         old = json.load(open(path))
         fresh = {"longform_chunked": scenario_longform, "pseudo_label_packs": scenario_pseudo_label,
-                 "beam_search_student": scenario_beam}
+                 "beam_search_student": scenario_beam, "timestamps_seek_loop": scenario_seek}
         names = [sc["name"] for sc in old["scenarios"]]
         for n in only:
             if n in fresh and n not in names:
@@ -396,6 +489,7 @@ def main(n_seeds=300, only=None):
     out.append(scenario_longform(seeds))
     out.append(scenario_pseudo_label(seeds))
     out.append(scenario_beam(seeds))
+    out.append(scenario_seek(seeds))
     for s in out:
         print(f"{s['name']:34s} seed {s['seed']:4d}  min margin {s['margin']:.3f} sigma")
         if s["margin"] < MIN_MARGIN and not os.environ.get("DECODE_GOLDEN_DEBUG"):

@@ -58,13 +58,17 @@ def _check_short(ops, s, graphs):
         args = ()
         kw["encoder_outputs"] = BaseModelOutput(last_hidden_state=enc)
     else:
-        args = (gd.features(s["seed"] + 1, B).to(ops.device),)
+        f = gd.features(s["seed"] + 1, B)
+        if s.get("frames"):                       # shorter inputs: the seek loop pads every window to 30 s itself
+            f = f[..., :s["frames"]].contiguous()
+        args = (f.to(ops.device),)
     if s["assistant"]:
         kw["assistant_model"] = student
     else:
         kw["use_graphs"] = graphs
-    seq = model.generate(*args, return_dict_in_generate=True, **kw).sequences
-    assert seq.tolist() == s["sequences"], (s["name"], seq.tolist(), s["sequences"])
+    if s["sequences"] is not None:
+        seq = model.generate(*args, return_dict_in_generate=True, **kw).sequences
+        assert seq.tolist() == s["sequences"], (s["name"], seq.tolist(), s["sequences"])
     plain = model.generate(*args, **kw)
     assert plain.tolist() == s["plain"], (s["name"], "plain return value")
     if s["assistant"]:
@@ -104,11 +108,9 @@ def _check_pseudo_label(ops, s, graphs):
                          use_graphs=graphs)
     ids, packs2, _ = lab(audios, s["speakers"])
     assert packs2 == s["packs"]
-    for row, ref in zip(ids, s["sequences"]):
-        want = ref[len(prompt):]
-        if gc["eos_token_id"] in want:
-            want = want[: want.index(gc["eos_token_id"])]
-        assert row == want, (row, want)
+    # the reference's plain return of generate(..., return_timestamps=True): the tokens of all segments of the seek loop
+    assert ids == s["sequences"], (ids, s["sequences"])
+    assert max(s["segments_per_pack"]) >= 2
 
 
 def _run_all(ops, graphs):
@@ -221,8 +223,51 @@ def test_generate_matches_transformers_live_and_rejects_unsupported_arguments():
                      (dict(max_new_tokens=500), ValueError)):
         with pytest.raises(exc):
             model.generate(feats, **bad)
-    with pytest.raises(NotImplementedError, match="long-form"):
+    with pytest.raises(ValueError, match="more than 3000 mel input features"):
         model.generate(torch.zeros(1, 80, 6000))
+    with pytest.raises(ValueError, match="attention_mask"):
+        model.generate(torch.zeros(2, 80, 6000), return_timestamps=True, language="en")
     en = _model(ops, gd.CFG_T, sd_t, gd.generation_fields(multilingual=False))
     with pytest.raises(ValueError, match="English-only"):
         en.generate(feats, language="en")
+
+
+def test_timestamp_seek_loop_matches_transformers_live():
+    """generate(..., return_timestamps=True) is a seek loop in the reference (TF:generation_whisper.py:784-903): every
+    window is decoded with the timestamp rules, `_retrieve_segment` splits it at consecutive timestamp pairs and moves
+    the utterance to the last predicted end of segment; inputs longer than 30 s run the same loop (batches need the
+    attention mask).  Compared live with the imported class on fresh seeds (fp32 both sides): a 30 s batch, a 75 s
+    utterance, and a batch of a 60 s and a 20 s utterance."""
+    pytest.importorskip("transformers")
+    from distil_whisper_amd.generation import retrieve_segment
+    ops = _ops("ref")
+    fields = gd.generation_fields(multilingual=True, suppress=True, timestamps=True)
+    multi = 0
+    for seed in (300, 301):
+        sd_t = gd.weights(seed)
+        model = _model(ops, gd.CFG_T, sd_t, fields)
+        long1 = torch.cat([gd.features(seed + 1, 1), gd.features(seed + 2, 1), gd.features(seed + 3, 1)[..., :1500]], -1)
+        a = torch.cat([gd.features(seed + 4, 1), gd.features(seed + 5, 1)], -1)
+        b = torch.cat([gd.features(seed + 6, 1)[..., :2000], torch.zeros(1, 80, 4000)], -1)
+        mask = torch.ones(2, 6000, dtype=torch.long)
+        mask[1, 2000:] = 0
+        for feats, kw in ((gd.features(seed + 1, 2), dict(max_new_tokens=6, return_timestamps=True, language="en")),
+                          (long1, dict(max_new_tokens=5, return_timestamps=True, language="de")),
+                          (torch.cat([a, b], 0), dict(max_new_tokens=4, return_timestamps=True, language="en",
+                                                      attention_mask=mask))):
+            with torch.no_grad():
+                ref = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, **kw)
+            out = model.generate(feats, return_dict_in_generate=True, **kw)
+            assert out.sequences.tolist() == ref.tolist(), (seed, kw)
+            multi += max(len(s) for s in out.segments) > 1
+    assert multi >= 4                                  # the loop really ran several passes
+    # the segment rule on its own (TF `_retrieve_segment`): pairs, single ending, no timestamps, empty
+    tb = 100
+    segs, off = retrieve_segment([100, 5, 6, 110, 110, 7, 120], tb, 3000)
+    assert [s["tokens"] for s in segs] == [[100, 5, 6, 110], [110, 7, 120]] and off == 3000
+    segs, off = retrieve_segment([100, 5, 110, 110, 7, 8], tb, 3000)
+    assert [s["tokens"] for s in segs] == [[100, 5, 110, 110]] and off == 10 * 2
+    segs, off = retrieve_segment([5, 6, 7], tb, 1234)
+    assert [s["tokens"] for s in segs] == [[5, 6, 7]] and off == 1234
+    segs, off = retrieve_segment([], tb, 77)
+    assert [s["tokens"] for s in segs] == [[]] and off == 77
