@@ -528,10 +528,10 @@ class WhisperForConditionalGeneration(nn.Module):
         HIP graphs; `use_cache=False` re-decodes the whole prefix every step and exists as a cross-check).
         `num_beams > 1` runs decoding.beam_search_decode (TF `_beam_search`).  `return_timestamps=True` (without
         `force_unique_generate_call`) and inputs longer than 30 s run the reference's timestamp seek loop
-        (`_generate_seek_loop`, TF:784-903) at temperature 0.
-        Arguments this path does not implement RAISE (nothing is silently ignored): group beam search, sampling /
-        temperature fallback and its thresholds, `condition_on_prev_tokens`, token-level timestamps, custom logits
-        processors.
+        (`seek_decode`, TF:784-903) with `condition_on_prev_tokens`, the fallback thresholds (`temperature` tuple,
+        `compression_ratio_threshold`, `logprob_threshold`) and the `no_speech_threshold` skip.
+        Arguments this path does not implement RAISE (nothing is silently ignored): group beam search, plain sampling,
+        the fallback heuristics outside the seek loop, token-level timestamps, custom logits processors.
         Returns what the reference returns: the generated tokens only (decoder prompt and EOS stripped, right-padded
         with pad_token_id), or with `return_dict_in_generate=True` / `force_unique_generate_call=True` the full
         sequences (prompt + generated, as GenerationMixin emits them)."""
@@ -545,13 +545,13 @@ class WhisperForConditionalGeneration(nn.Module):
                 raise NotImplementedError(f"generate({name}=...) is not implemented on the MI355X engine path")
         if return_token_timestamps or return_segments:
             raise NotImplementedError("return_token_timestamps / return_segments are not implemented on the MI355X path")
-        if condition_on_prev_tokens or compression_ratio_threshold is not None or logprob_threshold is not None or \
-                no_speech_threshold is not None:
-            raise NotImplementedError("the temperature-fallback options of sequential long-form (condition_on_prev_tokens, "
-                                      "compression_ratio_threshold, logprob_threshold, no_speech_threshold) are not "
-                                      "implemented on the MI355X path: the seek loop runs at temperature 0")
         temps = list(temperature) if isinstance(temperature, (list, tuple)) else [temperature]
-        if temps[0] is not None and temps[0] > 0.0:
+        fallback_args = dict(temperatures=temps, compression_ratio_threshold=compression_ratio_threshold,
+                             logprob_threshold=logprob_threshold, no_speech_threshold=no_speech_threshold,
+                             condition_on_prev_tokens=bool(condition_on_prev_tokens))
+        uses_fallback = bool(condition_on_prev_tokens) or compression_ratio_threshold is not None or \
+            logprob_threshold is not None or no_speech_threshold is not None or len(temps) > 1
+        if not uses_fallback and temps[0] is not None and temps[0] > 0.0:
             raise NotImplementedError("sampling (temperature > 0) is not implemented on the MI355X path")
         engine_keys = ("encoder_outputs", "assistant_model", "decoder_input_ids", "use_cache")
         unknown = [k for k in kwargs if k not in G._CONFIG_KEYS and k not in engine_keys]
@@ -580,6 +580,9 @@ class WhisperForConditionalGeneration(nn.Module):
         # ---- encoder
         encoder_outputs = kwargs.get("encoder_outputs")
         if encoder_outputs is not None:
+            if uses_fallback:
+                raise NotImplementedError("temperature fallback / condition_on_prev_tokens need input_features (the seek "
+                                          "loop encodes every window itself)")
             enc = encoder_outputs
             if not torch.is_tensor(enc):
                 enc = enc.last_hidden_state if hasattr(enc, "last_hidden_state") else enc[0]
@@ -602,7 +605,11 @@ class WhisperForConditionalGeneration(nn.Module):
                 # the reference's seek loop (TF:784-903): with timestamps every window is decoded until its audio is
                 # consumed, also when the input is a single 30 s window (run_pseudo_labelling.py:861-996 calls it so)
                 return self._generate_seek_loop(input_features, attention_mask, gc, language, task, is_multilingual,
-                                                prompt_ids, kwargs, use_graphs, return_dict_in_generate, num_beams)
+                                                prompt_ids, kwargs, use_graphs, return_dict_in_generate, num_beams,
+                                                fallback_args)
+            if uses_fallback:
+                raise NotImplementedError("temperature fallback / condition_on_prev_tokens are implemented for the "
+                                          "timestamp seek loop (return_timestamps=True) only on the MI355X path")
             if frames != 2 * d.max_src:
                 raise ValueError(f"Whisper expects the mel input features to be of length {2 * d.max_src}, but found "
                                  f"{frames}. Make sure to pad the input mel features to {2 * d.max_src}.")
@@ -717,21 +724,34 @@ class WhisperForConditionalGeneration(nn.Module):
 
     def seek_decode(self, input_features, max_frames, init_tokens, lengths, eos, pad, no_timestamps_token_id,
                     max_initial_timestamp_index=None, suppress_tokens=None, begin_suppress_tokens=None,
-                    detect_language=None):
-        """The seek loop itself (TF:generation_whisper.py:784-903, temperature 0): input_features [B, n_mels, frames],
-        max_frames[b] = valid mel frames of utterance b.  init_tokens: the decoder prompt rows (list of B lists) or a
-        callable(detect) building them (detect() = language ids from the first window); lengths(P) -> (max_new_tokens,
-        min_new_tokens) per pass.  Every pass encodes the next <= 30 s window of each unfinished utterance, decodes it
-        greedily with the timestamp rules and advances that utterance by what `retrieve_segment` says it consumed.
+                    detect_language=None, temperatures=(0.0,), compression_ratio_threshold=None, logprob_threshold=None,
+                    no_speech_threshold=None, condition_on_prev_tokens=False, prev_sot_token_id=None):
+        """The seek loop itself (TF:generation_whisper.py:784-903): input_features [B, n_mels, frames], max_frames[b] =
+        valid mel frames of utterance b.  init_tokens: the decoder prompt rows (list of B lists) or a callable(detect)
+        building them (detect() = language ids from the first window); lengths(P) -> (max_new_tokens, min_new_tokens)
+        for a decoder prompt of P tokens.  Every pass encodes the next <= 30 s window of each unfinished utterance,
+        decodes it with the timestamp rules and advances that utterance by what `retrieve_segment` says it consumed.
+          * condition_on_prev_tokens (TF:1853-1918): the tokens of the utterance's earlier segments (last 223, behind
+            <|startofprev|>) precede the prompt.  The reference left-pads a batch and masks the pads; rows are
+            independent, so here rows are decoded in groups of equal prompt length (no pads, same positions);
+          * fallback (TF:970-1116, 1243-1287): a window whose zlib compression ratio of the token bytes exceeds
+            `compression_ratio_threshold` or whose average log-probability is below `logprob_threshold` is decoded
+            again at the next temperature (sampling; the random stream is this process's, not the reference's);
+            `no_speech_threshold`: P(<|nospeech|>) after <|startoftranscript|> above it together with a low average
+            log-probability skips the window.  The scores are recomputed by one teacher-forced decoder pass.
         -> per utterance the list of segments {"start", "end", "tokens"}."""
+        import math
+        import zlib
         from . import generation as G
-        from .decoding import GreedyDecoder
+        from .decoding import GreedyDecoder, apply_timestamp_rules
         eng, d = self.engine, self.dims
         B = input_features.shape[0]
         dev = input_features.device
-        W = 2 * d.max_src
+        W, V = 2 * d.max_src, d.vocab
         feats = input_features.to(torch.float32)
         seek = [0] * B
+        temps = [0.0 if x is None else float(x) for x in (temperatures if isinstance(temperatures, (list, tuple))
+                                                         else [temperatures])]
 
         def window(rows):
             seg = torch.zeros((len(rows), feats.shape[1], W), dtype=torch.float32, device=dev)
@@ -743,41 +763,175 @@ class WhisperForConditionalGeneration(nn.Module):
             init = init_tokens(lambda: detect_language(eng.encode(window(list(range(B))), save=False)[0]))
         else:
             init = init_tokens
-        P = len(init[0])
-        tb = int(no_timestamps_token_id) + 1
-        ts_rules = dict(begin_index=P, no_timestamps_token_id=int(no_timestamps_token_id),
-                        max_initial_timestamp_index=max_initial_timestamp_index)
+        P0 = len(init[0])
+        nts = int(no_timestamps_token_id)
+        tb = nts + 1
+        cut_off = d.max_tgt // 2 - 1
+        prev_sot = prev_sot_token_id
+        if prev_sot is None and suppress_tokens is not None and len(suppress_tokens) >= 2:
+            prev_sot = suppress_tokens[-2]
+        need_scores = logprob_threshold is not None or no_speech_threshold is not None
+        if no_speech_threshold is not None and logprob_threshold is None:
+            raise ValueError("no_speech_threshold needs logprob_threshold (the reference compares both)")
+
+        def vmask(ids):
+            mk = torch.zeros(V, dtype=torch.bool, device=dev)
+            if ids:
+                mk[torch.as_tensor(list(ids), dtype=torch.long, device=dev)] = True
+            return mk
+        sup, bsup = vmask(suppress_tokens), vmask(begin_suppress_tokens)
+
+        def processed(raw, hist, n, P, min_new):
+            """The reference's processed scores of one step: raw f32 [r, V], hist int64 [r, >= n] (n tokens so far)."""
+            sc = raw.clone()
+            if n - P < min_new:
+                sc[:, eos] = float("-inf")
+            if n == P:
+                sc = sc.masked_fill(bsup[None, :], float("-inf"))
+            sc = sc.masked_fill(sup[None, :], float("-inf"))
+            return apply_timestamp_rules(sc, hist, n, P, nts, eos, max_initial_timestamp_index)
+
+        def sample(enc, ids, max_new, min_new, temp):
+            """Multinomial sampling at temperature `temp` over the processed scores (fallback passes)."""
+            r, P = ids.shape
+            cache = eng.decode_init(enc, r, P + max_new)
+            toks = torch.full((r, P + max_new), pad, dtype=torch.long, device=dev)
+            toks[:, :P] = ids
+            done = torch.zeros(r, dtype=torch.bool, device=dev)
+            logits = eng.decode_multi(ids, cache).view(r, P, -1)[:, -1, :V]
+            n = P
+            while True:
+                pr = torch.softmax(processed(logits.float(), toks, n, P, min_new) / temp, -1)
+                nxt = torch.multinomial(pr, 1)[:, 0]
+                nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+                toks[:, n] = nxt
+                done = done | (nxt == eos)
+                n += 1
+                if n >= P + max_new or bool(done.all()):
+                    break
+                logits = eng.decode_step(nxt[:, None].contiguous(), cache)[:, :V]
+            return toks[:, :n]
+
+        def scores_of(enc, ids, gens, min_new):
+            """(average log-probability of the chosen tokens, P(<|nospeech|>) after <|startoftranscript|>) per row from
+            ONE teacher-forced decoder pass over prompt + generated tokens (TF `_retrieve_avg_logprobs`, 1958-1975;
+            `WhisperNoSpeechDetection`, TF:generation/logits_process.py)."""
+            r, P = ids.shape
+            L = max(1, max(len(g) for g in gens))
+            full = torch.full((r, P + L), eos, dtype=torch.long, device=dev)
+            full[:, :P] = ids
+            for i, g in enumerate(gens):
+                if g:
+                    full[i, P:P + len(g)] = torch.as_tensor(g, dtype=torch.long, device=dev)
+            T = full.shape[1]
+            logits, _ = eng.decode(full[:, :T - 1].contiguous() if T > 1 else full, enc, save=False)
+            logits = logits[:r * (T - 1)].view(r, T - 1, -1)[:, :, :V].float()
+            tot = torch.zeros(r, dtype=torch.float64, device=dev)
+            first = None
+            for j in range(L):
+                sc = processed(logits[:, P - 1 + j], full, P + j, P, min_new)
+                if j == 0:
+                    first = sc
+                lp = torch.log_softmax(sc, -1).gather(1, full[:, P + j:P + j + 1])[:, 0]
+                live = torch.as_tensor([j < len(g) for g in gens], device=dev)
+                tot += torch.where(live, lp.double(), torch.zeros_like(tot))
+            avg = [float(tot[i]) / len(g) if g else 0.0 for i, g in enumerate(gens)]
+            if P0 > 1:
+                nsp = torch.softmax(logits[:, P - P0], -1)[:, nts - 1]
+            else:
+                nsp = torch.softmax(first, -1)[:, nts - 1]
+            return avg, nsp.tolist()
+
+        def ratio(tokens):
+            nbytes = int(math.log2(V) / 8) + 1
+            raw = b"".join(int(x).to_bytes(nbytes, "little") for x in tokens)
+            return len(raw) / len(zlib.compress(raw))
+
         segments = [[] for _ in range(B)]
+        do_cond = [bool(condition_on_prev_tokens)] * B
         decoders = {}
         while any(seek[b] < max_frames[b] for b in range(B)):
             rows = [b for b in range(B) if seek[b] < max_frames[b]]
             snf = {b: min(max_frames[b] - seek[b], W) for b in rows}
-            enc, _ = eng.encode(window(rows), save=False)
-            ids = torch.as_tensor([init[b] for b in rows], dtype=torch.long, device=dev)
-            max_new, min_new = lengths(P)
-            key = (len(rows), P + max_new)
-            dec = decoders.get(key)
-            if dec is None:
-                dec = decoders[key] = GreedyDecoder(eng, len(rows), P + max_new, eos_token_id=eos,
-                                                    suppress_tokens=suppress_tokens,
-                                                    begin_suppress_tokens=begin_suppress_tokens, use_graphs=False,
-                                                    timestamp_rules=ts_rules, pad_token_id=pad)
-            out = dec.run(enc, ids, max_new, min_new)[:, P:].tolist()
-            for i, b in enumerate(rows):
-                seq = out[i]
-                if seq and seq[-1] == pad:         # TF:1064-1071: drop the padding (all of it but one EOS when pad == EOS)
-                    npad = sum(1 for x in seq if x == pad) - (1 if pad == eos else 0)
-                    if npad:
-                        seq = seq[:-npad]
-                if seq and seq[-1] == eos:
-                    seq = seq[:-1]
+            enc_all, _ = eng.encode(window(rows), save=False)
+            enc_all = enc_all[:len(rows) * d.max_src].view(len(rows), d.max_src, -1)
+            # decoder prompts (TF:1853-1918)
+            prompts = {}
+            cond_now = any(do_cond[b] for b in rows) and len(segments[0]) > 0
+            for b in rows:
+                pre = []
+                if cond_now:
+                    if prev_sot is None:
+                        raise ValueError("condition_on_prev_tokens needs prev_sot_token_id in the generation config")
+                    if do_cond[b] and segments[b]:
+                        for sg in segments[b]:
+                            tk = sg["tokens"]
+                            pre += tk[:-1] if (len(tk) > 2 and tk[-2] >= tb) else tk
+                        pre = pre[-cut_off:]
+                    pre = [prev_sot] + pre
+                prompts[b] = pre + list(init[b])
+            accepted = {}
+            # (the reference left-pads the batch to its longest prompt and derives the lengths from that, TF:835-840)
+            max_new, min_new = lengths(max(len(prompts[b]) for b in rows))
+            for P in sorted({len(prompts[b]) for b in rows}):
+                group = [b for b in rows if len(prompts[b]) == P]
+                pending = list(group)
+                for ti, temp in enumerate(temps):
+                    pos = [rows.index(b) for b in pending]
+                    enc = enc_all[pos].reshape(len(pending) * d.max_src, -1).contiguous()
+                    ids = torch.as_tensor([prompts[b] for b in pending], dtype=torch.long, device=dev)
+                    if temp > 0.0:
+                        out = sample(enc, ids, max_new, min_new, temp)[:, P:].tolist()
+                    else:
+                        key = (len(pending), P, max_new)
+                        dec = decoders.get(key)
+                        if dec is None:
+                            dec = decoders[key] = GreedyDecoder(
+                                eng, len(pending), P + max_new, eos_token_id=eos, suppress_tokens=suppress_tokens,
+                                begin_suppress_tokens=begin_suppress_tokens, use_graphs=False, pad_token_id=pad,
+                                timestamp_rules=dict(begin_index=P, no_timestamps_token_id=nts,
+                                                     max_initial_timestamp_index=max_initial_timestamp_index))
+                        out = dec.run(enc, ids, max_new, min_new)[:, P:].tolist()
+                    gens = []
+                    for seq in out:
+                        if seq and seq[-1] == pad:     # TF:1064-1071: drop the padding (all but one EOS when pad == EOS)
+                            npad = sum(1 for x in seq if x == pad) - (1 if pad == eos else 0)
+                            if npad:
+                                seq = seq[:-npad]
+                        gens.append(seq)
+                    avg = nsp = None
+                    if need_scores:
+                        avg, nsp = scores_of(enc, ids, gens, min_new)
+                    again = []
+                    for i, b in enumerate(pending):
+                        fallback = skip = False
+                        if compression_ratio_threshold is not None and gens[i] and \
+                                ratio(gens[i]) > compression_ratio_threshold:
+                            fallback = True
+                        if logprob_threshold is not None and avg[i] < logprob_threshold:
+                            fallback = True
+                        if no_speech_threshold is not None and avg[i] < logprob_threshold and nsp[i] > no_speech_threshold:
+                            fallback, skip = False, True
+                        seq = gens[i][:-1] if (gens[i] and gens[i][-1] == eos) else gens[i]
+                        accepted[b] = (seq, skip)
+                        do_cond[b] = bool(condition_on_prev_tokens) and temp < 0.5
+                        if fallback:
+                            again.append(b)
+                    if not again or ti == len(temps) - 1:
+                        break
+                    pending = again
+            for b in rows:
+                seq, skip = accepted[b]
+                if skip:
+                    seek[b] += snf[b]
+                    continue
                 segs, offset = G.retrieve_segment(seq, tb, snf[b], time_offset=seek[b] * 0.01)
                 seek[b] += offset
                 segments[b] += segs
         return segments
 
     def _generate_seek_loop(self, input_features, attention_mask, gc, language, task, is_multilingual, prompt_ids, kwargs,
-                            use_graphs, return_dict_in_generate, num_beams):
+                            use_graphs, return_dict_in_generate, num_beams, fallback_args=None):
         """Timestamp-driven multi-pass transcription: `WhisperGenerationMixin.generate` steps 5-7 (TF:745-968) with
         temperature 0 and no fallback thresholds -- every utterance keeps a `seek` position in mel frames; each pass
         decodes the next <= 30 s window of every unfinished utterance with the timestamp rules, `retrieve_segment`
@@ -830,7 +984,8 @@ class WhisperForConditionalGeneration(nn.Module):
                                     getattr(gc, "max_initial_timestamp_index", None),
                                     list(gc.suppress_tokens) if gc.suppress_tokens else None,
                                     list(gc.begin_suppress_tokens) if gc.begin_suppress_tokens else None,
-                                    detect_language=detect_on)
+                                    detect_language=detect_on, prev_sot_token_id=getattr(gc, "prev_sot_token_id", None),
+                                    **(fallback_args or {}))
         rows_out = [[tok for sg in segments[b] for tok in sg["tokens"]] for b in range(B)]
         width = max((len(r) for r in rows_out), default=0)
         seqs = torch.full((B, width), pad, dtype=torch.long, device=dev)

@@ -216,7 +216,7 @@ def test_generate_matches_transformers_live_and_rejects_unsupported_arguments():
     for bad, exc in ((dict(num_beams=4, num_beam_groups=2), NotImplementedError), (dict(do_sample=True), NotImplementedError),
                      (dict(temperature=(0.2, 0.4)), NotImplementedError),
                      (dict(condition_on_prev_tokens=True), NotImplementedError),
-                     (dict(no_speech_threshold=0.6), NotImplementedError),
+                     (dict(no_speech_threshold=0.6, logprob_threshold=-1.0), NotImplementedError),
                      (dict(return_token_timestamps=True), NotImplementedError),
                      (dict(languge="en"), ValueError), (dict(language="klingon"), ValueError),
                      (dict(task="summarize", language="en"), ValueError),
@@ -271,3 +271,45 @@ def test_timestamp_seek_loop_matches_transformers_live():
     assert [s["tokens"] for s in segs] == [[5, 6, 7]] and off == 1234
     segs, off = retrieve_segment([], tb, 77)
     assert [s["tokens"] for s in segs] == [[]] and off == 77
+
+
+def test_seek_loop_conditioning_and_fallback_thresholds_match_transformers_live():
+    """The long-form heuristics of the reference's seek loop, live against the imported class (fp32 both sides):
+    `condition_on_prev_tokens` (earlier segments behind <|startofprev|> in front of the prompt; rows of a batch end up
+    with different prompt lengths), and at temperature 0 the decisions of `_need_fallback`: zlib compression ratio of
+    the token bytes, average log-probability of the chosen tokens, and the no-speech skip (P(<|nospeech|>) after
+    <|startoftranscript|> with a low average log-probability drops the window).  A real temperature fallback samples
+    from this process's random stream: it is only checked to run and to be reproducible under a fixed torch seed."""
+    pytest.importorskip("transformers")
+    ops = _ops("ref")
+    fields = gd.generation_fields(multilingual=True, suppress=True, timestamps=True)
+    fields["prev_sot_token_id"] = gd.STARTOFPREV
+    changed = 0
+    for seed in (400, 401):
+        sd_t = gd.weights(seed)
+        model = _model(ops, gd.CFG_T, sd_t, fields)
+        f2 = gd.features(seed + 1, 2)[..., :700].contiguous()
+        long1 = torch.cat([gd.features(seed + 2, 1), gd.features(seed + 3, 1)[..., :1000]], -1)
+        base = dict(max_new_tokens=6, return_timestamps=True, language="en")
+        plain = model.generate(f2, **base).tolist()
+        for feats, kw in ((f2, dict(base, condition_on_prev_tokens=True)),
+                          (long1, dict(max_new_tokens=5, return_timestamps=True, language="de",
+                                       condition_on_prev_tokens=True)),
+                          (f2, dict(base, temperature=0.0, logprob_threshold=-6.0, compression_ratio_threshold=1.2,
+                                    no_speech_threshold=0.0005)),
+                          (long1, dict(max_new_tokens=5, return_timestamps=True, language="en", temperature=(0.0,),
+                                       logprob_threshold=-6.5, no_speech_threshold=0.001,
+                                       condition_on_prev_tokens=True))):
+            with torch.no_grad():
+                ref = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, **kw)
+            got = model.generate(feats, **kw)
+            assert got.tolist() == ref.tolist(), (seed, kw)
+            changed += feats is f2 and got.tolist() != plain
+        torch.manual_seed(5)
+        a = model.generate(f2, **dict(base, temperature=(0.0, 0.4, 0.8), compression_ratio_threshold=0.5, logprob_threshold=-1.0))
+        torch.manual_seed(5)
+        b = model.generate(f2, **dict(base, temperature=(0.0, 0.4, 0.8), compression_ratio_threshold=0.5, logprob_threshold=-1.0))
+        assert a.tolist() == b.tolist() and a.shape[0] == 2
+    assert changed >= 1                                # conditioning / the skip rule really changed what was decoded
+    with pytest.raises(NotImplementedError, match="seek loop"):
+        model.generate(gd.features(1, 1), language="en", logprob_threshold=-1.0)
