@@ -313,3 +313,24 @@ def test_seek_loop_conditioning_and_fallback_thresholds_match_transformers_live(
     assert changed >= 1                                # conditioning / the skip rule really changed what was decoded
     with pytest.raises(NotImplementedError, match="seek loop"):
         model.generate(gd.features(1, 1), language="en", logprob_threshold=-1.0)
+
+
+@pytest.mark.gpu
+def test_seek_loop_heuristics_run_on_the_hip_path():
+    """The long-form heuristics on the HIP engine (scoring pass through engine.decode, sampling fallback through the
+    cached decoder passes): same call as the live CPU comparison; a bf16 GPU run is not required to take every
+    near-threshold decision like the fp32 reference, so this checks shapes, token ranges and determinism."""
+    ops = _ops("hip")
+    fields = gd.generation_fields(multilingual=True, suppress=True, timestamps=True)
+    fields["prev_sot_token_id"] = gd.STARTOFPREV
+    sd_t = gd.weights(400)
+    model = _model(ops, gd.CFG_T, sd_t, fields)
+    f2 = gd.features(401, 2)[..., :700].contiguous().cuda()
+    kw = dict(max_new_tokens=6, return_timestamps=True, language="en", condition_on_prev_tokens=True, temperature=(0.0,),
+              logprob_threshold=-6.0, compression_ratio_threshold=1.2, no_speech_threshold=0.0005)
+    a, b = model.generate(f2, **kw), model.generate(f2, **kw)
+    assert a.tolist() == b.tolist() and a.shape[0] == 2 and int(a.max()) < gd.V
+    torch.manual_seed(3)
+    c = model.generate(f2, max_new_tokens=6, return_timestamps=True, language="en", temperature=(0.0, 0.5),
+                       compression_ratio_threshold=0.5, logprob_threshold=-1.0)
+    assert c.shape[0] == 2 and int(c.max()) < gd.V
