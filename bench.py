@@ -173,6 +173,7 @@ def main():
                         "achieved": p["flops"] / (p["ms"] * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                         "traffic": pmc_traffic(key, args),
+                        "vendor_library_tflops": vendor_ceiling(),
                         "all_gemm_ms": sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")),
                         "all_gemm_tflops": sum(v["flops"] for k, v in prof.items() if k.startswith("gemm")) /
                         max(sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9,
@@ -200,6 +201,16 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def vendor_ceiling():
+    """Second ceiling next to the 2.5 PFLOP/s peak: what the vendor GEMM library reaches on the step's
+    row-major shapes on an MI355X of this pool (committed measurement, tools/hipblaslt_probe.py); None if not committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "vendor_gemm_ceiling.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("row_major_forward_median_tflops")
 
 
 def pmc_traffic(key, args):
