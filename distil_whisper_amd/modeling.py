@@ -849,7 +849,9 @@ class WhisperForConditionalGeneration(nn.Module):
 
         segments = [[] for _ in range(B)]
         do_cond = [bool(condition_on_prev_tokens)] * B
-        decoders = {}
+        if not hasattr(self, "_seek_decoders"):
+            self._seek_decoders = {}           # reused by later calls (pseudo-labelling decodes batch after batch)
+        decoders = self._seek_decoders
         while any(seek[b] < max_frames[b] for b in range(B)):
             rows = [b for b in range(B) if seek[b] < max_frames[b]]
             snf = {b: min(max_frames[b] - seek[b], W) for b in rows}
@@ -883,9 +885,12 @@ class WhisperForConditionalGeneration(nn.Module):
                     if temp > 0.0:
                         out = sample(enc, ids, max_new, min_new, temp)[:, P:].tolist()
                     else:
-                        key = (len(pending), P, max_new)
+                        key = (len(pending), P, max_new, eos, pad, nts, max_initial_timestamp_index,
+                               tuple(suppress_tokens or ()), tuple(begin_suppress_tokens or ()))
                         dec = decoders.get(key)
                         if dec is None:
+                            if len(decoders) >= 4:     # (a decoder owns its K/V caches: keep a handful alive)
+                                decoders.pop(next(iter(decoders)))
                             dec = decoders[key] = GreedyDecoder(
                                 eng, len(pending), P + max_new, eos_token_id=eos, suppress_tokens=suppress_tokens,
                                 begin_suppress_tokens=begin_suppress_tokens, use_graphs=False, pad_token_id=pad,
