@@ -37,14 +37,15 @@ extern int g_skinny_wide;     // gemm_skinny.hip
 int g_gemm_persistent = 1;
 // Kernel selection for the 256x256 block tile (bit mask; dw_debug_set(0, v)):
 //   bits 0-1 (3): base = 16-wave tile kernel (gemm_kernel.h) for everything, 8-wave 128x128 tile for small grids;
-//   bit 2 (4):    phase-pipelined kernel (gemm_phased.hip) for dX GEMMs (k-major B) with K >= 3840 (+7..10 % there);
+//   bit 2 (4):    phase-pipelined kernel (gemm_phased.hip) for dX GEMMs (k-major B) with K >= 3840: +7..10 % there in the
+//                 warm micro-benchmark, a tie in the step once the 8-wave kernels existed (467.6 vs 467.1 ms): off by default;
 //   bit 4 (16):   8-wave software-pipelined kernel (gemm_wp.h, 128x64 per wave) for row-major operands;
 //   bit 5 (32):   ... for dX GEMMs the phased kernel does not take;   bit 6 (64): ... for dW GEMMs (both k-major);
 //   bit 7 (128):  phased kernel for every dX GEMM (tests).
 // (gemm_wp.h also instantiates as 4 waves x 128x128 -- one wave per SIMD, half the LDS fragment traffic -- but a lone
 // wave cannot cover its own DMA issue slots: 4-10 % behind the 8-wave layout on every shape, not built.)
 // Every kernel produces bit-identical results (same fp32 chain over k per output element): tests/test_kernels_gpu.py.
-static int g_gemm_variant = 119;
+static int g_gemm_variant = 115;
 int g_gemm_strip = 0;
 int g_gemm_cus = 256;
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)

@@ -139,7 +139,7 @@ def test_gemm_pipelined_variants_are_bit_identical(ops, ref, variant, ta, tb):
             ops.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32, out=got, atomic_acc=True, split_k=5)
             assert torch.equal(got, want)
     finally:
-        ops.lib.dw_debug_set(0, 119)
+        ops.lib.dw_debug_set(0, 115)
 
 
 def test_gemm_dynamic_job_handout_is_invisible(ops, ref):
