@@ -130,6 +130,8 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     if (p.split_k > (g->k >> 6)) p.split_k = g->k >> 6;
     p.slice_stride = 0;
     p.sched = nullptr;
+    p.zg_f16 = g->z_is_gelu_grad ? 1 : 0;
+    if (p.zg_f16 && g->z_out && g->act != 1) return DW_EINVAL;   // gelu'(z) is a by-product of the GELU epilogue
     p.ln_x = g->ln_x; p.ln_g = g->ln_gamma; p.ln_b = g->ln_beta; p.ld_lnx = g->ld_lnx; p.ln_x_dtype = g->ln_x_dtype;
     p.ln_eps = g->ln_eps;
     p.kv_out = (bf16*)g->kv_out; p.kv_ld = g->kv_ld; p.kv_split = g->kv_split; p.kv_rpb = g->kv_rows_per_batch;

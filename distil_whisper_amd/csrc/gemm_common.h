@@ -29,6 +29,7 @@ struct GemmP {
     bf16* kv_out;          // output columns >= kv_split of row m go to the K/V cache instead of C:
     long kv_ld;            //   kv_out[((m / kv_rpb) * kv_pitch + kv_row0 + m % kv_rpb) * kv_ld + (n - kv_split)]
     int kv_split, kv_rpb, kv_pitch, kv_row0;
+    int zg_f16;            // z_out / zgrad hold gelu'(z) in fp16 instead of z in bf16 (see DwGemm.z_is_gelu_grad)
     int* sched;            // persistent kernels: 9 device counters of this stream (dynamic job hand-out), or null
 };
 
@@ -185,22 +186,34 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
     if (!plain) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += b4[e];
-        if (p.z_out) {
+        if (p.z_out && !p.zg_f16) {
             bf16x4 z4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
             *(bf16x4*)(p.z_out + (long)m * p.ldz + n) = z4;
         }
         if (p.act == 1) {
+            const bool store_g = p.z_out && p.zg_f16;
+            f16x4 g4;
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
                 f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
-                const f32x2 g2 = gelu_fast2(x2);
-                v[e] = g2[0]; v[e + 1] = g2[1];
+                f32x2 cdf, pdf;
+                gelu_parts2(x2, cdf, pdf);                  // one exp + one rcp per element serve gelu AND gelu'
+                v[e] = x2[0] * cdf[0]; v[e + 1] = x2[1] * cdf[1];
+                if (store_g) {
+                    const f32x2 g2 = cdf + x2 * pdf;
+                    g4[e] = (_Float16)g2[0]; g4[e + 1] = (_Float16)g2[1];
+                }
             }
+            if (store_g) *(f16x4*)((_Float16*)p.z_out + (long)m * p.ldz + n) = g4;
         }
         if (have_side) {
-            if (p.zgrad) {
+            if (p.zgrad && p.zg_f16) {                    // the forward stored gelu'(z) (fp16 bits in the bf16-typed slots)
+                const f16x4 g4 = __builtin_bit_cast(f16x4, zs);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (float)g4[e];
+            } else if (p.zgrad) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     f32x2 x2; x2[0] = bf2f(zs[e]); x2[1] = bf2f(zs[e + 1]);
@@ -386,9 +399,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                     float x = v[e];
                     if (!plain) {
                         x += b4[e];
-                        if (p.z_out) p.z_out[(long)m * p.ldz + nn] = f2bf(x);
-                        if (p.act == 1) x = gelu_fast(round_bf16(x));
-                        if (p.zgrad) x *= gelu_grad_fast(bf2f(p.zgrad[(long)m * p.ldzg + nn]));
+                        if (p.z_out && !p.zg_f16) p.z_out[(long)m * p.ldz + nn] = f2bf(x);
+                        if (p.act == 1) {
+                            const float xr = round_bf16(x);
+                            if (p.z_out && p.zg_f16) ((_Float16*)p.z_out)[(long)m * p.ldz + nn] = (_Float16)gelu_grad_fast(xr);
+                            x = gelu_fast(xr);
+                        }
+                        if (p.zgrad && p.zg_f16) x *= (float)((const _Float16*)p.zgrad)[(long)m * p.ldzg + nn];
+                        else if (p.zgrad) x *= gelu_grad_fast(bf2f(p.zgrad[(long)m * p.ldzg + nn]));
                         if (p.r) {
                             const float rv = p.r_dtype == DW_F32 ? ((const float*)p.r)[(long)rr * p.ldr + nn]
                                                                  : bf2f(((const bf16*)p.r)[(long)rr * p.ldr + nn]);

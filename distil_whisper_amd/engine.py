@@ -338,7 +338,8 @@ class WhisperEngine:
         # --- feed forward
         h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save)
         a = self.act(R, d.ffn)
-        res = ops.gemm(h[:R], st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1, want_z=save, out=a[:R])
+        res = ops.gemm(h[:R], st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1,
+                       want_z=("grad" if self.ffn_keeps_gelu_grad else True) if save else False, out=a[:R])
         z = res[1] if save else None
         x2 = ops.gemm(a[:R], st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
                       out_dtype=self.stream)
@@ -394,6 +395,9 @@ class WhisperEngine:
         return cache
 
     # ---- single-call decoder pass (C entry dw_decode_step) ---------------------------------------------------------
+    # the FFN's saved by-product is gelu'(z) in fp16 (the backward epilogue multiplies) instead of z in bf16 (it
+    # evaluates erf/exp again): same bytes, no transcendentals in the dX GEMM of fc2
+    ffn_keeps_gelu_grad = True
     use_c_decode = True     # HIP path: one library call per decoder pass instead of ~30 per-kernel calls
 
     def _decode_desc(self, cache, n):

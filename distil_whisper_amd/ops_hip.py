@@ -31,6 +31,7 @@ class DwGemm(C.Structure):
         ("ld_lnx", C.c_int64), ("kv_ld", C.c_int64),
         ("ln_x_dtype", C.c_int32), ("kv_split", C.c_int32), ("kv_rows_per_batch", C.c_int32),
         ("kv_batch_pitch", C.c_int32), ("kv_row0", C.c_int32), ("ln_eps", C.c_float),
+        ("z_is_gelu_grad", C.c_int32),
     ]
 
 
@@ -276,11 +277,16 @@ class HipOps:
             assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
             g.bias = bias.data_ptr()
         if want_z:
-            z = self.empty((M, N), torch.bfloat16)
-            g.z_out, g.ldz = z.data_ptr(), z.stride(0)
+            # want_z="grad": the epilogue stores gelu'(z) as fp16 (what the backward multiplies by) instead of z as bf16
+            as_grad = want_z == "grad"
+            assert not as_grad or act == 1
+            z = self.empty((M, N), torch.float16 if as_grad else torch.bfloat16)
+            g.z_out, g.ldz, g.z_is_gelu_grad = z.data_ptr(), z.stride(0), int(as_grad)
         if zgrad is not None:
-            assert zgrad.dtype == torch.bfloat16 and zgrad.shape == (M, N) and zgrad.stride(1) == 1
+            assert zgrad.dtype in (torch.bfloat16, torch.float16) and zgrad.shape == (M, N) and zgrad.stride(1) == 1
+            assert not (want_z and (zgrad.dtype == torch.float16) != (want_z == "grad"))
             g.zgrad_in, g.ldzg = zgrad.data_ptr(), zgrad.stride(0)
+            g.z_is_gelu_grad = int(zgrad.dtype == torch.float16)
         if residual is not None:
             assert residual.stride(1) == 1 and residual.shape[1] == N
             g.r, g.ldr, g.r_dtype = residual.data_ptr(), residual.stride(0), _dt(residual)

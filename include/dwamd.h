@@ -91,6 +91,9 @@ typedef struct DwGemm {
     int32_t ln_x_dtype;      /* DW_F32 / DW_BF16 */
     int32_t kv_split, kv_rows_per_batch, kv_batch_pitch, kv_row0;
     float ln_eps;
+    int32_t z_is_gelu_grad;  /* 1: z_out (with act = 1) receives gelu'(z) in fp16 instead of z in bf16, and zgrad_in is read as
+                                such: the backward epilogue multiplies by the stored derivative instead of evaluating it
+                                (same bytes; the derivative is rounded to 11 bits where the reference keeps fp32) */
 } DwGemm;
 int dw_gemm_bf16(const DwGemm* g, void* stream);
 /* out[i] (+)= sum over slices of part[s*stride + i]; n, stride multiples of 4 (split-K combination, deterministic). */

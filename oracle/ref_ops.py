@@ -66,14 +66,20 @@ class RefOps:
         v = A @ Bm
         if bias is not None:
             v = v + bias
+        def dgelu(zz):
+            cdf = 0.5 * (1.0 + torch.erf(zz * 0.7071067811865476))
+            pdf = 0.3989422804014327 * torch.exp(-0.5 * zz * zz)
+            return cdf + zz * pdf
         z = self._bf(v) if want_z else None
+        if want_z == "grad":                   # the kernel's alternative by-product: gelu'(z) rounded to fp16
+            z = dgelu(z.float())
+            z = z.to(torch.float16) if self.lowp != torch.float32 else z      # exact-arithmetic mode keeps it exact
+            z._is_gelu_grad = True
         if act == 1:
             v = F.gelu(self._bf(v).float())
         if zgrad is not None:
-            zz = zgrad.float()
-            cdf = 0.5 * (1.0 + torch.erf(zz * 0.7071067811865476))
-            pdf = 0.3989422804014327 * torch.exp(-0.5 * zz * zz)
-            v = v * (cdf + zz * pdf)
+            stored = zgrad.dtype == torch.float16 or getattr(zgrad, "_is_gelu_grad", False)
+            v = v * (zgrad.float() if stored else dgelu(zgrad.float()))
         if residual is not None:
             r = residual.float()
             if r_row_mod > 0:

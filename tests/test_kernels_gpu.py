@@ -103,6 +103,30 @@ def test_gemm_epilogues(ops, ref, tile):
     c = ops.gemm(a, b, zgrad=zg, tile=tile)
     rc = ref.gemm(a, b, zgrad=zg)
     assert relerr(c, rc) < 6e-3
+    # the student's FFN keeps gelu'(z) in fp16 instead of z (DwGemm.z_is_gelu_grad): same C, derivative within fp16
+    # rounding of the fp32 derivative, and the backward epilogue that multiplies by it equals the one that evaluates it
+    # up to that rounding; ragged N exercises the scalar edge path of both
+    for n in (N, N - 3):
+        c2, g = ops.gemm(a, b[:n], bias=bias[:n], act=1, want_z="grad", tile=tile)
+        c1, z1 = ops.gemm(a, b[:n], bias=bias[:n], act=1, want_z=True, tile=tile)
+        rc, rg = ref.gemm(a, b[:n], bias=bias[:n], act=1, want_z="grad")
+        assert g.dtype == torch.float16 and torch.equal(c1, c2)
+        want = ref.gemm(a, b[:n], zgrad=z1)                   # derivative evaluated from the kernel's own z
+        dg = ref.gemm(torch.zeros_like(a), b[:n], bias=torch.ones_like(bias[:n]), zgrad=z1, out_dtype=torch.float32)
+        assert (g.float() - dg).abs().max().item() <= 1.5e-3   # fp16 ulp at 1 is 9.8e-4, + bf16-z tie flips
+        got = ops.gemm(a, b[:n], zgrad=g, tile=tile)
+        assert relerr(got, want) < 6e-3 and relerr(got, ops.gemm(a, b[:n], zgrad=z1, tile=tile)) < 3e-3
+    with pytest.raises(RuntimeError):                        # gelu'(z) is a by-product of the GELU epilogue only
+        g2 = torch.empty((M, N), dtype=torch.float16, device=a.device)
+        import ctypes
+        from distil_whisper_amd import ops_hip
+        d = ops_hip.DwGemm()
+        ctypes.memset(ctypes.byref(d), 0, ctypes.sizeof(d))
+        cc = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        d.a, d.b, d.c, d.z_out = a.data_ptr(), b.data_ptr(), cc.data_ptr(), g2.data_ptr()
+        d.m, d.n, d.k, d.lda, d.ldb, d.ldc, d.ldz = M, N, K, K, K, N, N
+        d.c_dtype, d.z_is_gelu_grad = ops_hip.DW_BF16, 1
+        ops._chk(ops.lib.dw_gemm_bf16(ctypes.byref(d), ops._stream()), "z_is_gelu_grad without act")
 
 
 @pytest.mark.parametrize("variant,ta,tb", [(131, False, True), (19, False, False), (35, False, True), (67, True, True)])
