@@ -476,8 +476,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
             int qi = qt * 64 + i;
             qi = qi < p.Lq ? qi : p.Lq - 1;
             const float* src = (threadIdx.x < 64 ? LSE : DEL) + qi;
-            __builtin_amdgcn_global_load_lds((const glb_void_t*)src,
-                                             (lds_void_t*)(base + 16384 + (threadIdx.x < 64 ? 0 : 256)), 4, 0, 0);
+            glds4(src, base + 16384 + (threadIdx.x < 64 ? 0 : 256));
         }
     };
 

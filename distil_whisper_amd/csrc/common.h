@@ -88,10 +88,21 @@ __device__ __forceinline__ int swz7(int row) {
     return (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1);
 }
 
-// Direct global->LDS 16-byte-per-lane load (global_load_lds_dwordx4): the LDS destination is
-// (wave-uniform base) + lane*16; the global source address is per lane.
+// Direct global->LDS load (global_load_lds_dwordx4 / _dword): the LDS destination is (wave-uniform base in M0) + lane * 16
+// (or * 4); the global source address is per lane.
+// Inline assembly ON PURPOSE: issued through the builtin, the compiler treats the instruction as an LDS store it cannot
+// disambiguate from reads of the OTHER staging buffer and puts `s_waitcnt vmcnt(0)` in front of the next ds_read --
+// i.e. it waits for the prefetch it has just issued, every tile.  Hidden from its memory model, the only vmcnt waits are
+// the explicit wait_vm0() calls in front of the barriers (every user has one).  The compiler's own vmcnt bookkeeping
+// for ordinary loads stays correct: the counter retires in order, so unseen operations in flight can only make its
+// waits longer, never shorter.
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const glb_void_t*)gsrc, (lds_void_t*)lds_wave_base, 16, 0, 0);
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_void_t*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(gsrc) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_void_t*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(m0v), "v"(gsrc) : "memory");
 }
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

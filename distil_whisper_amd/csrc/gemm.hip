@@ -25,6 +25,7 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_phased_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_phased.hip
 int dw_gemm_tile256_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile256.hip: 16 waves, 4 x 4
 int dw_gemm_tile128_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile128.hip: 8 waves, 2 x 4
+int dw_gemm_wp8_nn_ref_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_nn_ref.hip (builtin DMA; A/B only)
 int dw_gemm_wp8_nn_launch(const GemmP& p, hipStream_t s);                   // gemm_wp8_*.hip: software-pipelined loop, 8 waves
 int dw_gemm_wp8_nt_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp8_tt_launch(const GemmP& p, hipStream_t s);
@@ -41,13 +42,15 @@ int g_gemm_persistent = 1;
 //                 warm micro-benchmark, a tie in the step once the 8-wave kernels existed (467.6 vs 467.1 ms): off by default;
 //   bit 4 (16):   8-wave software-pipelined kernel (gemm_wp.h, 128x64 per wave) for row-major operands;
 //   bit 5 (32):   ... for dX GEMMs the phased kernel does not take;   bit 6 (64): ... for dW GEMMs (both k-major);
-//   bit 7 (128):  phased kernel for every dX GEMM (tests).
+//   bit 7 (128):  phased kernel for every dX GEMM (tests);
+//   bit 8 (256):  row-major 8-wave kernel built with the operand DMA issued through the compiler builtin (A/B reference).
 // (gemm_wp.h also instantiates as 4 waves x 128x128 -- one wave per SIMD, half the LDS fragment traffic -- but a lone
 // wave cannot cover its own DMA issue slots: 4-10 % behind the 8-wave layout on every shape, not built.)
 // Every kernel produces bit-identical results (same fp32 chain over k per output element): tests/test_kernels_gpu.py.
 static int g_gemm_variant = 115;
 int g_gemm_strip = 0;
 int g_gemm_cus = 256;
+static int g_gemm_stage_next = 1;   // dw_debug_set key 11: request the next job's first K tile under the epilogue (gemm_wp.h)
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
 
 // Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never
@@ -78,6 +81,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 7) { g_decode_fuse_off = value; return DW_OK; }
     if (key == 8) { g_skinny_wide = value; return DW_OK; }
     if (key == 10) { g_gemm_dynamic = value; return DW_OK; }
+    if (key == 11) { g_gemm_stage_next = value; return DW_OK; }
     if (key == 9) { if (value < 8 || value > 256 || (value & 7)) return DW_EINVAL; g_gemm_cus = value; return DW_OK; }
     return DW_EINVAL;
 }
@@ -131,6 +135,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.slice_stride = 0;
     p.sched = nullptr;
     p.zg_f16 = g->z_is_gelu_grad ? 1 : 0;
+    p.stage_next = g_gemm_stage_next;
     if (p.zg_f16 && g->z_out && g->act != 1) return DW_EINVAL;   // gelu'(z) is a by-product of the GELU epilogue
     p.ln_x = g->ln_x; p.ln_g = g->ln_gamma; p.ln_b = g->ln_beta; p.ld_lnx = g->ld_lnx; p.ln_x_dtype = g->ln_x_dtype;
     p.ln_eps = g->ln_eps;
@@ -184,7 +189,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
                 // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
                 // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
                 const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
-                if ((v & 16) && wp_ok && !epi_bound) return dw_gemm_wp8_nn_launch(q, s);
+                if ((v & 16) && wp_ok && !epi_bound) return (v & 256) ? dw_gemm_wp8_nn_ref_launch(q, s) : dw_gemm_wp8_nn_launch(q, s);
             } else if (!g->trans_a && g->trans_b) {
                 if (((v & 4) && g->k >= 3840 && q.split_k == 1) || (v & 128)) return dw_gemm_phased_launch(q, 0, 1, s);
                 if ((v & 32) && wp_ok) return dw_gemm_wp8_nt_launch(q, s);

@@ -29,6 +29,7 @@ struct GemmP {
     bf16* kv_out;          // output columns >= kv_split of row m go to the K/V cache instead of C:
     long kv_ld;            //   kv_out[((m / kv_rpb) * kv_pitch + kv_row0 + m % kv_rpb) * kv_ld + (n - kv_split)]
     int kv_split, kv_rpb, kv_pitch, kv_row0;
+    int stage_next;        // software-pipelined kernels: request the next job's first K tile under the epilogue (debug key 11)
     int zg_f16;            // z_out / zgrad hold gelu'(z) in fp16 instead of z in bf16 (see DwGemm.z_is_gelu_grad)
     int* sched;            // persistent kernels: 9 device counters of this stream (dynamic job hand-out), or null
 };
@@ -249,9 +250,12 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
     }
 }
 
-template <int FM, int FN, int TN, int PFDIST = 0>
+struct GemmNoHook { __device__ __forceinline__ void operator()() const {} };
+// `hook` runs once per wave after the epilogue's leading loads are issued and before its first barrier (the software
+// pipelined kernels request the next job's first operand tile there).
+template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
-                                              int m0, int wm0, int n0, int wn0, int ks) {
+                                              int m0, int wm0, int n0, int wn0, int ks, Hook hook = Hook()) {
     // ---- epilogue ----
     // The MFMAs were issued as (B-fragment, A-fragment), so each 32x32 accumulator holds the TRANSPOSED output tile:
     // lane&31 = output row, register r = output column (r&3) + 8*(r>>2) + 4*(lane>>5).  Every wave turns its
@@ -333,6 +337,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
         auto walk = [&](auto side_c) __attribute__((always_inline)) {
             constexpr bool SIDE = decltype(side_c)::value;
             if constexpr (SIDE) static_for<0, PFD>([&](auto gc) __attribute__((always_inline)) { side_load(gc); });
+            hook();
             __syncthreads();                       // every wave is done reading the operand tiles
             static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
@@ -360,6 +365,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     }
 
     // ---- general walk (ragged tile edges, unaligned pointers, atomic accumulation): looped, loads at use ----
+    hook();
     __syncthreads();
     static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;

@@ -32,7 +32,29 @@
 #define PINF(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]), "+v"((f)[2]), "+v"((f)[3]))
 #define PINF2(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]))
 
-template <bool TA, bool TB, int WM, int WN>
+// One 16-byte-per-lane operand DMA (buffer_load_dwordx4 ... lds: LDS destination = M0 + lane * 16), written as inline
+// assembly ON PURPOSE.  Issued through the builtin, the compiler models it as an LDS store it cannot disambiguate from
+// the fragment reads of the OTHER K-tile buffer and puts `s_waitcnt vmcnt(0)` in front of the first ds_read after every
+// DMA issue: the wave then sits out the whole operand latency once per K tile (the "parked on vmcnt" 40 % of the PMC
+// profile), and the two-sub-step lead the pipeline gives each piece is never used.  Hidden from its memory model, the
+// only vmcnt waits left are the explicit ones in front of the barriers.  (Giving the two buffers separate LDS
+// variables + a K loop unrolled by two, so that alias scopes exist, also removes the wait but costs 8 address
+// registers the kernel does not have: 1 700 spilled dwords.)
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+__device__ __forceinline__ i32x4_t wp_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4_t r;
+    r[0] = (int)(unsigned)a; r[1] = (int)((unsigned)(a >> 32) & 0xffffu); r[2] = 0x7fffffff; r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void wp_dma16(const i32x4_t& rsrc, const char* lds_dst, unsigned voffset, int soffset) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const lds_void_t*)lds_dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(m0v), "v"(voffset), "s"(rsrc), "s"(soffset));
+}
+
+// ASMDMA = false builds the same kernel with the operand DMA issued through the compiler builtin (A/B reference only).
+template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(const GemmP p) {
     constexpr int BM = 256, BN = 256, NW = WM * WN, FM = BM / WM / 32, FN = BN / WN / 32, TN = BN / WN;
     static_assert(NW * 32 * (TN + 4) * 4 <= 2 * (BM + BN) * 128, "epilogue patches must fit the operand buffers");
@@ -113,8 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             gA = (const bf16*)((const char*)gA + (long)first * stepA);
             gB = (const bf16*)((const char*)gB + (long)first * stepB);
         }
-        const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);
-        const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, 0x7fffffff, 0x00020000);
+        const i32x4_t rsA = wp_rsrc(gA), rsB = wp_rsrc(gB);
         int kA = 0, kB = 0;                               // byte offset of the K tile the next DMA fetches
 
         f32x16 acc[FM][FN];
@@ -125,16 +146,25 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // this wave's pieces [4 half, 4 half + 4) of both operands of the K tile at (kA, kB) into LDS buffer `buf`
-        auto dma = [&](auto hc, int buf) {
-            constexpr int h = decltype(hc)::value;
-            char* tA = smem + buf * STAGE + wave * 1024;
-            char* tB = tA + BM * 128;
-#pragma unroll
-            for (int i = (CP / 2) * h; i < (CP / 2) * (h + 1); ++i) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(tA + i * (NW * 1024)), 16, offA[i], kA, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(tB + i * (NW * 1024)), 16, offB[i], kB, 0, 0);
+        // load j (0 .. CP-1) of half h of the K tile at (kA, kB) into LDS buffer `buf`: piece (CP/2) h + j/2 of A (j even)
+        // or B (j odd); a wave issues CP loads per half
+        auto dma1 = [&](auto hc, auto jc, int buf) __attribute__((always_inline)) {
+            constexpr int i = (CP / 2) * decltype(hc)::value + decltype(jc)::value / 2;
+            const char* tA = smem + buf * STAGE + wave * 1024 + i * (NW * 1024);
+            if constexpr (ASMDMA) {
+                if constexpr ((decltype(jc)::value & 1) == 0) wp_dma16(rsA, tA, offA[i], kA);
+                else wp_dma16(rsB, tA + BM * 128, offB[i], kB);
+            } else {
+                const auto bA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);
+                const auto bB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, 0x7fffffff, 0x00020000);
+                if constexpr ((decltype(jc)::value & 1) == 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(bA, (lds_void_t*)tA, 16, offA[i], kA, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(bB, (lds_void_t*)(tA + BM * 128), 16, offB[i], kB, 0, 0);
             }
+        };
+        auto dma = [&](auto hc, int buf) __attribute__((always_inline)) {
+            static_for<0, CP>([&](auto jc) __attribute__((always_inline)) { dma1(hc, jc, buf); });
         };
         bf16x8 af[2][FM], bfr[2][FN];
         auto frags = [&](auto sc, auto kc, int buf) {
@@ -152,30 +182,39 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
                 else bfr[set][j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane);
             }
         };
-        auto mfmas = [&](auto sc) {
-            constexpr int set = decltype(sc)::value;
-            static_for<0, FM>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                static_for<0, FN>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][j], af[set][i], acc[i][j], 0, 0, 0);
-                });
-            });
+        // The MFMAs of a sub-step with the memory instructions pinned between them: fragment reads in the first gaps
+        // (sched_group_barrier: one MFMA, then a group of DS reads), then -- VH = 1 / 2 -- the CP operand loads of half
+        // VH - 1, one per gap (inline assembly has no scheduling class: each is fenced into its gap).  The DMA writes a
+        // buffer no wave reads any more, so its place behind the reads is a choice, not a dependence.
+        // Masks: 0x8 MFMA, 0x100 DS read.
+        auto mfma1 = [&](auto sc, auto qc) __attribute__((always_inline)) {
+            constexpr int set = decltype(sc)::value, i = decltype(qc)::value / FN, j = decltype(qc)::value % FN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[set][j], af[set][i], acc[i][j], 0, 0, 0);
         };
-        // pinned interleave of a sub-step: one MFMA, then one memory instruction group.  The DMA writes LDS, so program
-        // order keeps it behind the sub-step's fragment reads: reads go to the first gaps, DMA pieces to the next ones.
-        // Masks: 0x8 MFMA, 0x100 DS read, 0x20 VMEM read.
-        auto interleave = [&](auto rc, auto vc) {
-            constexpr bool R = decltype(rc)::value != 0, V = decltype(vc)::value != 0;
+        auto substep = [&](auto sc, auto rc, auto vhc, int dbuf) __attribute__((always_inline)) {
+            constexpr bool R = decltype(rc)::value != 0;
+            constexpr int VH = decltype(vhc)::value;
             constexpr int NMF = FM * FN;
             constexpr int DSI = FM * (TA ? 2 : 1) + FN * (TB ? 2 : 1);   // DS instructions of the sub-step's fragments
-            constexpr int RG = V ? NMF / 4 : NMF / 2;                    // gaps that carry fragment reads
+            constexpr int RG = VH ? NMF / 4 : NMF / 2;                   // gaps that carry fragment reads
             constexpr int PER = (DSI + RG - 1) / RG;
+            static_assert(RG + CP <= NMF, "not enough MFMA gaps for the operand loads");
+            static_for<0, RG>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
 #pragma unroll
-            for (int q = 0; q < NMF; ++q) {
+            for (int q = 0; q < RG; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                if (R && q < RG) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
-                if (V && q >= RG && q < RG + CP) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+                if (R) __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VH != 0) {
+                static_for<0, CP>([&](auto jc) __attribute__((always_inline)) {
+                    mfma1(sc, std::integral_constant<int, RG + decltype(jc)::value>{});
+                    dma1(std::integral_constant<int, VH - 1>{}, jc, dbuf);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                static_for<RG + CP, NMF>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
+            } else {
+                static_for<RG, NMF>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -184,6 +223,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>;
         using I8 = std::integral_constant<int, 8>;
+        (void)sizeof(I8);
 
         // ---- prologue: tile 0 whole, first half of tile 1, fragments of (0, 0) ----
         dma(I0{}, 0); dma(I1{}, 0);
@@ -198,22 +238,19 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         auto body = [&](auto m1c, auto m2c, int t) {
             constexpr bool MORE1 = decltype(m1c)::value, MORE2 = decltype(m2c)::value;
             const int buf = t & 1;
-            // sub-step 0
+            // sub-step 0: second half of tile t+1
             if constexpr (FM == 4) PINF(af[0]); else PINF2(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
             frags(I1{}, I1{}, buf);
-            if constexpr (MORE1) { dma(I1{}, buf ^ 1); kA += stepA; kB += stepB; }
-            mfmas(I0{});
-            if constexpr (MORE1) interleave(I8{}, I8{}); else interleave(I8{}, I0{});
+            if constexpr (MORE1) { substep(I0{}, I1{}, I2{}, buf ^ 1); kA += stepA; kB += stepB; }
+            else substep(I0{}, I1{}, I0{}, 0);
             // sub-step 1
             if constexpr (FM == 4) PINF(af[1]); else PINF2(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
             frags(I0{}, I2{}, buf);
-            mfmas(I1{});
-            interleave(I8{}, I0{});
+            substep(I1{}, I1{}, I0{}, 0);
             // sub-step 2
             if constexpr (FM == 4) PINF(af[0]); else PINF2(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
             frags(I1{}, I3{}, buf);
-            mfmas(I0{});
-            interleave(I8{}, I0{});
+            substep(I0{}, I1{}, I0{}, 0);
             // every wave: its DMA pieces of tile t+1 have landed, its last fragments of tile t are in registers
             if constexpr (FM == 4) PINF(af[1]); else PINF2(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
             if constexpr (MORE1) {
@@ -221,13 +258,11 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // sub-step 3
+            // sub-step 3: fragments of (t+1, 0), first half of tile t+2
             if constexpr (MORE1) frags(I0{}, I0{}, buf ^ 1);
-            if constexpr (MORE2) dma(I0{}, buf);
-            mfmas(I1{});
-            if constexpr (MORE2) interleave(I8{}, I8{});
-            else if constexpr (MORE1) interleave(I8{}, I0{});
-            else interleave(I0{}, I0{});
+            if constexpr (MORE2) substep(I1{}, I1{}, I1{}, buf);
+            else if constexpr (MORE1) substep(I1{}, I1{}, I0{}, 0);
+            else substep(I1{}, I0{}, I0{}, 0);
         };
         int t = 0;
         for (; t + 2 < nt; ++t) body(std::true_type{}, std::true_type{}, t);
@@ -241,7 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     gemm_jobs_end(p, jobs);
 }
 
-template <bool TA, bool TB, int WM, int WN>
+template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true>
 static int launch_wp(const GemmP& p0, hipStream_t s) {
     GemmP p = p0;
     const int tiles_m = (p.m + 255) / 256;
@@ -250,7 +285,7 @@ static int launch_wp(const GemmP& p0, hipStream_t s) {
     p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
     if (nblk > g_gemm_cus) nblk = g_gemm_cus;
-    hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
+    hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN, ASMDMA>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

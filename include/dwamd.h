@@ -239,12 +239,18 @@ int dw_decode_step(const DwDecodeStep* d, void* stream);
 /* ---- self tests (diagnostics for bring-up; not on the hot path) --------------------------------------------------
  * Runs ds_read_b64_tr_b16 on a known LDS image: out int32 [64][4] = element ids received by each lane. */
 int dw_selftest_tr16(int32_t* out, void* stream);
-/* Tuning knobs for kernel A/B experiments; not part of the hot path.  key 0: GEMM main loop (3 = plain 16-wave
- * 256x256 / 8-wave 128x128 tile kernels, 5 = phase-pipelined kernel for every 256-tile dX GEMM,
- * 7 = 3 + phase-pipelined kernel for long-K dX GEMMs [default]); key 1:
- * strip width override (0 = rule); key 2: persistent workgroups on/off; key 3: attention backward variant (bit 0 dQ,
- * bit 1 dK/dV fast tile staging, bit 2 dK/dV at 3 waves per SIMD; default 5); key 4: single-query attention through
- * the streaming decode kernel (default 1). */
+/* Tuning knobs for kernel A/B experiments and tests; not part of the hot path (defaults are the measured best).
+ *   key 0   GEMM kernel selection, bit mask (default 115): bits 0-1 base 16-wave tile kernel; bit 2 phase-pipelined
+ *           kernel for dX GEMMs with K >= 3840; bits 4/5/6 8-wave software-pipelined kernel for row-major / k-major-B /
+ *           both-k-major operands; bit 7 phase-pipelined kernel for every dX GEMM.  All bit-identical.
+ *   key 1   rasterisation strip width override (0 = rule);   key 6  strip L2 budget in 512 KiB units (default 8)
+ *   key 2   persistent workgroups on/off;   key 9  persistent grid size in CUs (multiple of 8, default 256)
+ *   key 10  dynamic per-XCD tile hand-out (default 1);   key 11  request the next tile's first operands under the
+ *           epilogue in the software-pipelined kernels (default 1)
+ *   key 3   attention backward variant (bit 0 dQ, bit 1 dK/dV fast tile staging, bit 2 dK/dV at 3 waves per SIMD;
+ *           default 5);   key 4  single-query attention kernel (bit 0 on [default], bit 1 all-loads-up-front variant)
+ *   key 5   log-mel DFT on the matrix cores (default 1);   key 7  decode-step fusions off (bit 0 LayerNorm-on-load,
+ *           bit 1 K/V append);   key 8  wide LM-head GEMV (default 1) */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus

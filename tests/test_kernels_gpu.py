@@ -193,6 +193,36 @@ def test_gemm_dynamic_job_handout_is_invisible(ops, ref):
         ops.lib.dw_debug_set(9, 256); ops.lib.dw_debug_set(10, 1)
 
 
+def test_gemm_next_tile_staging_under_the_epilogue_is_invisible(ops, ref):
+    """The software-pipelined kernels request the NEXT tile's first operand block into LDS buffer 0 while the epilogue
+    of the current tile runs out of buffer 1 (dw_debug_set key 11; even K-tile counts only).  Same bits with it on and
+    off: every operand layout, 2 / 4 / 20 K tiles (and an odd count, which must not stage), more tiles than
+    workgroups with ragged edges, static and dynamic hand-out, epilogues with and without side inputs, repeated
+    launches (race screen)."""
+    try:
+        for ta, tb in ((False, False), (False, True), (True, True)):
+            for M, N, K in ((9000, 2048, 128), (9000, 2000, 256), (4104, 5120, 1280), (9000, 2048, 192)):
+                a = rnd((K, M) if ta else (M, K), 0.5, seed=91)
+                b = rnd((K, N) if tb else (N, K), 0.1, seed=92)
+                bias = rnd((N,), 0.5, torch.float32, seed=93)
+                res = rnd((M, N), 1.0, torch.float32, seed=94)
+                zg = rnd((M, N), 1.0, seed=95)
+                runs = (lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, act=1, tile=256),
+                        lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, bias=bias, residual=res,
+                                         out_dtype=torch.float32, tile=256),
+                        lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, zgrad=zg, tile=256))
+                ops.lib.dw_debug_set(11, 0)
+                want = [f().clone() for f in runs]
+                ops.lib.dw_debug_set(11, 1)
+                for dyn in (1, 0):
+                    ops.lib.dw_debug_set(10, dyn)
+                    for rep in range(2):
+                        for f, w in zip(runs, want):
+                            assert torch.equal(f(), w), (ta, tb, M, N, K, dyn)
+    finally:
+        ops.lib.dw_debug_set(10, 1); ops.lib.dw_debug_set(11, 1)
+
+
 @pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,n_new", [(1, 1), (16, 1), (12, 3), (32, 2)])
 def test_gemm_skinny_layernorm_on_load_and_kv_append(ops, ref, xdtype, M, n_new):
