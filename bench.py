@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream (default: side stream)")
+    ap.add_argument("--no-wgrad-overlap", action="store_true",
+                    help="weight-gradient GEMMs of the backward on the main stream (default: second stream)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -89,7 +91,8 @@ def main():
     recipe = args.mode == "recipe"
     tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
-                             mel_filters=filt, overlap_teacher=not args.no_overlap)
+                             mel_filters=filt, overlap_teacher=not args.no_overlap,
+                             overlap_wgrad=not (args.no_wgrad_overlap or args.no_overlap))
     del t_sd, s_sd
     torch.cuda.empty_cache()
 
@@ -157,11 +160,14 @@ def main():
     if not args.no_roofline:
         ops.profile = {}
         overlap, tr.overlap_teacher = tr.overlap_teacher, False   # one kernel at a time for the per-launch events
+        wgrad_overlap = tr.student.wgrad_stream is not None
+        tr.set_overlap_wgrad(False)
         one_step()
         torch.cuda.synchronize()
         prof = ops.collect_profile()
         ops.profile = None
         tr.overlap_teacher = overlap
+        tr.set_overlap_wgrad(wgrad_overlap)
         log("per-kernel-class ms (instrumented step): " + json.dumps(
             {k: {"n": v["n"], "ms": round(v["ms"], 2), "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1)}
              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}))

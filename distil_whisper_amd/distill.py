@@ -40,11 +40,14 @@ class GradReducer:
         self.handles = []
         self.cuda = flat.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.active) else None
+        self.also_wait = []
 
     def _launch(self, lo, hi):
         view = self.flat[lo:hi]
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            for w in self.also_wait:      # streams that also write gradients (the engine's weight-gradient stream)
+                self.stream.wait_stream(w)
             with torch.cuda.stream(self.stream):
                 self.handles.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM, group=self.group,
                                                          async_op=True))
@@ -81,7 +84,7 @@ class DistillationTrainer:
     def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
                  share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None,
-                 overlap_teacher=False, bucket_bytes=256 << 20, always_reduce=False):
+                 overlap_teacher=False, overlap_wgrad=False, bucket_bytes=256 << 20, always_reduce=False):
         self.ops = ops
         self.sdims, self.tdims = WhisperDims.from_any(student_dims), WhisperDims.from_any(teacher_dims)
         frozen = []
@@ -109,10 +112,22 @@ class DistillationTrainer:
         # so that per-kernel profiles of the step stay one-kernel-at-a-time)
         self.overlap_teacher = overlap_teacher and self.student_store.P.is_cuda
         self._tstream = torch.cuda.Stream(device=self.student_store.P.device) if self.overlap_teacher else None
+        # optional: the weight-gradient GEMMs of the student's backward on a second stream (engine._wgrad): they are off
+        # the critical path, and a persistent GEMM of one stream takes the CUs the other stream's kernel leaves idle in
+        # its last round of tiles
+        self.set_overlap_wgrad(overlap_wgrad)
         self._sumsq = ops.zeros((1,), torch.float32)
         self._accum = 1            # micro-batches summed in the gradient buffer of the current optimizer step
         self._last_gm = 1.0        # gradient multiplier the last optimizer step applied (1 / (world * accum))
         self.segments = st.adam_segments(weight_decay)
+
+    def set_overlap_wgrad(self, on):
+        on = bool(on) and self.student_store.P.is_cuda
+        ws = torch.cuda.Stream(device=self.student_store.P.device) if on else None
+        self.student.join_wgrad_stream()
+        self.student.wgrad_stream = ws
+        if self.reducer is not None:
+            self.reducer.also_wait = [ws] if ws is not None else []
 
     # ------------------------------------------------------------------------------------------------------------
     def features(self, audio):
@@ -128,6 +143,8 @@ class DistillationTrainer:
         input_features = input_features.to(torch.float32).contiguous()
         decoder_input_ids = decoder_input_ids.contiguous()
         labels_flat = labels.reshape(-1).contiguous()
+        if self.overlap_teacher and self._tstream is None:
+            self._tstream = torch.cuda.Stream(device=self.student_store.P.device)
         side = self._tstream if (self.overlap_teacher and not self.share_encoder) else None
         if side is not None:
             main = torch.cuda.current_stream(input_features.device)
@@ -164,6 +181,7 @@ class DistillationTrainer:
             self.reducer.ready(st.train_start if self.freeze_encoder else st.dec_start, st.train_end)
         if not self.freeze_encoder:
             S.backward_encoder(ectx, denc, on_ready=self.reducer.ready if dp else None)
+        S.join_wgrad_stream()
         return losses
 
     def optimizer_step(self, lr=None):

@@ -220,6 +220,7 @@ class WhisperEngine:
         self.stream = stream_dtype
         self.lowp = ops.lowp
         self.ldv = _rup(self.dims.vocab, 64)
+        self.wgrad_stream = None   # torch.cuda.Stream: weight-gradient GEMMs / bias column sums of the backward go there
 
     # ---- helpers -------------------------------------------------------------------------------------------------
     def act(self, rows, cols, dtype=None):
@@ -262,6 +263,24 @@ class WhisperEngine:
 
     def _wgrad(self, dy, x, gout, gbias, R, bias_cols=None):
         """gout (+)= dy^T . x over the (padded) token dimension; gbias (+)= column sums of dy."""
+        ws = self.wgrad_stream
+        if ws is not None:
+            # Weight gradients are off the critical path of the backward (nothing below reads them): issued on a second
+            # stream, their persistent GEMMs take the CUs the dX chain's kernels leave idle in their last tile round
+            # (and vice versa).  Ordering: the side stream waits for everything the main stream has enqueued so far
+            # (dy and x are complete); the caller joins the streams before anyone reads the gradients
+            # (join_wgrad_stream).  record_stream keeps the allocator from handing dy / x to a later main-stream
+            # kernel while the side stream still reads them.
+            main = torch.cuda.current_stream(dy.device)
+            ws.wait_stream(main)
+            with torch.cuda.stream(ws):
+                self._wgrad_issue(dy, x, gout, gbias, R, bias_cols)
+            dy.record_stream(ws)
+            x.record_stream(ws)
+        else:
+            self._wgrad_issue(dy, x, gout, gbias, R, bias_cols)
+
+    def _wgrad_issue(self, dy, x, gout, gbias, R, bias_cols):
         if gout is not None:  # the gradient buffer was zeroed (or holds earlier micro-batches): always accumulate
             self.ops.gemm(dy, x, trans_a=True, trans_b=True, out_dtype=torch.float32, out=gout, atomic_acc=True)
         if gbias is not None:
@@ -270,6 +289,12 @@ class WhisperEngine:
             else:
                 for lo, hi in bias_cols:
                     self.ops.colsum(dy[:R, lo:hi], gbias[lo:hi], accumulate=True)
+
+    def join_wgrad_stream(self):
+        """The main stream waits for every weight-gradient kernel issued so far (before the optimizer, the gradient
+        all-reduce of a finished range, or any other reader of the gradient buffer)."""
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream(self.st.P.device).wait_stream(self.wgrad_stream)
 
     # ---- encoder -------------------------------------------------------------------------------------------------
     def encode(self, mel, save=False):

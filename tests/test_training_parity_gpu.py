@@ -169,8 +169,8 @@ def test_trainer_over_rccl_with_one_rank_equals_plain_trainer(ops):
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
-        tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, always_reduce=True, bucket_bytes=64 << 10)
-        assert tr.reducer.stream is not None
+        tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, always_reduce=True, bucket_bytes=64 << 10, overlap_wgrad=True)
+        assert tr.reducer.stream is not None and tr.reducer.also_wait == [tr.student.wgrad_stream]
         launched = []
         orig = tr.reducer._launch
         tr.reducer._launch = lambda lo, hi: launched.append((lo, hi)) or orig(lo, hi)
@@ -182,6 +182,48 @@ def test_trainer_over_rccl_with_one_rank_equals_plain_trainer(ops):
     finally:
         dist.destroy_process_group()
     assert relerr(p_dp, p_plain) < 1e-6 and abs(gn_dp - gn_plain) < 1e-4 * gn_plain
+
+
+def test_weight_gradient_stream_equals_single_stream(ops):
+    """overlap_wgrad=True issues the weight-gradient GEMMs and bias column sums of the backward on a second HIP stream
+    (engine._wgrad); the gradients, the clipped norm and the parameters after two steps must equal the single-stream
+    run (weight-matrix gradients bit for bit: same kernels, same operands; the whole buffer to the float-atomic
+    summation noise of the bias / LayerNorm gradients).  Also with the teacher forward on its own stream and with
+    gradient accumulation."""
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 95)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    b = wo.synthetic_batch(cfg_t, 2, seed=96, T=64, with_audio=False)
+    feats = (torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(9)) * 0.5).cuda()
+    ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+
+    def run(tr, accumulate=False):
+        tr.forward_backward(feats, ids, labels)
+        torch.cuda.synchronize()
+        g = tr.student_store.G.clone()
+        tr.optimizer_step()
+        if accumulate:
+            tr.train_step_accumulated([(feats, ids, labels), (feats, ids, labels)])
+        else:
+            tr.train_step(feats, ids, labels)
+        torch.cuda.synchronize()
+        return g, tr.student_store.P.clone(), tr.grad_norm().item()
+    g0, p0, n0 = run(make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd))
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, overlap_wgrad=True, overlap_teacher=True)
+    assert tr.student.wgrad_stream is not None
+    g1, p1, n1 = run(tr)
+    st = tr.student_store
+    for name in ("model.encoder.layers.1.fc1.weight", "model.encoder.layers.0.self_attn.q_proj.weight",
+                 "model.decoder.layers.0.encoder_attn.out_proj.weight", "model.decoder.layers.0.fc2.weight"):
+        o, shape, _ = st.entries[name]
+        n = 1
+        for d in shape:
+            n *= d
+        assert torch.equal(g1[o:o + n], g0[o:o + n]), name
+    assert relerr(g1, g0) < 1e-6 and relerr(p1, p0) < 1e-6 and abs(n1 - n0) < 1e-4 * n0
+    ga, pa, _ = run(make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd), accumulate=True)
+    gb, pb, _ = run(make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, overlap_wgrad=True), accumulate=True)
+    assert relerr(pb, pa) < 1e-6
 
 
 def test_trainer_save_and_resume_continues_the_run(ops):
