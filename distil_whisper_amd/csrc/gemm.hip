@@ -26,6 +26,9 @@ int dw_gemm_phased_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // ge
 int dw_gemm_tile256_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile256.hip: 16 waves, 4 x 4
 int dw_gemm_tile128_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile128.hip: 8 waves, 2 x 4
 int dw_gemm_wp8_nn_ref_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_nn_ref.hip (builtin DMA; A/B only)
+int dw_gemm_wp8_nn320_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_m320.hip (320 x 256 block tile)
+int dw_gemm_wp8_nt320_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp8_nn_dbg_launch(const GemmP& p, int dbg, hipStream_t s);         // gemm_wp8_dbg.hip (main-loop ablations; profiling only)
 int dw_gemm_wp8_nn_launch(const GemmP& p, hipStream_t s);                   // gemm_wp8_*.hip: software-pipelined loop, 8 waves
 int dw_gemm_wp8_nt_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp8_tt_launch(const GemmP& p, hipStream_t s);
@@ -47,7 +50,7 @@ int g_gemm_persistent = 1;
 // (gemm_wp.h also instantiates as 4 waves x 128x128 -- one wave per SIMD, half the LDS fragment traffic -- but a lone
 // wave cannot cover its own DMA issue slots: 4-10 % behind the 8-wave layout on every shape, not built.)
 // Every kernel produces bit-identical results (same fp32 chain over k per output element): tests/test_kernels_gpu.py.
-static int g_gemm_variant = 115;
+static int g_gemm_variant = 2163;   // 115 (8-wave software-pipelined kernels + phased dX) | 2048 (320-row tiles where they pay)
 int g_gemm_strip = 0;
 int g_gemm_cus = 256;
 static int g_gemm_stage_next = 1;   // dw_debug_set key 11: request the next job's first K tile under the epilogue (gemm_wp.h)
@@ -112,6 +115,7 @@ extern "C" int dw_reduce_slices(const float* part, int64_t stride, int slices, f
     return DW_OK;
 }
 
+static inline bool q_split_ok(const GemmP& p) { return p.split_k == 1 && !p.atomic; }
 extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     DW_CLEAR_ERR();
     if (!g || (!g->a && !g->ln_x) || !g->b || !g->c) return DW_EINVAL;
@@ -184,11 +188,29 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         const int v = g_gemm_variant;
         p.strip = g_gemm_strip;
         if (g_gemm_dynamic) p.sched = gemm_sched_slot(s);
+        // 320-row tiles (row-major A, variant bit 2048; gemm_wp.h): M % 320 == 0, N % 256 == 0, and no more rounds of the
+        // CUs than 256-row tiles need, counted in 256-row-tile times (a 320-row tile costs 1.25).  Measured against the
+        // 256-row kernels on M = 48000 (tools/bench_gemm_variants.py): +7..8 % for K >= 3840 on both operand layouts
+        // (also against the phased kernel), +2..6 % for row-major B with N >= 2560 at K = 1280, -2 % (NN) / -7 % (NT) at
+        // N = K = 1280 and -3 % for k-major B at N = 5120, K = 1280: those keep the 256-row tile.  Bit 4096 forces the
+        // 320-row tile wherever it is eligible (experiments).
+        bool use320 = false;
+        if ((v & 2048) && wp_ok && !g->trans_a && q_split_ok(p) && g->m % 320 == 0 && g->n % 256 == 0) {
+            const long tn = g->n / 256;
+            const long r256 = (((g->m + 255) / 256) * tn + g_gemm_cus - 1) / g_gemm_cus * 4;
+            const long r320 = ((g->m / 320) * tn + g_gemm_cus - 1) / g_gemm_cus * 5;
+            const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
+            if (v & 4096) use320 = true;
+            else if (!g->trans_b) use320 = r320 <= r256 && !epi_bound && (g->k >= 2560 || g->n >= 2560);
+            else use320 = r320 < r256 && g->k >= 2560;
+        }
         auto launch256 = [&](const GemmP& q) -> int {
+            if (use320) return g->trans_b ? dw_gemm_wp8_nt320_launch(q, s) : dw_gemm_wp8_nn320_launch(q, s);
             if (!g->trans_a && !g->trans_b) {
                 // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
                 // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
                 const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
+                if ((v & 16) && wp_ok && !epi_bound && (v & 1536)) return dw_gemm_wp8_nn_dbg_launch(q, (v >> 9) & 3, s);
                 if ((v & 16) && wp_ok && !epi_bound) return (v & 256) ? dw_gemm_wp8_nn_ref_launch(q, s) : dw_gemm_wp8_nn_launch(q, s);
             } else if (!g->trans_a && g->trans_b) {
                 if (((v & 4) && g->k >= 3840 && q.split_k == 1) || (v & 128)) return dw_gemm_phased_launch(q, 0, 1, s);

@@ -29,7 +29,7 @@ struct GemmP {
     bf16* kv_out;          // output columns >= kv_split of row m go to the K/V cache instead of C:
     long kv_ld;            //   kv_out[((m / kv_rpb) * kv_pitch + kv_row0 + m % kv_rpb) * kv_ld + (n - kv_split)]
     int kv_split, kv_rpb, kv_pitch, kv_row0;
-    int stage_next;        // software-pipelined kernels: request the next job's first K tile under the epilogue (debug key 11)
+    int stage_next;        // debug key 11; bit 4 (16): the software-pipelined kernels skip the epilogue (profiling: tools/gemm_overhead.py)
     int zg_f16;            // z_out / zgrad hold gelu'(z) in fp16 instead of z in bf16 (see DwGemm.z_is_gelu_grad)
     int* sched;            // persistent kernels: 9 device counters of this stream (dynamic job hand-out), or null
 };
@@ -182,8 +182,9 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, i
 // One epilogue row group: 4 consecutive output columns of one row, all fused element-wise work of the GEMM (bias, Z
 // store, GELU, GELU' with the prefetched z, residual add with the prefetched r, C store).  `v` holds the fp32
 // accumulator values; the caller guarantees the 4 columns are in range and every pointer allows 4-wide accesses.
+// `cdst` / `zdst`: addresses of the 4 output elements in C (element size per c_dtype) and in z_out (2-byte elements).
 __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], const f32x4& b4, bool plain, bool have_side,
-                                              const bf16x4& zs, const f32x4& rs, float* cf, int m, int n) {
+                                              const bf16x4& zs, const f32x4& rs, char* cdst, char* zdst) {
     if (!plain) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += b4[e];
@@ -191,7 +192,7 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
             bf16x4 z4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
-            *(bf16x4*)(p.z_out + (long)m * p.ldz + n) = z4;
+            *(bf16x4*)zdst = z4;
         }
         if (p.act == 1) {
             const bool store_g = p.z_out && p.zg_f16;
@@ -207,7 +208,7 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
                     g4[e] = (_Float16)g2[0]; g4[e + 1] = (_Float16)g2[1];
                 }
             }
-            if (store_g) *(f16x4*)((_Float16*)p.z_out + (long)m * p.ldz + n) = g4;
+            if (store_g) *(f16x4*)zdst = g4;
         }
         if (have_side) {
             if (p.zgrad && p.zg_f16) {                    // the forward stored gelu'(z) (fp16 bits in the bf16-typed slots)
@@ -241,12 +242,12 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[e];
-        *(f32x4*)(cf + (long)m * p.ldc + n) = o;
+        *(f32x4*)cdst = o;
     } else {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *(bf16x4*)((bf16*)p.c + (long)m * p.ldc + n) = o;
+        *(bf16x4*)cdst = o;
     }
 }
 
@@ -255,7 +256,12 @@ struct GemmNoHook { __device__ __forceinline__ void operator()() const {} };
 // pipelined kernels request the next job's first operand tile there).
 template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
-                                              int m0, int wm0, int n0, int wn0, int ks, Hook hook = Hook()) {
+                                              int m0_, int wm0_, int n0_, int wn0_, int ks_, Hook hook = Hook()) {
+    // tile and wave coordinates are the same in every lane: say so (the job index comes out of an LDS slot, which the
+    // compiler must otherwise treat as a per-lane value, and every row address would be 64-bit vector arithmetic)
+    const int m0 = __builtin_amdgcn_readfirstlane(m0_), wm0 = __builtin_amdgcn_readfirstlane(wm0_);
+    const int n0 = __builtin_amdgcn_readfirstlane(n0_), wn0 = __builtin_amdgcn_readfirstlane(wn0_);
+    const int ks = __builtin_amdgcn_readfirstlane(ks_);
     // ---- epilogue ----
     // The MFMAs were issued as (B-fragment, A-fragment), so each 32x32 accumulator holds the TRANSPOSED output tile:
     // lane&31 = output row, register r = output column (r&3) + 8*(r>>2) + 4*(lane>>5).  Every wave turns its
@@ -283,7 +289,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     const int n = n0 + wn0 + pc;
     const bool n_in = n < p.n;
     const bool full = p.vec && n + 3 < p.n;
-    const bool interior = p.vec && !p.atomic && n0 + wn0 + TN <= p.n && m0 + wm0 + FM * 32 <= p.m;
+    const bool interior = p.vec && !p.atomic && p.r_row_mod <= 0 && n0 + wn0 + TN <= p.n && m0 + wm0 + FM * 32 <= p.m;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && n_in) {
         if (full) b4 = *(const f32x4*)(p.bias + n);
@@ -316,18 +322,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
         // waves share a SIMD (128 registers per lane, and the other waves cover more of the latency).
         const bool pf_z = p.zgrad != nullptr, pf_r = p.r != nullptr;
         constexpr int PFD = PFDIST > 0 ? (PFDIST < NIT ? PFDIST : NIT) : NIT;
+        // Addresses: every access of the walk is (wave-uniform row-group origin) + (a per-lane offset that does not
+        // change over the walk).  Written that way -- a uniform 64-bit base plus an unsigned 32-bit lane offset -- the
+        // compiler keeps the bases in scalar registers and the loads / stores use the SGPR-base addressing form: one
+        // lane-offset register per matrix (C, z_out, zgrad, r) instead of a 64-bit row * stride product per row group
+        // (which was most of the epilogue's VALU work and register pressure).
+        const int es_c = p.c_dtype == DW_F32 ? 4 : 2;
+        const int es_r = p.r_dtype == DW_F32 ? 4 : 2;
+        const long row_u = (long)(m0 + wm0), col_u = (long)(n0 + wn0);              // wave-uniform tile origin
+        char* const c_u = (p.c_dtype == DW_F32 ? (char*)cf : (char*)p.c) + (row_u * p.ldc + col_u) * es_c;
+        char* const z_u = (char*)p.z_out + (row_u * p.ldz + col_u) * 2;
+        const char* const zg_u = (const char*)p.zgrad + (row_u * p.ldzg + col_u) * 2;
+        const char* const r_u = (const char*)p.r + (row_u * p.ldr + col_u) * es_r;
+        const unsigned l_c = (unsigned)((pr * (int)p.ldc + pc) * es_c);
+        const unsigned l_z = (unsigned)((pr * (int)p.ldz + pc) * 2);
+        const unsigned l_zg = (unsigned)((pr * (int)p.ldzg + pc) * 2);
+        const unsigned l_r = (unsigned)((pr * (int)p.ldr + pc) * es_r);
         bf16x4 zq[PFD];
         f32x4 rq[PFD];                             // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
         auto side_load = [&](auto gc) __attribute__((always_inline)) {   // gc: linear row-group index = slab * NIT + group
             constexpr int gi = decltype(gc)::value;
             constexpr int slot = gi % PFD;
-            const int mm = m0 + wm0 + (gi / NIT) * 32 + (gi % NIT) * RPI + pr;
-            if (pf_z) zq[slot] = *(const bf16x4*)(p.zgrad + (long)mm * p.ldzg + n);
+            constexpr long rg = (gi / NIT) * 32 + (gi % NIT) * RPI;              // first row of the row group in the wave tile
+            if (pf_z) zq[slot] = *(const bf16x4*)(zg_u + rg * p.ldzg * 2 + l_zg);
             if (pf_r) {
-                const int rr = p.r_row_mod > 0 ? (mm % p.r_row_mod) : mm;
-                if (p.r_dtype == DW_F32) rq[slot] = *(const f32x4*)((const float*)p.r + (long)rr * p.ldr + n);
+                const char* src = r_u + rg * p.ldr * es_r + l_r;
+                if (p.r_dtype == DW_F32) rq[slot] = *(const f32x4*)src;
                 else {
-                    const f32x2 t = *(const f32x2*)((const bf16*)p.r + (long)rr * p.ldr + n);
+                    const f32x2 t = *(const f32x2*)src;
                     rq[slot][0] = t[0]; rq[slot][1] = t[1];
                 }
             }
@@ -345,7 +367,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                 static_for<0, NIT>([&](auto itc) __attribute__((always_inline)) {
                     constexpr int it = decltype(itc)::value;
                     const int rl = it * RPI + pr;
-                    const int m = m0 + wm0 + i * 32 + rl;
+                    constexpr long rg = i * 32 + it * RPI;
                     const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
                     bf16x4 zs;
                     f32x4 rs;
@@ -355,7 +377,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                         if constexpr (gi + PFD < FM * NIT) side_load(std::integral_constant<int, gi + PFD>{});
                     }
                     float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                    gemm_epi_vec4(p, v, b4, plain, SIDE, zs, rs, cf, m, n);
+                    gemm_epi_vec4(p, v, b4, plain, SIDE, zs, rs, c_u + rg * p.ldc * es_c + l_c, z_u + rg * p.ldz * 2 + l_z);
                 });
             });
         };
@@ -395,7 +417,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                         rs[0] = t[0]; rs[1] = t[1];
                     }
                 }
-                gemm_epi_vec4(p, v, b4, plain, true, zs, rs, cf, m, n);
+                gemm_epi_vec4(p, v, b4, plain, true, zs, rs,
+                              p.c_dtype == DW_F32 ? (char*)(cf + (long)m * p.ldc + n) : (char*)((bf16*)p.c + (long)m * p.ldc + n),
+                              (char*)(p.z_out + (long)m * p.ldz + n));
             } else {
                 // ragged / unaligned columns: scalar path
 #pragma unroll 1

@@ -31,6 +31,13 @@
 // previous sub-step) and the compiler's lgkmcnt wait for the set lands here.
 #define PINF(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]), "+v"((f)[2]), "+v"((f)[3]))
 #define PINF2(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]))
+#define PIN_SET(set)                                                                                              \
+    do {                                                                                                          \
+        if constexpr (FM == 4) PINF(af[set]);                                                                     \
+        else if constexpr (FM == 5) { PINF(af[set]); asm volatile("" : "+v"(af[set][4])); }                      \
+        else PINF2(af[set]);                                                                                      \
+        if constexpr (FN == 4) PINF(bfr[set]); else PINF2(bfr[set]);                                              \
+    } while (0)
 
 // One 16-byte-per-lane operand DMA (buffer_load_dwordx4 ... lds: LDS destination = M0 + lane * 16), written as inline
 // assembly ON PURPOSE.  Issued through the builtin, the compiler models it as an LDS store it cannot disambiguate from
@@ -54,11 +61,27 @@ __device__ __forceinline__ void wp_dma16(const i32x4_t& rsrc, const char* lds_ds
 }
 
 // ASMDMA = false builds the same kernel with the operand DMA issued through the compiler builtin (A/B reference only).
-template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true>
+// BM = 320 (row-major A only): a 320 x 256 block tile, 160 x 64 per wave (5 x 2 accumulators).  M = 48000 is 150 row
+// tiles exactly and N = 1280 / 2560 / 3840 give 750 / 1500 / 2250 tiles = 2.93 / 5.86 / 8.79 rounds of the 256 CUs
+// where 256-row tiles give 940 / 1880 / 2820 = 3.67 / 7.34 / 11.02 (the last round a third full); per MFMA the wave
+// reads 7 % fewer fragment bytes and the workgroup stages 10 % fewer operand bytes -- on a chip whose GEMM rate is set
+// by the socket power limit (tools/gemm_power_probe.py) bytes moved per flop are what the clock is paid with.
+template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true, int DBG = 0, int BM = 256>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(const GemmP p) {
-    constexpr int BM = 256, BN = 256, NW = WM * WN, FM = BM / WM / 32, FN = BN / WN / 32, TN = BN / WN;
+    constexpr int BN = 256, NW = WM * WN, FM = BM / WM / 32, FN = BN / WN / 32, TN = BN / WN;
     static_assert(NW * 32 * (TN + 4) * 4 <= 2 * (BM + BN) * 128, "epilogue patches must fit the operand buffers");
-    constexpr int CP = 32 / NW;                       // DMA pieces (1 KiB) per wave per operand per K tile
+    static_assert(BM == 256 || !TA, "the k-major A image is built for 256-row tiles");
+    constexpr int CPA = BM / 8 / NW, CPB = BN / 8 / NW;   // DMA pieces (1 KiB) per wave per operand per K tile
+    constexpr int CP = CPB;
+    constexpr bool UNI = BM != 256;
+#ifndef DW_EPF
+#define DW_EPF 4
+#endif
+    constexpr int EPF = DW_EPF;                       // epilogue side-input prefetch distance of the 320-row tile (register budget)
+    static_assert(CPA * 8 * NW == BM && CPB * 8 * NW == BN && CPA <= 8 && CPB <= 8, "piece split");
+    // a K tile is requested in two halves; half h carries A pieces [HA0(h), HA0(h+1)) and B pieces [HB0(h), HB0(h+1))
+    constexpr int NA0 = (CPA + 1) / 2, NB0 = CPB / 2;          // pieces of half 0
+    constexpr int NH0 = NA0 + NB0, NH1 = CPA + CPB - NH0;      // loads a wave issues per half
     constexpr int STAGE = (BM + BN) * 128;            // one K tile: A [256][64] | B [256][64] (or their k-major images)
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
 
@@ -89,7 +112,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             gA = p.a + (long)m0 * p.lda;
             stepA = 128;
 #pragma unroll
-            for (int i = 0; i < CP; ++i) {
+            for (int i = 0; i < CPA; ++i) {
                 const int row = (wave + i * NW) * 8 + (lane >> 3);
                 const int ls = (lane & 7) ^ swz7(row);
                 const int grow = m0 + row < p.m ? row : p.m - 1 - m0;
@@ -99,7 +122,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             gA = p.a + m0;
             stepA = 128 * (int)p.lda;
 #pragma unroll
-            for (int i = 0; i < CP; ++i) {
+            for (int i = 0; i < CPA; ++i) {
                 const int krow = (wave + i * NW) * 2 + (lane >> 5);
                 const int ls = (lane & 31) ^ ((krow & 3) << 2);
                 const int gcol = m0 + ls * 8 < p.m ? ls * 8 : 0;
@@ -127,6 +150,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
                 offB[i] = (unsigned)((krow * p.ldb + gcol) * 2);
             }
         }
+        // UNI (320-row tiles; the launcher guarantees m % 320 == 0 and n % 256 == 0, so no row is ever clamped): the
+        // pieces of an operand differ by a uniform byte stride, which goes into the scalar offset of the load -- ONE
+        // address register per operand instead of CPA + CPB (the 160 accumulator + 56 fragment registers of this tile
+        // leave no room for nine; a value spilled inside the K loop is reloaded with a VMEM instruction whose vmcnt
+        // wait also waits for every operand load in flight)
+        const int pieceA = UNI ? NW * (TA ? 2 : 8) * (int)p.lda * 2 : 0;
+        const int pieceB = UNI ? NW * (TB ? 2 : 8) * (int)p.ldb * 2 : 0;
         int nt = p.k >> 6;
         {
             const int base = nt / p.split_k, rem = nt - base * p.split_k;
@@ -146,30 +176,37 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        // load j (0 .. CP-1) of half h of the K tile at (kA, kB) into LDS buffer `buf`: piece (CP/2) h + j/2 of A (j even)
-        // or B (j odd); a wave issues CP loads per half
+        // load j of half h (NH0 / NH1 loads per wave) of the K tile at (kA, kB) into LDS buffer `buf`: A and B pieces
+        // alternate (A first) until one operand's share of the half is used up
         auto dma1 = [&](auto hc, auto jc, int buf) __attribute__((always_inline)) {
-            constexpr int i = (CP / 2) * decltype(hc)::value + decltype(jc)::value / 2;
-            const char* tA = smem + buf * STAGE + wave * 1024 + i * (NW * 1024);
+            constexpr int h = decltype(hc)::value, j = decltype(jc)::value;
+            constexpr int na = h ? CPA - NA0 : NA0, nb = h ? CPB - NB0 : NB0, nmin = na < nb ? na : nb;
+            constexpr bool isA = j < 2 * nmin ? (j & 1) == 0 : na > nb;
+            constexpr int idx = j < 2 * nmin ? j / 2 : j - nmin;             // index within the operand's share of the half
+            constexpr int i = (isA ? (h ? NA0 : 0) : (h ? NB0 : 0)) + idx;
+            static_assert(j < na + nb, "load index");
+            const char* tA = smem + ((DBG & 2) ? (buf & 1) : buf) * STAGE + wave * 1024 + i * (NW * 1024);
+            if constexpr ((DBG & 2) != 0) { if (buf < 8) return; }                  // ablation: no operand DMA in the loop
             if constexpr (ASMDMA) {
-                if constexpr ((decltype(jc)::value & 1) == 0) wp_dma16(rsA, tA, offA[i], kA);
-                else wp_dma16(rsB, tA + BM * 128, offB[i], kB);
+                if constexpr (isA) wp_dma16(rsA, tA, offA[UNI ? 0 : i], UNI ? kA + i * pieceA : kA);
+                else wp_dma16(rsB, tA + BM * 128, offB[UNI ? 0 : i], UNI ? kB + i * pieceB : kB);
             } else {
                 const auto bA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);
                 const auto bB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, 0x7fffffff, 0x00020000);
-                if constexpr ((decltype(jc)::value & 1) == 0)
+                if constexpr (isA)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(bA, (lds_void_t*)tA, 16, offA[i], kA, 0, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(bB, (lds_void_t*)(tA + BM * 128), 16, offB[i], kB, 0, 0);
             }
         };
         auto dma = [&](auto hc, int buf) __attribute__((always_inline)) {
-            static_for<0, CP>([&](auto jc) __attribute__((always_inline)) { dma1(hc, jc, buf); });
+            static_for<0, (decltype(hc)::value ? NH1 : NH0)>([&](auto jc) __attribute__((always_inline)) { dma1(hc, jc, buf); });
         };
         bf16x8 af[2][FM], bfr[2][FN];
         auto frags = [&](auto sc, auto kc, int buf) {
             constexpr int set = decltype(sc)::value, kk = decltype(kc)::value;
-            const char* tA = smem + buf * STAGE;
+            if constexpr ((DBG & 1) != 0) { if (buf < 8) return; }                  // ablation: no fragment reads in the loop
+            const char* tA = smem + ((DBG & 1) ? (buf & 1) : buf) * STAGE;
             const char* tB = tA + BM * 128;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
@@ -198,7 +235,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             constexpr int DSI = FM * (TA ? 2 : 1) + FN * (TB ? 2 : 1);   // DS instructions of the sub-step's fragments
             constexpr int RG = VH ? NMF / 4 : NMF / 2;                   // gaps that carry fragment reads
             constexpr int PER = (DSI + RG - 1) / RG;
-            static_assert(RG + CP <= NMF, "not enough MFMA gaps for the operand loads");
+            constexpr int NLD = VH == 1 ? NH0 : NH1;                       // operand loads of the half this sub-step issues
+            static_assert(RG + (NH0 > NH1 ? NH0 : NH1) <= NMF, "not enough MFMA gaps for the operand loads");
             static_for<0, RG>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
 #pragma unroll
             for (int q = 0; q < RG; ++q) {
@@ -207,12 +245,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (VH != 0) {
-                static_for<0, CP>([&](auto jc) __attribute__((always_inline)) {
+                static_for<0, NLD>([&](auto jc) __attribute__((always_inline)) {
                     mfma1(sc, std::integral_constant<int, RG + decltype(jc)::value>{});
                     dma1(std::integral_constant<int, VH - 1>{}, jc, dbuf);
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                static_for<RG + CP, NMF>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
+                static_for<RG + NLD, NMF>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
             } else {
                 static_for<RG, NMF>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
             }
@@ -226,12 +264,17 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         (void)sizeof(I8);
 
         // ---- prologue: tile 0 whole, first half of tile 1, fragments of (0, 0) ----
-        dma(I0{}, 0); dma(I1{}, 0);
+        dma(I0{}, (DBG & 2) ? 8 : 0); dma(I1{}, (DBG & 2) ? 8 : 0);
         kA += stepA; kB += stepB;
-        if (nt > 1) dma(I0{}, 1);
-        if (nt > 1) { if (CP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } else wait_vm0();
+        if (nt > 1) dma(I0{}, (DBG & 2) ? 9 : 1);
+        if (nt > 1) {      // tile 0 has landed when only the NH0 loads of tile 1's first half are outstanding
+            if constexpr (NH0 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (NH0 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else { static_assert(NH0 == 4 || NH0 == 8 || NH0 == 5, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        } else wait_vm0();
         __syncthreads();
-        frags(I0{}, I0{}, 0);
+        frags(I0{}, I0{}, (DBG & 1) ? 8 : 0);
+        if constexpr ((DBG & 1) != 0) frags(I1{}, I1{}, 8);
         __builtin_amdgcn_sched_barrier(0);
 
         // one K tile; MORE1: tile t+1 exists, MORE2: tile t+2 exists.  (kA, kB) point at tile t+1 on entry.
@@ -239,20 +282,20 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             constexpr bool MORE1 = decltype(m1c)::value, MORE2 = decltype(m2c)::value;
             const int buf = t & 1;
             // sub-step 0: second half of tile t+1
-            if constexpr (FM == 4) PINF(af[0]); else PINF2(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
+            PIN_SET(0);
             frags(I1{}, I1{}, buf);
             if constexpr (MORE1) { substep(I0{}, I1{}, I2{}, buf ^ 1); kA += stepA; kB += stepB; }
             else substep(I0{}, I1{}, I0{}, 0);
             // sub-step 1
-            if constexpr (FM == 4) PINF(af[1]); else PINF2(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
+            PIN_SET(1);
             frags(I0{}, I2{}, buf);
             substep(I1{}, I1{}, I0{}, 0);
             // sub-step 2
-            if constexpr (FM == 4) PINF(af[0]); else PINF2(af[0]); if constexpr (FN == 4) PINF(bfr[0]); else PINF2(bfr[0]);
+            PIN_SET(0);
             frags(I1{}, I3{}, buf);
             substep(I0{}, I1{}, I0{}, 0);
             // every wave: its DMA pieces of tile t+1 have landed, its last fragments of tile t are in registers
-            if constexpr (FM == 4) PINF(af[1]); else PINF2(af[1]); if constexpr (FN == 4) PINF(bfr[1]); else PINF2(bfr[1]);
+            PIN_SET(1);
             if constexpr (MORE1) {
                 wait_vm0();
                 __builtin_amdgcn_s_barrier();
@@ -269,23 +312,31 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         if (nt >= 2) { body(std::true_type{}, std::false_type{}, t); ++t; }
         body(std::false_type{}, std::false_type{}, t);
 
-        gemm_epilogue<FM, FN, TN, 8>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
+        if (!(p.stage_next & 16)) gemm_epilogue<FM, FN, TN, (BM == 256 ? 8 : EPF)>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
+        else { float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+            if (t == 123.456f) *(float*)p.c = t; }
         __syncthreads();   // the LDS patches are reused as operand buffers by the next job
         gemm_jobs_advance(jobs, job_slot);
     }
     gemm_jobs_end(p, jobs);
 }
 
-template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true>
+template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true, int DBG = 0, int BM = 256>
 static int launch_wp(const GemmP& p0, hipStream_t s) {
     GemmP p = p0;
-    const int tiles_m = (p.m + 255) / 256;
+    const int tiles_m = (p.m + BM - 1) / BM;
     p.tiles_n = (p.n + 255) / 256;
     p.nwg = tiles_m * p.tiles_n;
     p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
     if (nblk > g_gemm_cus) nblk = g_gemm_cus;
-    hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN, ASMDMA>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
+    hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN, ASMDMA, DBG, BM>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -163,7 +163,49 @@ def test_gemm_pipelined_variants_are_bit_identical(ops, ref, variant, ta, tb):
             ops.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32, out=got, atomic_acc=True, split_k=5)
             assert torch.equal(got, want)
     finally:
-        ops.lib.dw_debug_set(0, 115)
+        ops.lib.dw_debug_set(0, 2163)
+
+
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm_320_row_tiles_are_bit_identical(ops, ref, tb):
+    """gemm_wp8_m320.hip (variant bit 2048): 320 x 256 block tiles, 160 x 64 per wave, one address register per operand
+    with the piece stride in the scalar offset.  Same k order per accumulator as the 16-wave 256-row kernel, so every
+    output bit must agree: both B layouts, 1..5 and 20 K tiles, one and several tile rounds (persistent walk), every
+    fused epilogue flavour (bias + GELU, stored gelu', GELU' input, bf16 / fp32 residual, fp32 output), repeated launches.
+    Shapes the 320-row tile is not built for (M % 320, N % 256) must fall back to the 256-row kernels unchanged."""
+    try:
+        for M, N, K in ((640, 512, 64), (960, 256, 128), (1280, 768, 192), (3200, 1280, 320), (320 * 150, 1280, 1280),
+                        (320 * 30, 3840, 256)):
+            a = rnd((M, K), 0.5, seed=51)
+            b = rnd((K, N) if tb else (N, K), 0.1, seed=52)
+            bias = rnd((N,), 0.5, torch.float32, seed=53)
+            r16 = rnd((M, N), 1.0, seed=54)
+            r32 = rnd((M, N), 1.0, torch.float32, seed=55)
+            zin = rnd((M, N), 1.0, seed=56)
+            flavours = (dict(bias=bias, act=1), dict(out_dtype=torch.float32), dict(bias=bias, residual=r16),
+                        dict(bias=bias, residual=r32, out_dtype=torch.float32), dict(zgrad=zin), dict(bias=bias, act=1, want_z=True),
+                        dict(bias=bias, act=1, want_z="grad"), dict(zgrad=zin.to(torch.float16)))
+            want = []
+            ops.lib.dw_debug_set(0, 3)
+            for f in flavours:
+                o = ops.gemm(a, b, trans_b=tb, tile=256, **f)
+                want.append([t.clone() for t in o] if isinstance(o, tuple) else [o.clone()])
+            ops.lib.dw_debug_set(0, 115 | 2048 | 4096)
+            for rep in range(2):
+                for f, w in zip(flavours, want):
+                    o = ops.gemm(a, b, trans_b=tb, tile=256, **f)
+                    o = list(o) if isinstance(o, tuple) else [o]
+                    for g_, w_ in zip(o, w):
+                        assert torch.equal(g_, w_), (M, N, K, tb, sorted(f), rep, (g_.float() - w_.float()).abs().max().item())
+            assert relerr(want[1][0], ref.gemm(a, b, trans_b=tb, out_dtype=torch.float32)) < 1e-5
+        # not eligible: ragged M / N -> the 256-row kernels, same bits
+        a, b = rnd((1000, 128), 0.5, seed=57), rnd((128, 304) if tb else (304, 128), 0.1, seed=58)
+        ops.lib.dw_debug_set(0, 3)
+        w = ops.gemm(a, b, trans_b=tb, tile=256).clone()
+        ops.lib.dw_debug_set(0, 115 | 2048 | 4096)
+        assert torch.equal(ops.gemm(a, b, trans_b=tb, tile=256), w)
+    finally:
+        ops.lib.dw_debug_set(0, 2163)
 
 
 def test_gemm_dynamic_job_handout_is_invisible(ops, ref):

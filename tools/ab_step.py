@@ -20,7 +20,7 @@ def step():
     return tr.train_step(tr.features(audio), dec_in, labels)
 # (GEMM variant, strip[, attention-backward mode]); variant 3 = default, 4 = phase-pipelined kernel; strip 0 = auto rule;
 # attention mode = dw_debug_set key 3 (default 1)
-configs = eval(os.environ.get("DW_AB", "[(7,0,5),(115,0,5)]"))
+configs = eval(os.environ.get("DW_AB", "[(115,0,5),(2163,0,5)]"))
 step(); torch.cuda.synchronize()
 res = {c: [] for c in configs}
 for r in range(4):

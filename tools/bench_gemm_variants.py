@@ -41,4 +41,4 @@ for name, M, N, K, ta, tb in shapes:
             e.record(); torch.cuda.synchronize()
             res[v].append(2.0*M*N*K/(s.elapsed_time(e)/10*1e-3)/1e12)
     print(name, {v: f"med {sorted(r)[len(r)//2]:.0f} max {max(r):.0f}" for v, r in res.items()}, flush=True)
-ops.lib.dw_debug_set(0, 115)
+ops.lib.dw_debug_set(0, 2163)

@@ -30,4 +30,4 @@ for v in variants + variants:
         torch.cuda.synchronize()
         tf = [2.0 * M * N * K * per / (ev[c].elapsed_time(ev[c + 1]) * 1e-3) / 1e12 for c in range(chunks)]
         print(f"vendor    N={N} K={K}: " + " ".join(f"{x:.0f}" for x in tf), flush=True)
-ops.lib.dw_debug_set(0, 115)
+ops.lib.dw_debug_set(0, 2163)
