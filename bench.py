@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream (default: side stream)")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="weight-gradient GEMMs of the backward on the main stream (default: second stream)")
+    ap.add_argument("--no-teacher-overlap", action="store_true", help="teacher forward on the main stream only")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -91,7 +92,7 @@ def main():
     recipe = args.mode == "recipe"
     tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
-                             mel_filters=filt, overlap_teacher=not args.no_overlap,
+                             mel_filters=filt, overlap_teacher=not (args.no_overlap or args.no_teacher_overlap),
                              overlap_wgrad=not (args.no_wgrad_overlap or args.no_overlap))
     del t_sd, s_sd
     torch.cuda.empty_cache()

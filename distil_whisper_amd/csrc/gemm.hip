@@ -68,7 +68,10 @@ static int* gemm_sched_slot(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
     int* ptr = nullptr;
-    if (hipMalloc((void**)&ptr, 64) != hipSuccess || hipMemset(ptr, 0, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // zeroed ON the stream that will use them: a hipMemset on the null stream is not ordered against a non-blocking
+    // stream (torch's side streams), and the first persistent GEMM of a new stream could read uninitialised counters --
+    // tile indices out of range, a memory access fault (seen once, under rocprofv3 --pmc with three streams active)
+    if (hipMalloc((void**)&ptr, 64) != hipSuccess || hipMemsetAsync(ptr, 0, 64, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     slots[s] = ptr;
     return ptr;
 }
