@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream (default: side stream)")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="weight-gradient GEMMs of the backward on the main stream (default: second stream)")
+    ap.add_argument("--no-pad-teacher-rows", action="store_true",
+                    help="teacher decoder GEMMs over exactly B*T rows (default: padded to a multiple of 320 rows)")
     ap.add_argument("--no-teacher-overlap", action="store_true", help="teacher forward on the main stream only")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -93,7 +95,8 @@ def main():
     tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
                              mel_filters=filt, overlap_teacher=not (args.no_overlap or args.no_teacher_overlap),
-                             overlap_wgrad=not (args.no_wgrad_overlap or args.no_overlap))
+                             overlap_wgrad=not (args.no_wgrad_overlap or args.no_overlap),
+                             pad_teacher_rows=not args.no_pad_teacher_rows)
     del t_sd, s_sd
     torch.cuda.empty_cache()
 

@@ -179,9 +179,18 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     if (tile == 16 && !dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return DW_EINVAL;
     if ((tile == 0 || tile == 16) && dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return dw_gemm_skinny_launch(p, s);
     if (fused) return DW_EINVAL;                  // the fusions exist in the skinny-M kernel only
+    bool one_round_320 = false;
     if (tile != 128 && tile != 256) {
         const long t256 = (long)((g->m + 255) / 256) * ((g->n + 255) / 256);
         tile = t256 >= 512 ? 256 : 128;
+        // A grid too small for two rounds of 256-tiles that is ONE round of 320-row tiles filling at least half the
+        // CUs (the teacher decoder's padded M = 14400, N = 1280: 225 workgroups) runs that round instead of 4-5 rounds
+        // of 128-tiles.
+        if (tile == 128 && (g_gemm_variant & 2048) && !g->trans_a && p.split_k == 1 && !p.atomic && g->m % 320 == 0 &&
+            g->n % 256 == 0) {
+            const long t320 = (long)(g->m / 320) * (g->n / 256);
+            if (t320 <= g_gemm_cus && 2 * t320 >= g_gemm_cus) { tile = 256; one_round_320 = true; }
+        }
     }
     if (tile == 256) {
         // the software-pipelined kernels address their operand DMA with 31-bit buffer offsets
@@ -203,7 +212,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
             const long r256 = (((g->m + 255) / 256) * tn + g_gemm_cus - 1) / g_gemm_cus * 4;
             const long r320 = ((g->m / 320) * tn + g_gemm_cus - 1) / g_gemm_cus * 5;
             const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
-            if (v & 4096) use320 = true;
+            if ((v & 4096) || one_round_320) use320 = true;
             else if (!g->trans_b) use320 = r320 <= r256 && !epi_bound && (g->k >= 2560 || g->n >= 2560);
             else use320 = r320 < r256 && g->k >= 2560;
         }

@@ -84,7 +84,8 @@ class DistillationTrainer:
     def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
                  share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None,
-                 overlap_teacher=False, overlap_wgrad=False, bucket_bytes=256 << 20, always_reduce=False):
+                 overlap_teacher=False, overlap_wgrad=False, pad_teacher_rows=False, bucket_bytes=256 << 20,
+                 always_reduce=False):
         self.ops = ops
         self.sdims, self.tdims = WhisperDims.from_any(student_dims), WhisperDims.from_any(teacher_dims)
         frozen = []
@@ -96,6 +97,7 @@ class DistillationTrainer:
         self.teacher_store = ParamStore(ops, self.tdims, teacher_sd, trainable=False, round_bf16=True)
         self.student = WhisperEngine(ops, self.student_store, torch.float32)
         self.teacher = WhisperEngine(ops, self.teacher_store, ops.lowp)
+        self.teacher.pad_gemm_rows = bool(pad_teacher_rows)   # decoder GEMMs of the frozen teacher over M padded to 320 rows
         self.temperature, self.kl_weight = temperature, kl_weight
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm

@@ -221,6 +221,14 @@ class WhisperEngine:
         self.lowp = ops.lowp
         self.ldv = _rup(self.dims.vocab, 64)
         self.wgrad_stream = None   # torch.cuda.Stream: weight-gradient GEMMs / bias column sums of the backward go there
+        # Forward-only decoder passes (the frozen teacher) may run their GEMMs over a row count padded to a multiple of
+        # 320 when that costs <= 1/32 extra rows: M = 32 x 447 = 14304 -> 14400 = 45 row tiles of the 320 x 256 GEMM
+        # kernel, ONE round of 225 workgroups for N = 1280 where the 128-tile kernel needs 4.4 rounds of 1120.  Pad rows
+        # hold garbage; every operation between the embedding and the logits is row-local (GEMM rows, LayerNorm rows,
+        # attention indexed by (batch, position) over the first B*T rows), so they never reach a valid row.
+        self.pad_gemm_rows = False
+        self.pad_gemm_rows_min = 2560       # smallest B*T worth padding
+        self.pad_gemm_rows_slack = 1 / 32   # most extra rows accepted, as a fraction of B*T
 
     # ---- helpers -------------------------------------------------------------------------------------------------
     def act(self, rows, cols, dtype=None):
@@ -233,8 +241,14 @@ class WhisperEngine:
             t[rows:].zero_()
         return t
 
-    def _ln(self, name, x, R, save):
-        y = self.act(R, x.shape[1])
+    def _gemm_rows(self, R, save):
+        if save or not self.pad_gemm_rows or R < self.pad_gemm_rows_min:
+            return R
+        Rg = _rup(R, 320)
+        return Rg if Rg - R <= R * self.pad_gemm_rows_slack else R
+
+    def _ln(self, name, x, R, save, rows_alloc=None):
+        y = self.act(R if rows_alloc is None else rows_alloc, x.shape[1])
         _, mu, rs = self.ops.layernorm_fwd(x[:R] if x.shape[0] != R else x, self.st.p[f"{name}.weight"],
                                            self.st.p[f"{name}.bias"], 1e-5, save_stats=save, out=y[:R])
         return y, mu, rs
@@ -329,19 +343,22 @@ class WhisperEngine:
             ctx.update(x_final=x, mu=mu, rs=rs, enc_out=y)
         return y, ctx
 
-    def _layer_fwd(self, p, x, B, L, enc_out, Lk, causal, save):
-        """One pre-LN transformer layer (TF:modeling_whisper.py:379-413 encoder, 448-505 decoder)."""
+    def _layer_fwd(self, p, x, B, L, enc_out, Lk, causal, save, Rg=None):
+        """One pre-LN transformer layer (TF:modeling_whisper.py:379-413 encoder, 448-505 decoder).  Rg >= B*L: rows
+        the projections run over (`pad_gemm_rows`; x then has Rg rows); attention and LayerNorm see the B*L valid rows."""
         ops, st, d = self.ops, self.st, self.dims
         D, H, R = d.d_model, d.heads, B * L
+        Rg = R if Rg is None else Rg
+        assert Rg == R or not save
         lc = {} if save else None
         # --- self attention
         av = st.attn_views(f"{p}.self_attn")
-        h, mu, rs = self._ln(f"{p}.self_attn_layer_norm", x, R, save)
-        qkv = self.act(R, 3 * D)
-        ops.gemm(h[:R], av["wqkv"], bias=av["bqkv"], out=qkv[:R])
-        o = self.act(R, D)
+        h, mu, rs = self._ln(f"{p}.self_attn_layer_norm", x, R, save, Rg)
+        qkv = self.act(Rg, 3 * D)
+        ops.gemm(h[:Rg], av["wqkv"], bias=av["bqkv"], out=qkv[:Rg])
+        o = self.act(Rg, D)
         _, lse = ops.attn_fwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], B, H, L, L, causal, 0.125, out=o[:R])
-        x1 = ops.gemm(o[:R], av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
+        x1 = ops.gemm(o[:Rg], av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
         if save:
             lc.update(x0=x, mu0=mu, rs0=rs, h0=h, qkv=qkv, o0=o, lse0=lse)
         x = x1
@@ -349,24 +366,24 @@ class WhisperEngine:
         if enc_out is not None:
             cv = st.attn_views(f"{p}.encoder_attn")
             Re = B * Lk
-            h, mu, rs = self._ln(f"{p}.encoder_attn_layer_norm", x, R, save)
-            q = self.act(R, D)
-            ops.gemm(h[:R], cv["wqkv"][:D], bias=cv["bqkv"][:D], out=q[:R])
+            h, mu, rs = self._ln(f"{p}.encoder_attn_layer_norm", x, R, save, Rg)
+            q = self.act(Rg, D)
+            ops.gemm(h[:Rg], cv["wqkv"][:D], bias=cv["bqkv"][:D], out=q[:Rg])
             kv = self.act(Re, 2 * D)
             ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=kv[:Re])
-            o = self.act(R, D)
+            o = self.act(Rg, D)
             _, lse = ops.attn_fwd(q[:R], kv[:Re, :D], kv[:Re, D:], B, H, L, Lk, False, 0.125, out=o[:R])
-            x1 = ops.gemm(o[:R], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            x1 = ops.gemm(o[:Rg], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
             if save:
                 lc.update(x1=x, mu1=mu, rs1=rs, h1=h, q1=q, kv1=kv, o1=o, lse1=lse)
             x = x1
         # --- feed forward
-        h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save)
-        a = self.act(R, d.ffn)
-        res = ops.gemm(h[:R], st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1,
-                       want_z=("grad" if self.ffn_keeps_gelu_grad else True) if save else False, out=a[:R])
+        h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save, Rg)
+        a = self.act(Rg, d.ffn)
+        res = ops.gemm(h[:Rg], st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1,
+                       want_z=("grad" if self.ffn_keeps_gelu_grad else True) if save else False, out=a[:Rg])
         z = res[1] if save else None
-        x2 = ops.gemm(a[:R], st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
+        x2 = ops.gemm(a[:Rg], st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
                       out_dtype=self.stream)
         if save:
             lc.update(x2=x, mu2=mu, rs2=rs, h2=h, a=a, z=z)
@@ -380,14 +397,15 @@ class WhisperEngine:
         B, T = ids.shape
         R, Lk = B * T, d.max_src
         ctx = {"B": B, "T": T, "R": R, "ids": ids, "layers": [], "enc_out": enc_out} if save else None
+        Rg = self._gemm_rows(R, save)
         if self.stream == torch.float32:
             x = ops.embed_fwd(ids, st.p["model.decoder.embed_tokens.weight"],
-                              st.p["model.decoder.embed_positions.weight"], torch.float32)
+                              st.p["model.decoder.embed_positions.weight"], torch.float32, rows_alloc=Rg)
         else:
             x = ops.embed_fwd(ids, st.s["model.decoder.embed_tokens.weight"],
-                              st.s["model.decoder.embed_positions.weight"], self.lowp)
+                              st.s["model.decoder.embed_positions.weight"], self.lowp, rows_alloc=Rg)
         for i in range(d.dec_layers):
-            x, lc = self._layer_fwd(f"model.decoder.layers.{i}", x, B, T, enc_out, Lk, True, save)
+            x, lc = self._layer_fwd(f"model.decoder.layers.{i}", x, B, T, enc_out, Lk, True, save, Rg)
             if save:
                 ctx["layers"].append(lc)
         hf, mu, rs = self._ln("model.decoder.layer_norm", x, R, save)

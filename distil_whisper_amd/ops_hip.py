@@ -391,12 +391,18 @@ class HipOps:
                                            self._stream()), "distill_loss")
         return losses
 
-    def embed_fwd(self, ids, tok, pos, out_dtype):
+    def embed_fwd(self, ids, tok, pos, out_dtype, rows_alloc=0):
+        """rows_alloc > B*T: the output buffer gets that many rows (the extra rows are zero; callers whose GEMMs run
+        over a padded row count)."""
         B, T = ids.shape
         D = tok.shape[1]
         assert ids.dtype == torch.int64 and ids.is_contiguous() and tok.is_contiguous() and pos.is_contiguous()
         assert tok.dtype == pos.dtype
-        out = self.empty((B * T, D), out_dtype)
+        if rows_alloc > B * T:
+            out = self.empty((rows_alloc, D), out_dtype)
+            out[B * T:].zero_()
+        else:
+            out = self.empty((B * T, D), out_dtype)
         self._chk(self.lib.dw_embed_fwd(_p(ids), _p(tok), _p(pos), _dt(tok), _p(out), _dt(out), B, T, D,
                                         self._stream()), "embed_fwd")
         return out

@@ -228,10 +228,12 @@ class RefOps:
         tokens[:, n].copy_(nxt)
         cur.copy_(nxt.view(B, 1))
 
-    def embed_fwd(self, ids, tok, pos, out_dtype):
+    def embed_fwd(self, ids, tok, pos, out_dtype, rows_alloc=0):
         B, T = ids.shape
-        x = tok.float()[ids.reshape(-1)] + pos.float()[:T].repeat(B, 1)
-        return x.to(out_dtype)
+        x = (tok.float()[ids.reshape(-1)] + pos.float()[:T].repeat(B, 1)).to(out_dtype)
+        if rows_alloc > B * T:
+            x = torch.cat([x, x.new_zeros(rows_alloc - B * T, x.shape[1])], 0)
+        return x
 
     def embed_bwd(self, dx, ids, dtok, dpos):
         B, T = ids.shape

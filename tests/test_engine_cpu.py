@@ -163,3 +163,30 @@ def test_freeze_embed_positions_and_recipe_layout():
     tr.optimizer_step()  # frozen range untouched
     assert torch.equal(st.p["model.decoder.embed_positions.weight"], s_sd["model.decoder.embed_positions.weight"])
     assert torch.equal(st.p["model.encoder.layers.0.fc1.weight"], s_sd["model.encoder.layers.0.fc1.weight"])
+
+
+def test_teacher_decoder_over_padded_gemm_rows_gives_the_same_logits():
+    """`pad_gemm_rows`: the forward-only (teacher) decoder pass runs its projections over a row count padded to a
+    multiple of 320 (B*T = 74 -> 320 here; 14304 -> 14400 in the benchmark) with garbage in the pad rows -- every
+    operation between the embedding and the logits is row-local, so the B*T valid rows of the logits are unchanged, and
+    the trainer's loss with it."""
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup()
+    ops = RefOps("cpu", lowp=torch.float32)
+    dims = WhisperDims.from_any(cfg_t)
+    eng = WhisperEngine(ops, ParamStore(ops, dims, t_sd, trainable=False), torch.float32)
+    enc, _ = eng.encode(batch["input_features"], save=False)
+    ids = batch["decoder_input_ids"]
+    want, _ = eng.decode(ids, enc, save=False)
+    eng.pad_gemm_rows, eng.pad_gemm_rows_min, eng.pad_gemm_rows_slack = True, 1, 100.0
+    assert eng._gemm_rows(ids.numel(), False) == 320 and eng._gemm_rows(ids.numel(), True) == ids.numel()
+    got, _ = eng.decode(ids, enc, save=False)
+    R = ids.numel()
+    assert torch.equal(got[:R], want[:R])
+    eng.pad_gemm_rows_slack = 1 / 32
+    assert eng._gemm_rows(14304, False) == 14400 and eng._gemm_rows(14000, False) == 14080 and eng._gemm_rows(100, False) == 100
+    a = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+    b = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, pad_teacher_rows=True)
+    b.teacher.pad_gemm_rows_min, b.teacher.pad_gemm_rows_slack = 1, 100.0
+    la = a.forward_backward(batch["input_features"], batch["decoder_input_ids"], batch["labels"])
+    lb = b.forward_backward(batch["input_features"], batch["decoder_input_ids"], batch["labels"])
+    assert torch.equal(la, lb)

@@ -198,6 +198,15 @@ def test_gemm_320_row_tiles_are_bit_identical(ops, ref, tb):
                     for g_, w_ in zip(o, w):
                         assert torch.equal(g_, w_), (M, N, K, tb, sorted(f), rep, (g_.float() - w_.float()).abs().max().item())
             assert relerr(want[1][0], ref.gemm(a, b, trans_b=tb, out_dtype=torch.float32)) < 1e-5
+        # automatic tile choice: a grid too small for two rounds of 256-tiles that is ONE round of 320-row tiles (the
+        # teacher decoder's padded M = 14400, N = 1280: 225 workgroups) takes that round instead of 128-tiles
+        if not tb:
+            a, b = rnd((14400, 1280), 0.5, seed=59), rnd((1280, 1280), 0.1, seed=60)
+            bias, r16 = rnd((1280,), 0.5, torch.float32, seed=61), rnd((14400, 1280), 1.0, seed=62)
+            ops.lib.dw_debug_set(0, 3)
+            w = ops.gemm(a, b, bias=bias, residual=r16).clone()              # 128-tiles
+            ops.lib.dw_debug_set(0, 2163)
+            assert torch.equal(ops.gemm(a, b, bias=bias, residual=r16), w)   # one round of 320-row tiles
         # not eligible: ragged M / N -> the 256-row kernels, same bits
         a, b = rnd((1000, 128), 0.5, seed=57), rnd((128, 304) if tb else (304, 128), 0.1, seed=58)
         ops.lib.dw_debug_set(0, 3)

@@ -226,6 +226,32 @@ def test_weight_gradient_stream_equals_single_stream(ops):
     assert relerr(pb, pa) < 1e-6
 
 
+def test_teacher_over_padded_gemm_rows_gives_the_same_step(ops):
+    """pad_teacher_rows=True: the frozen teacher's decoder GEMMs run over B*T padded to a multiple of 320 rows (garbage
+    in the pad rows, every operation row-local): teacher logits, losses and the student's parameters after a step are
+    those of the unpadded run (the tile kernels keep the same k order per output element whatever M is)."""
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 97)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    b = wo.synthetic_batch(cfg_t, 2, seed=98, T=80, with_audio=False)
+    feats = (torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(10)) * 0.5).cuda()
+    ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+    a = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    p = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, pad_teacher_rows=True)
+    p.teacher.pad_gemm_rows_min, p.teacher.pad_gemm_rows_slack = 1, 100.0
+    assert p.teacher._gemm_rows(ids.numel(), False) == 320
+    enc, _ = a.teacher.encode(feats, save=False)
+    la, _ = a.teacher.decode(ids, enc, save=False)
+    lp, _ = p.teacher.decode(ids, enc, save=False)
+    R = ids.numel()
+    assert torch.equal(lp[:R], la[:R])
+    losses_a = a.train_step(feats, ids, labels)
+    losses_p = p.train_step(feats, ids, labels)
+    torch.cuda.synchronize()
+    assert torch.equal(losses_a[:2], losses_p[:2])
+    assert relerr(p.student_store.P, a.student_store.P) < 1e-6
+
+
 def test_trainer_save_and_resume_continues_the_run(ops):
     """state_dict / load_state_dict carry weights, Adam moments and the step count: a resumed trainer takes the same
     third step as the original one (to the float-atomic summation noise of the small gradients, see above), whereas a

@@ -30,6 +30,7 @@ for r in range(4):
         type(tr.student).ffn_keeps_gelu_grad = bool(c[5]) if len(c) > 5 else True
         tr.set_overlap_wgrad(bool(c[7]) if len(c) > 7 else False)          # weight-gradient GEMMs on a second stream
         tr.overlap_teacher = bool(c[8]) if len(c) > 8 else False           # teacher forward on a second stream
+        tr.teacher.pad_gemm_rows = bool(c[9]) if len(c) > 9 else False     # teacher decoder GEMMs over M padded to 320 rows
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(2): step()
