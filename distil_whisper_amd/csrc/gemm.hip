@@ -53,7 +53,7 @@ int g_gemm_persistent = 1;
 static int g_gemm_variant = 2163;   // 115 (8-wave software-pipelined kernels + phased dX) | 2048 (320-row tiles where they pay)
 int g_gemm_strip = 0;
 int g_gemm_cus = 256;
-static int g_gemm_stage_next = 1;   // dw_debug_set key 11: request the next job's first K tile under the epilogue (gemm_wp.h)
+static int g_gemm_stage_next = 1;   // dw_debug_set key 11: profiling switches of the software-pipelined kernels (bit 4: skip the epilogue)
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
 
 // Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never

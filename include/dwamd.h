@@ -240,13 +240,18 @@ int dw_decode_step(const DwDecodeStep* d, void* stream);
  * Runs ds_read_b64_tr_b16 on a known LDS image: out int32 [64][4] = element ids received by each lane. */
 int dw_selftest_tr16(int32_t* out, void* stream);
 /* Tuning knobs for kernel A/B experiments and tests; not part of the hot path (defaults are the measured best).
- *   key 0   GEMM kernel selection, bit mask (default 115): bits 0-1 base 16-wave tile kernel; bit 2 phase-pipelined
- *           kernel for dX GEMMs with K >= 3840; bits 4/5/6 8-wave software-pipelined kernel for row-major / k-major-B /
- *           both-k-major operands; bit 7 phase-pipelined kernel for every dX GEMM.  All bit-identical.
+ *   key 0   GEMM kernel selection, bit mask (default 2163 = 115 | 2048): bits 0-1 base 16-wave tile kernel; bit 2
+ *           phase-pipelined kernel for dX GEMMs with K >= 3840; bits 4/5/6 8-wave software-pipelined kernel for row-major /
+ *           k-major-B / both-k-major operands; bit 7 phase-pipelined kernel for every dX GEMM; bit 8 row-major kernel with
+ *           the operand DMA through the compiler builtin (A/B reference); bit 11 (2048) 320 x 256 block tiles for
+ *           row-major A where they pay (M % 320 == 0, N % 256 == 0; K >= 2560, or row-major B with N >= 2560; a grid
+ *           of one round of them instead of 128-tiles), bit 12 (4096) wherever eligible.  All bit-identical.
+ *           Bits 9 / 10 (512 / 1024): main-loop ablations of the row-major kernel for profiling -- no fragment reads /
+ *           no operand DMA in the K loop (WRONG results by construction; tools/gemm_overhead.py, gemm_power_probe.py).
  *   key 1   rasterisation strip width override (0 = rule);   key 6  strip L2 budget in 512 KiB units (default 8)
  *   key 2   persistent workgroups on/off;   key 9  persistent grid size in CUs (multiple of 8, default 256)
- *   key 10  dynamic per-XCD tile hand-out (default 1);   key 11  request the next tile's first operands under the
- *           epilogue in the software-pipelined kernels (default 1)
+ *   key 10  dynamic per-XCD tile hand-out (default 1);   key 11  profiling: bit 4 (16) makes the software-pipelined
+ *           kernels skip their epilogue (nothing is stored; tools/gemm_overhead.py); other bits unused (default 1)
  *   key 3   attention backward variant (bit 0 dQ, bit 1 dK/dV fast tile staging, bit 2 dK/dV at 3 waves per SIMD;
  *           default 5);   key 4  single-query attention kernel (bit 0 on [default], bit 1 all-loads-up-front variant)
  *   key 5   log-mel DFT on the matrix cores (default 1);   key 7  decode-step fusions off (bit 0 LayerNorm-on-load,
