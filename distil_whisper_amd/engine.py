@@ -229,6 +229,7 @@ class WhisperEngine:
         self.pad_gemm_rows = False
         self.pad_gemm_rows_min = 2560       # smallest B*T worth padding
         self.pad_gemm_rows_slack = 1 / 32   # most extra rows accepted, as a fraction of B*T
+        self.pad_lm_rows = True             # training passes: zero pad rows behind hf / logits for the LM-head backward
 
     # ---- helpers -------------------------------------------------------------------------------------------------
     def act(self, rows, cols, dtype=None):
@@ -408,15 +409,25 @@ class WhisperEngine:
             x, lc = self._layer_fwd(f"model.decoder.layers.{i}", x, B, T, enc_out, Lk, True, save, Rg)
             if save:
                 ctx["layers"].append(lc)
-        hf, mu, rs = self._ln("model.decoder.layer_norm", x, R, save)
-        logits = self.act(R, self.ldv)
+        # Training pass: the rows of hf / logits are padded with ZERO rows to a multiple of 320 (same rule as
+        # pad_gemm_rows) so that the backward's dhf = dlogits . E (M = B*T, N = D, K = padded vocabulary) is one round
+        # of 320-row tiles instead of two rounds of 256-tiles; zero rows add nothing to dE = dlogits^T . hf.
+        Rl = R
+        if save and self.pad_lm_rows and R >= self.pad_gemm_rows_min:
+            Rl = _rup(R, 320)
+            Rl = Rl if Rl - R <= R * self.pad_gemm_rows_slack else R
+        hf, mu, rs = self._ln("model.decoder.layer_norm", x, R, save, Rl)
+        logits = self.act(Rl, self.ldv)
+        if Rl > R:
+            hf[R:Rl].zero_()
+            logits[R:Rl].zero_()
         # N = padded vocabulary (multiple of 64): the rows of the shadow buffer behind E are finite parameters / zero
         # slack, the resulting pad columns are never read as logits (the loss kernel stops at V and zeroes them)
         eo = st.entries["model.decoder.embed_tokens.weight"][0]
         e_pad = st.S[eo:eo + self.ldv * d.d_model].view(self.ldv, d.d_model)
         ops.gemm(hf[:R], e_pad, out=logits[:R])
         if save:
-            ctx.update(x_final=x, mu=mu, rs=rs, hf=hf)
+            ctx.update(x_final=x, mu=mu, rs=rs, hf=hf, lm_rows=Rl)
         return logits, ctx
 
     # ---- incremental decoding with a KV cache (TF:modeling_whisper.py:312-335, EncoderDecoderCache) -----------------
@@ -657,7 +668,9 @@ class WhisperEngine:
         # the shadow buffer behind E are finite parameters / zero slack)
         eo = st.entries[emb][0]
         e_pad = st.S[eo:eo + self.ldv * D].view(self.ldv, D)
-        dh = ops.gemm(dlogits[:R], e_pad, trans_b=True)
+        Rl = ctx.get("lm_rows", R)
+        assert dlogits.shape[0] >= Rl
+        dh = ops.gemm(dlogits[:Rl], e_pad, trans_b=True)      # rows R..Rl of dlogits are zero (decode, pad_lm_rows)
         nl = d.dec_layers
         dres, dy = self._ln_bwd("model.decoder.layer_norm", dh, ctx["x_final"], ctx["mu"], ctx["rs"], None, R,
                                 emit=True, colsum_to=self._bias_grad(f"model.decoder.layers.{nl - 1}.fc2.bias"))

@@ -190,3 +190,22 @@ def test_teacher_decoder_over_padded_gemm_rows_gives_the_same_logits():
     la = a.forward_backward(batch["input_features"], batch["decoder_input_ids"], batch["labels"])
     lb = b.forward_backward(batch["input_features"], batch["decoder_input_ids"], batch["labels"])
     assert torch.equal(la, lb)
+
+
+def test_lm_head_backward_over_zero_padded_rows_gives_the_same_gradients():
+    """`pad_lm_rows`: in a training pass hf / logits get zero rows up to a multiple of 320 so that dhf = dlogits . E runs
+    over M = 320 k rows (one round of 320-row GEMM tiles at the benchmark's 14304 -> 14400); zero rows add nothing to
+    dE = dlogits^T . hf and their dhf rows are never read: every gradient equals the unpadded run's."""
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup()
+    ops = RefOps("cpu", lowp=torch.float32)
+
+    def grads(pad):
+        tr = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+        tr.student.pad_lm_rows = pad
+        tr.student.pad_gemm_rows_min, tr.student.pad_gemm_rows_slack = 1, 100.0
+        losses = tr.forward_backward(batch["input_features"], batch["decoder_input_ids"], batch["labels"])
+        return losses, tr.student_store.G.clone()
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    assert torch.equal(l0, l1)
+    assert relerr(g1, g0) < 1e-6     # (dE sums 320 rows instead of 128: zero terms, but the split of K into slices differs)
