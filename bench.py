@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--mode", default="full", choices=["full", "recipe"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream (default: side stream)")
+    ap.add_argument("--no-overlap", action="store_true", help="everything on the main stream: no teacher stream, no weight-gradient stream (default: both side streams)")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="weight-gradient GEMMs of the backward on the main stream (default: second stream)")
     ap.add_argument("--no-pad-teacher-rows", action="store_true",
