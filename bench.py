@@ -49,8 +49,13 @@ def step_flops(d, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)      # >= 10 warm-up, >= 30 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the whole step from one captured HIP graph (auto: on with one rank; data-parallel "
+                         "ranks issue their RCCL buckets from the host and run eagerly)")
+    ap.add_argument("--no-ab", action="store_true", help="skip the in-process A/B legs (graph / eager / eager without "
+                                                         "side streams, 10 steps each) reported under `ab`")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of 30 s clips")
     ap.add_argument("--model", default="large-v3", choices=["tiny.en", "small.en", "large-v3"])
     ap.add_argument("--mode", default="full", choices=["full", "recipe"])
@@ -69,9 +74,16 @@ def main():
         print(json.dumps(cpu_baseline_leg(args.model, le0, ld0, args.mode == "recipe")), flush=True)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL), same arguments
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank}, {torch.cuda.device_count()} device(s) visible")
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -110,16 +122,30 @@ def main():
     labels = ids[:, 1:].clone()
     labels[torch.arange(T, device=dev)[None, :] >= lens[:, None]] = -100
 
-    def one_step():
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
+    if use_graph and world > 1:
+        raise SystemExit("bench.py: --graph on needs one rank (data-parallel steps run eagerly)")
+
+    def eager_step():
         feats = tr.features(audio)
         return tr.train_step(feats, dec_in, labels)
+
+    def graph_step():
+        return tr.train_step_graphed(audio, dec_in, labels)
+
+    one_step = graph_step if use_graph else eager_step
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"engine ready: {args.model} {args.mode} B={B} world={world}; warm-up x{args.warmup}")
+    log(f"engine ready: {args.model} {args.mode} B={B} world={world} graph={use_graph}; warm-up x{args.warmup}")
+    if use_graph:
+        for _ in range(3):            # two eager steps on the capture stream, then the capture (untimed, before the warm-up)
+            one_step()
+        torch.cuda.synchronize()
+        log("step captured into a HIP graph")
     for i in range(args.warmup):
         losses = one_step()
         if i == 0:
@@ -128,11 +154,28 @@ def main():
                 f"mem={torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     sync()
     log(f"timing {args.steps} steps")
+    torch.cuda.reset_peak_memory_stats()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
+        h0 = time.perf_counter()
         losses = one_step()
+        marks[i + 1].record()                      # (main stream, after the optimizer: one event per step)
+        host_ms.append((time.perf_counter() - h0) * 1e3)
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms = torch.cuda.memory_stats()
+    step_stats = {"gpu_ms_median": per_step[len(per_step) // 2], "gpu_ms_p90": per_step[int(0.9 * (len(per_step) - 1))],
+                  "gpu_ms_min": per_step[0], "gpu_ms_max": per_step[-1],
+                  "host_enqueue_ms_median": sorted(host_ms)[len(host_ms) // 2], "host_enqueue_ms_max": max(host_ms),
+                  "reserved_peak_gib": ms.get("reserved_bytes.all.peak", 0) / 2**30,
+                  "allocated_peak_gib": ms.get("allocated_bytes.all.peak", 0) / 2**30,
+                  "num_alloc_retries": ms.get("num_alloc_retries", 0), "num_device_alloc": ms.get("num_device_alloc", 0),
+                  "num_device_free": ms.get("num_device_free", 0)}
+    log("per-step: " + json.dumps(step_stats))
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -159,6 +202,13 @@ def main():
     else:
         fl = (enc(tdims.enc_layers) + dec(tdims.dec_layers) + head) + 3 * (enc(le) + dec(ld) + head)
     step_tflops = value / 30.0 * fl / 1e12 / world
+
+    ab = None
+    if world == 1 and not args.no_ab:
+        ab = ab_legs(tr, eager_step, graph_step, B)
+        log("A/B (median ms/step over 10 steps, same process): " + json.dumps(ab))
+    tr.drop_graph()
+    torch.cuda.empty_cache()
 
     roofline = None
     if not args.no_roofline:
@@ -207,10 +257,64 @@ def main():
                           "parallelism": f"dp{world}", "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
                           "bwd+allreduce+clip+adamw", "loss": loss_val},
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
-               "flops_per_sample": fl, "roofline": roofline, "cpu_baseline": cpu_baseline}
+               "flops_per_sample": fl, "step_mode": "hip_graph" if use_graph else "eager", "step_stats": step_stats,
+               "ab": ab, "roofline": roofline, "cpu_baseline": cpu_baseline}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """Re-exec this script under torch.distributed.run with one rank per GPU of this node (what the driver does for
+    N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`)."""
+    import socket
+    import subprocess
+    if torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} requested but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3):
+    """The same process, the same weights and inputs, seconds apart: median GPU ms per step (HIP events around each
+    step on the main stream) of the three ways to issue the step."""
+    def leg(step_fn, pre=0):
+        for _ in range(pre + warm):
+            step_fn()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        marks[0].record()
+        for i in range(steps):
+            step_fn()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        t = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        return {"median_ms": t[len(t) // 2], "min_ms": t[0], "max_ms": t[-1], "audio_s_per_s": B * 30e3 / t[len(t) // 2]}
+
+    out = {}
+    ov_t, ov_w = tr.overlap_teacher, tr.student.wgrad_stream is not None
+    tr.drop_graph()
+    torch.cuda.empty_cache()
+    out["hip_graph_side_streams" if (ov_t or ov_w) else "hip_graph_single_stream"] = leg(graph_step, pre=3)
+    tr.drop_graph()
+    torch.cuda.empty_cache()
+    out["eager_side_streams" if (ov_t or ov_w) else "eager_single_stream"] = leg(eager_step)
+    tr.overlap_teacher = not (ov_t or ov_w)
+    tr.set_overlap_wgrad(not (ov_t or ov_w))
+    flipped = "single_stream" if (ov_t or ov_w) else "side_streams"
+    out["eager_" + flipped] = leg(eager_step)
+    torch.cuda.empty_cache()
+    out["hip_graph_" + flipped] = leg(graph_step, pre=3)
+    tr.drop_graph()
+    torch.cuda.empty_cache()
+    tr.overlap_teacher = ov_t
+    tr.set_overlap_wgrad(ov_w)
+    return out
 
 
 def vendor_ceiling():

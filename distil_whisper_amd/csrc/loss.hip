@@ -127,7 +127,8 @@ __global__ __launch_bounds__(LOSS_NT) void loss_final_kernel(const float* row_ce
     if (threadIdx.x == 0) {
         // no valid label in the batch: the reference's means are 0/0 = NaN (CrossEntropyLoss over zero tokens,
         // kl.sum() / padding_mask.sum()); report NaN as well so that the empty batch is visible (the gradient written
-        // by the row kernel is zero in that case, i.e. the step is a no-op instead of poisoning the weights)
+        // by the row kernel is zero in that case; losses[3] = 0 is the gate of dw_adam_tick, which then skips the whole
+        // optimizer step on the device: zero gradients alone would still move the weights by momentum and weight decay)
         const float ce = a / (float)counts[0];
         const float kl = b / (float)counts[1] * T * T;
         losses[0] = ce;

@@ -110,3 +110,91 @@ extern "C" int dw_adamw(float* p, const float* g, float* m, float* v, void* shad
     DW_CHECK_LAUNCH();
     return DW_OK;
 }
+
+// ---- device-resident optimizer state: the whole training step (including this update) can be captured in a HIP graph --
+// state (8 doubles, caller-owned): [0] lr (host writes it before every step: LR scheduler), [1] step count (advanced
+// HERE), [2] beta1, [3] beta2; derived by the tick kernel for the update kernels of this step: [4] lr / (1 - beta1^step),
+// [5] sqrt(1 - beta2^step), [6] applied (1.0 / 0.0).
+__global__ void adam_tick_kernel(double* st, const float* gate) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool apply = !gate || gate[0] > 0.f;      // gate = n_valid of the loss kernel: a batch without labels is skipped
+    if (apply) st[1] += 1.0;
+    const double step = st[1] < 1.0 ? 1.0 : st[1];
+    st[4] = st[0] / (1.0 - pow(st[2], step));
+    st[5] = sqrt(1.0 - pow(st[3], step));
+    st[6] = apply ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, long n,
+                                                        const float* sumsq, float max_norm, float grad_mul,
+                                                        const double* st, double weight_decay, float eps) {
+    if (st[6] == 0.0) return;
+    const float step_size = (float)st[4], bc2_sqrt = (float)st[5];
+    const float decay = (float)(1.0 - st[0] * weight_decay);
+    const float beta1 = (float)st[2], omb1 = (float)(1.0 - st[2]), beta2 = (float)st[3], omb2 = (float)(1.0 - st[3]);
+    float clip = grad_mul;
+    if (max_norm > 0.f && sumsq) {
+        const float norm = sqrtf(sumsq[0]) * fabsf(grad_mul);
+        const float coef = max_norm / (norm + 1e-6f);
+        clip *= coef < 1.f ? coef : 1.f;
+    }
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 pv = *(f32x4*)(p + i);
+            const f32x4 gv = *(const f32x4*)(g + i);
+            f32x4 mv = *(f32x4*)(m + i);
+            f32x4 vv = *(f32x4*)(v + i);
+            bf16x4 sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg = gv[e] * clip;
+                pv[e] *= decay;
+                mv[e] = beta1 * mv[e] + omb1 * gg;
+                vv[e] = beta2 * vv[e] + omb2 * (gg * gg);
+                const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+                pv[e] -= step_size * (mv[e] / denom);
+                sh[e] = f2bf(pv[e]);
+            }
+            *(f32x4*)(p + i) = pv;
+            *(f32x4*)(m + i) = mv;
+            *(f32x4*)(v + i) = vv;
+            if (shadow) *(bf16x4*)(shadow + i) = sh;
+        } else {
+            for (long j = i; j < n; ++j) {
+                const float gg = g[j] * clip;
+                float pj = p[j] * decay;
+                const float mj = beta1 * m[j] + omb1 * gg;
+                const float vj = beta2 * v[j] + omb2 * (gg * gg);
+                pj -= step_size * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+                p[j] = pj; m[j] = mj; v[j] = vj;
+                if (shadow) shadow[j] = f2bf(pj);
+            }
+        }
+    }
+}
+
+extern "C" int dw_adam_tick(double* state, const float* gate, void* stream) {
+    DW_CLEAR_ERR();
+    if (!state || ((uintptr_t)state & 7)) return DW_EINVAL;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, gate);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
+extern "C" int dw_adamw_dev(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, const float* sumsq,
+                            float max_norm, float grad_mul, const double* state, double eps, double weight_decay,
+                            void* stream) {
+    DW_CLEAR_ERR();
+    if (!p || !g || !m || !v || !state || n <= 0) return DW_EINVAL;
+    if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) ||
+        ((uintptr_t)shadow & 7) || ((uintptr_t)state & 7))
+        return DW_EINVAL;
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adamw_dev_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16*)shadow, (long)n,
+                       sumsq, max_norm, grad_mul, state, weight_decay, (float)eps);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}

@@ -104,8 +104,13 @@ class DistillationTrainer:
         self.freeze_encoder, self.share_encoder = freeze_encoder, share_encoder
         if share_encoder and not freeze_encoder:
             raise ValueError("share_encoder requires freeze_encoder (run_distillation.py:1046-1049)")
-        self.step_count = 0
         st = self.student_store
+        # optimizer scalars live on the device (lr, step count, betas: include/dwamd.h dw_adam_tick), so that the whole
+        # step is a fixed launch sequence (HIP-graph capturable) and an all-ignored batch can be skipped without a host sync
+        self._adam = ops.adam_state(lr, betas[0], betas[1], 0)
+        self._lr_dev = lr
+        self._gate = None            # f32[1] on the device: labels counted in the micro-batches of the current step
+        self._graph = None           # captured whole-step HIP graph (train_step_graphed)
         self.reducer = GradReducer(st.G, process_group, bucket_bytes, always_reduce) if st.G is not None else None
         self.world = self.reducer.world if self.reducer else 1
         self.mel_filters = mel_filters
@@ -155,13 +160,13 @@ class DistillationTrainer:
                 enc_t, _ = T.encode(input_features, save=False)
                 logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False)
                 del enc_t
-            for t_ in (input_features, decoder_input_ids):
-                t_.record_stream(side)
+            # (no record_stream: the inputs are the caller's and stay alive over the call, the side stream is joined
+            # below, and logits_t -- a block of the side stream's pool -- is next written by the teacher forward of the
+            # following step, which starts with side.wait_stream(main), i.e. after the loss kernel that reads it)
         enc_s, ectx = S.encode(input_features, save=not self.freeze_encoder)
         logits_s, dctx = S.decode(decoder_input_ids, enc_s, save=True)
         if side is not None:
             main.wait_stream(side)
-            logits_t.record_stream(main)
         elif self.share_encoder:
             t_ids = shift_tokens_right(labels, self.tdims.pad_token_id, self.tdims.decoder_start_token_id)
             logits_t, _ = T.decode(t_ids, enc_s, save=False)
@@ -173,6 +178,7 @@ class DistillationTrainer:
         losses = ops.distill_loss(logits_s[:R], logits_t[:R], labels_flat, self.sdims.vocab, self.temperature, 0.8,
                                   self.kl_weight, 1.0, True)
         del logits_t
+        self._gate = losses[3:4] if (zero_grad or self._gate is None) else self._gate + losses[3:4]
         if zero_grad:
             S.zero_small_grads()
         st = self.student_store
@@ -186,28 +192,107 @@ class DistillationTrainer:
         S.join_wgrad_stream()
         return losses
 
-    def optimizer_step(self, lr=None):
+    def set_lr(self, lr):
+        """Learning rate of the next optimizer step(s) (the reference steps `get_scheduler`'s LambdaLR once per step,
+        run_distillation.py:1410-1415, 1613): written to the device-resident optimizer state when it changed."""
+        if lr is not None and lr != self._lr_dev:
+            self._adam[0:1].fill_(lr)
+            self._lr_dev = lr
+
+    @property
+    def step_count(self):
+        """Optimizer steps applied so far (device-resident: a step on a batch without labels is skipped there)."""
+        return int(self._adam[1].item())
+
+    @step_count.setter
+    def step_count(self, n):
+        self._adam[1:2].fill_(float(n))
+
+    def optimizer_step(self, lr=None, _write_lr=True):
         """clip_grad_norm_ + AdamW over the flat buffers; refreshes the bf16 shadow weights (fused) and the packed
-        conv weights."""
+        conv weights.  The step is skipped ON THE DEVICE when the micro-batches of this step held no label at all
+        (the reference's loss is 0/0 = NaN there and poisons every parameter, run_distillation.py:1486-1493; with zero
+        gradients AdamW would still move the weights by momentum and weight decay)."""
         ops, st = self.ops, self.student_store
         if self.reducer is not None:
             self.reducer.wait()
-        self.step_count += 1
+        if _write_lr:
+            self.set_lr(self.lr if lr is None else lr)
         lo, hi = st.train_start, st.train_end
         gm = 1.0 / (self.world * self._accum)
         self._last_gm = gm
         self._sumsq.zero_()
         ops.sumsq(st.G[lo:hi], self._sumsq)
+        ops.adam_tick(self._adam, self._gate)
         for a, b, wd in self.segments:
-            ops.adamw(st.P[a:b], st.G[a:b], st.M[a:b], st.V[a:b], st.S[a:b], self._sumsq, self.max_grad_norm, gm,
-                      self.lr if lr is None else lr, self.betas[0], self.betas[1], self.eps, wd, self.step_count)
+            ops.adamw_dev(st.P[a:b], st.G[a:b], st.M[a:b], st.V[a:b], st.S[a:b], self._sumsq, self.max_grad_norm, gm,
+                          self._adam, self.eps, wd)
         if not self.freeze_encoder:
             st.repack_conv()
+        self._gate = None
 
     def train_step(self, input_features, decoder_input_ids, labels, lr=None):
         losses = self.forward_backward(input_features, decoder_input_ids, labels)
         self.optimizer_step(lr)
         return losses
+
+    # ---- the whole step as ONE captured HIP graph --------------------------------------------------------------
+    def train_step_graphed(self, inputs, decoder_input_ids, labels, lr=None, eager_steps=2):
+        """`train_step` (preceded by the log-mel front end when `inputs` are waveforms [B, n_samples] instead of
+        features [B, n_mels, 3000]) replayed from one HIP graph.  The shapes of a step are static, so its ~2 700
+        launches on three streams (main, frozen teacher, weight gradients), every buffer address and the cross-stream
+        dependencies are planned ONCE: the first `eager_steps` calls run eagerly on the capture stream (first-use
+        initialisation of the library and the engine), the next call captures the step -- torch's allocator serves the
+        capture from a private pool, which is the static activation arena of this (B, T): lifetimes are the Python
+        lifetimes of one step, no allocator call and no host-side stream bookkeeping remain afterwards -- and every
+        later call is three small device copies into the static input buffers plus one graph launch.  Every call
+        performs exactly one optimizer step; the returned losses tensor is static (overwritten by the next call).
+        Data-parallel runs keep the eager path (`train_step`): the bucketed RCCL all-reduce is issued between the
+        backward's layers from the host."""
+        if self.reducer is not None and self.reducer.active:
+            raise RuntimeError("train_step_graphed: data-parallel steps run eagerly (RCCL buckets are issued from the host)")
+        dev = self.student_store.P.device
+        key = (tuple(inputs.shape), inputs.dtype, tuple(decoder_input_ids.shape), self.overlap_teacher,
+               self.student.wgrad_stream is not None)
+        g = self._graph
+        if g is None or g["key"] != key:
+            g = self._graph = {"key": key, "calls": 0, "graph": None, "stream": torch.cuda.Stream(device=dev),
+                               "x": torch.empty_like(inputs), "ids": torch.empty_like(decoder_input_ids),
+                               "labels": torch.empty_like(labels), "losses": None}
+        self.set_lr(self.lr if lr is None else lr)
+        g["x"].copy_(inputs)
+        g["ids"].copy_(decoder_input_ids)
+        g["labels"].copy_(labels)
+
+        def body():
+            feats = self.features(g["x"]) if g["x"].dim() == 2 else g["x"]
+            losses = self.forward_backward(feats, g["ids"], g["labels"])
+            self.optimizer_step(_write_lr=False)
+            return losses
+
+        if g["graph"] is not None:
+            g["graph"].replay()
+        elif g["calls"] < eager_steps:
+            cur, cs = torch.cuda.current_stream(dev), g["stream"]
+            cs.wait_stream(cur)
+            with torch.cuda.stream(cs):
+                g["losses"] = body()
+            cur.wait_stream(cs)
+        else:
+            if self.ops.profile is not None:
+                raise RuntimeError("train_step_graphed: per-launch profiling events cannot be captured")
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=g["stream"]):
+                g["losses"] = body()
+            g["graph"] = graph
+            graph.replay()
+        g["calls"] += 1
+        return g["losses"]
+
+    def drop_graph(self):
+        """Forget the captured step (its private memory pool is released with it)."""
+        self._graph = None
 
     def train_step_accumulated(self, micro_batches, lr=None):
         """Gradient accumulation over a list of (input_features, decoder_input_ids, labels): gradients are summed in
@@ -222,7 +307,7 @@ class DistillationTrainer:
             self.optimizer_step(lr)
         finally:
             self._accum = 1
-        return torch.stack(out).mean(0)
+        return torch.stack(out).nanmean(0)     # (a micro-batch without labels reports NaN losses; it adds no gradient)
 
     def grad_norm(self):
         """Global gradient norm the last optimizer step clipped (what `accelerator.clip_grad_norm_` returns,
@@ -255,8 +340,13 @@ class DistillationTrainer:
             for n, t in state[key].items():
                 o, shape, _ = st.entries[n]
                 buf[o:o + t.numel()].view(shape).copy_(t.to(buf.device))
-        self.step_count = int(state["step"])
         h = state.get("hyper", {})
         self.lr, self.eps = h.get("lr", self.lr), h.get("eps", self.eps)
         self.betas = tuple(h.get("betas", self.betas))
         self.temperature, self.kl_weight = h.get("temperature", self.temperature), h.get("kl_weight", self.kl_weight)
+        self.max_grad_norm = h.get("max_grad_norm", self.max_grad_norm)
+        self.weight_decay = h.get("weight_decay", self.weight_decay)
+        self.segments = st.adam_segments(self.weight_decay)       # per-range weight decay follows the restored value
+        self._adam = self.ops.adam_state(self.lr, self.betas[0], self.betas[1], int(state["step"]))
+        self._lr_dev = self.lr
+        self._graph = None        # (a captured step has the old hyper-parameters baked in: re-planned on next use)

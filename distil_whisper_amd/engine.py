@@ -221,6 +221,7 @@ class WhisperEngine:
         self.lowp = ops.lowp
         self.ldv = _rup(self.dims.vocab, 64)
         self.wgrad_stream = None   # torch.cuda.Stream: weight-gradient GEMMs / bias column sums of the backward go there
+        self._wgrad_held, self._wgrad_fences = [], []
         # Forward-only decoder passes (the frozen teacher) may run their GEMMs over a row count padded to a multiple of
         # 320 when that costs <= 1/32 extra rows: M = 32 x 447 = 14304 -> 14400 = 45 row tiles of the 320 x 256 GEMM
         # kernel, ONE round of 225 workgroups for N = 1280 where the 128-tile kernel needs 4.4 rounds of 1120.  Pad rows
@@ -284,16 +285,36 @@ class WhisperEngine:
             # stream, their persistent GEMMs take the CUs the dX chain's kernels leave idle in their last tile round
             # (and vice versa).  Ordering: the side stream waits for everything the main stream has enqueued so far
             # (dy and x are complete); the caller joins the streams before anyone reads the gradients
-            # (join_wgrad_stream).  record_stream keeps the allocator from handing dy / x to a later main-stream
-            # kernel while the side stream still reads them.
+            # (join_wgrad_stream).  Lifetime: dy and x belong to the main stream's allocator pool, which hands a freed
+            # block to the next main-stream kernel at once -- so this engine keeps them referenced until the main
+            # stream has waited for an event recorded behind their last side-stream reader (_wgrad_fence).  No
+            # `record_stream`: that defers the reuse of a block until the host observes the side stream's progress, and
+            # with the host a few steps ahead of the device every step's activations (94 GiB) came from fresh
+            # hipMalloc'ed blocks until the device was full (round 2: 287 GiB reserved, one 4.6 s allocator retry).
             main = torch.cuda.current_stream(dy.device)
             ws.wait_stream(main)
             with torch.cuda.stream(ws):
                 self._wgrad_issue(dy, x, gout, gbias, R, bias_cols)
-            dy.record_stream(ws)
-            x.record_stream(ws)
+            self._wgrad_held += [dy, x]
         else:
             self._wgrad_issue(dy, x, gout, gbias, R, bias_cols)
+
+    wgrad_lag = 2     # layers of weight-gradient work the side stream may be behind before the main stream waits for it
+
+    def _wgrad_fence(self):
+        """Layer boundary of the backward: mark the side stream's position; tensors handed to it `wgrad_lag` boundaries
+        ago are released after the main stream has waited for that mark."""
+        ws = self.wgrad_stream
+        if ws is None or not (self._wgrad_held or self._wgrad_fences):
+            return
+        ev = torch.cuda.Event()
+        ev.record(ws)
+        self._wgrad_fences.append((ev, self._wgrad_held))
+        self._wgrad_held = []
+        while len(self._wgrad_fences) > self.wgrad_lag:
+            ev, held = self._wgrad_fences.pop(0)
+            torch.cuda.current_stream(self.st.P.device).wait_event(ev)
+            held.clear()
 
     def _wgrad_issue(self, dy, x, gout, gbias, R, bias_cols):
         if gout is not None:  # the gradient buffer was zeroed (or holds earlier micro-batches): always accumulate
@@ -310,6 +331,8 @@ class WhisperEngine:
         all-reduce of a finished range, or any other reader of the gradient buffer)."""
         if self.wgrad_stream is not None:
             torch.cuda.current_stream(self.st.P.device).wait_stream(self.wgrad_stream)
+        self._wgrad_fences.clear()
+        self._wgrad_held = []
 
     # ---- encoder -------------------------------------------------------------------------------------------------
     def encode(self, mel, save=False):
@@ -547,7 +570,10 @@ class WhisperEngine:
         return x
 
     def decode_step(self, ids_t, cache):
-        """One greedy-decoding step: ids_t int64 [B, 1] at position cache["t"] -> logits low-precision [B, ldv]."""
+        """One greedy-decoding step: ids_t int64 [B, 1] at position cache["t"] -> logits low-precision [B, ldv].
+        ALIASING: on the HIP path (`use_c_decode`) the returned tensor is the per-(cache, n) workspace of
+        dw_decode_step: it is overwritten by the next pass over the same cache with the same number of new positions
+        (its address is what captured HIP graphs replay into).  Consume or clone it before the next step."""
         ops, st, d = self.ops, self.st, self.dims
         B, t, ML = cache["B"], cache["t"], cache["max_len"]
         D, H, Lk = d.d_model, d.heads, d.max_src
@@ -572,7 +598,8 @@ class WhisperEngine:
         (ids int64 [B, n]) -> logits low-precision [B*n, ldv] (row b*n + j = position t+j of row b).  The new keys and
         values are appended first and the self-attention runs with the bottom-right aligned causal mask (query j sees
         keys <= t + j): the cached multi-token verify step of speculative decoding (run_eval.py:578-599) and the
-        prompt prefill.  cache["t"] advances by n; callers roll it back to drop rejected positions."""
+        prompt prefill.  cache["t"] advances by n; callers roll it back to drop rejected positions.  The returned logits
+        alias the cache's workspace for this n on the HIP path (see decode_step)."""
         ops, st, d = self.ops, self.st, self.dims
         B, t, ML = cache["B"], cache["t"], cache["max_len"]
         n = ids.shape[1]
@@ -681,6 +708,7 @@ class WhisperEngine:
             below = self._bias_grad(f"model.decoder.layers.{i - 1}.fc2.bias") if i > 0 else None
             dres, dy = self._layer_bwd(f"model.decoder.layers.{i}", lc, dres, dy, B, T, Lk, True, denc, i > 0, below)
             ctx["layers"][i] = None
+            self._wgrad_fence()
         if tr_emb or st.is_trainable("model.decoder.embed_positions.weight"):
             dtok = st.g[emb] if tr_emb else self._scratch_tok()
             dpos = st.g.get("model.decoder.embed_positions.weight")
@@ -719,6 +747,7 @@ class WhisperEngine:
             dres, dy = self._layer_bwd(f"model.encoder.layers.{i}", ctx["layers"][i], dres, dy, B, L, 0, False, None,
                                        i > 0, below)
             ctx["layers"][i] = None
+            self._wgrad_fence()
             if on_ready is not None:
                 # everything above layer i-1's last parameter is final (fc2.bias of layer i-1 still receives the
                 # column sums emitted by this layer's last LayerNorm backward, so the cut is at layer i's first entry)

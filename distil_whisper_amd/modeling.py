@@ -335,11 +335,13 @@ class _EngineFn(torch.autograd.Function):
         denc = eng.backward_decoder(ctx.dctx, buf, want_denc=ctx.ectx is not None)
         if ctx.ectx is not None:
             eng.backward_encoder(ctx.ectx, denc)
-        # views of the flat gradient buffer: autograd's AccumulateGrad copies them into `.grad` (one copy, not two);
-        # parameters frozen after construction (`requires_grad_(False)`, run_distillation.py:1018-1040) get None
+        # copies of the flat gradient buffer's ranges: the buffer is zeroed and rewritten by the next backward, so a
+        # returned view would change under torch.autograd.grad results, tensor hooks or DDP bucket views that keep it.
+        # (AccumulateGrad takes ownership of a fresh non-view gradient without copying it again: still one copy.)
+        # Parameters frozen after construction (`requires_grad_(False)`, run_distillation.py:1018-1040) get None.
         grads = []
         for name, p in zip(model._param_names, model._param_list):
-            grads.append(st.g[name] if (p.requires_grad and name in st.g) else None)
+            grads.append(st.g[name].clone() if (p.requires_grad and name in st.g) else None)
         return (None, None, None, None, *grads)
 
 
@@ -894,6 +896,7 @@ class WhisperForConditionalGeneration(nn.Module):
                             dec = decoders[key] = GreedyDecoder(
                                 eng, len(pending), P + max_new, eos_token_id=eos, suppress_tokens=suppress_tokens,
                                 begin_suppress_tokens=begin_suppress_tokens, use_graphs=False, pad_token_id=pad,
+                                check_every=4,      # eager passes: stop within 3 steps of the last row's EOS
                                 timestamp_rules=dict(begin_index=P, no_timestamps_token_id=nts,
                                                      max_initial_timestamp_index=max_initial_timestamp_index))
                         out = dec.run(enc, ids, max_new, min_new)[:, P:].tolist()

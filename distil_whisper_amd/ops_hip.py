@@ -79,6 +79,9 @@ _SIGS = {
     "dw_add": ([C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p], C.c_int),
     "dw_sumsq_f32": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 2 + [C.c_double] * 5 + [C.c_int, C.c_void_p], C.c_int),
+    "dw_adam_tick": ([C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+    "dw_adamw_dev": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 2 + [C.c_void_p] + [C.c_double] * 2 +
+                     [C.c_void_p], C.c_int),
     "dw_selftest_tr16": ([C.c_void_p, C.c_void_p], C.c_int),
     "dw_debug_set": ([C.c_int, C.c_int], C.c_int),
     "dw_reduce_slices": ([C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p], C.c_int),
@@ -517,6 +520,20 @@ class HipOps:
                                     float(grad_mul), float(lr), float(beta1), float(beta2), float(eps),
                                     float(weight_decay), int(step), self._stream()), "adamw")
 
+    def adam_state(self, lr, beta1, beta2, step=0):
+        """Device-resident optimizer scalars (8 doubles, include/dwamd.h dw_adam_tick)."""
+        return torch.tensor([lr, step, beta1, beta2, 0, 0, 0, 0], dtype=torch.float64, device=self.device)
+
+    def adam_tick(self, state, gate=None):
+        assert state.dtype == torch.float64 and state.numel() == 8 and (gate is None or gate.dtype == torch.float32)
+        self._chk(self.lib.dw_adam_tick(_p(state), _p(gate), self._stream()), "adam_tick")
+
+    def adamw_dev(self, p, g, m, v, shadow, sumsq, max_norm, grad_mul, state, eps, weight_decay):
+        assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+        self._chk(self.lib.dw_adamw_dev(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(sumsq), float(max_norm),
+                                        float(grad_mul), _p(state), float(eps), float(weight_decay), self._stream()),
+                  "adamw_dev")
+
 
 def _timed(key):
     def deco(fn):
@@ -531,7 +548,7 @@ def _timed(key):
 
 
 for _name, _key in (("layernorm_fwd", "ln_fwd"), ("layernorm_bwd", "ln_bwd"), ("distill_loss", "loss"),
-                    ("logmel", "logmel"), ("adamw", "adamw"), ("cast_bf16", "cast"), ("colsum", "colsum"),
+                    ("logmel", "logmel"), ("adamw", "adamw"), ("adamw_dev", "adamw"), ("cast_bf16", "cast"), ("colsum", "colsum"),
                     ("sumsq", "sumsq"), ("embed_fwd", "embed"), ("embed_bwd", "embed"), ("im2col_mel", "conv_aux"),
                     ("im2col_s2", "conv_aux"), ("col2im_s2_gelu_bwd", "conv_aux"), ("gelu_bwd", "conv_aux"),
                     ("pack_conv_weight", "conv_aux"), ("unpack_conv_grad", "conv_aux"), ("greedy_select", "select")):

@@ -182,6 +182,18 @@ int dw_sumsq_f32(const float* g, int64_t n, float* out, float* partials, void* s
 int dw_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq,
              float max_norm, float grad_mul, double lr, double beta1, double beta2, double eps, double weight_decay,
              int step, void* stream);
+/* The same update with the optimizer's scalar state RESIDENT ON THE DEVICE, so that one whole training step (forward,
+ * backward, clip, AdamW) is a fixed launch sequence that can be captured in a HIP graph and replayed: nothing the host
+ * passes by value changes from step to step.  state: 8 doubles, caller-owned: [0] lr (the host rewrites it before a step
+ * when an LR scheduler runs: get_scheduler, run_distillation.py:1410-1415), [1] number of optimizer steps taken so far,
+ * [2] beta1, [3] beta2, [4..6] written by dw_adam_tick for the update kernels of this step, [7] unused.
+ * dw_adam_tick: once per optimizer step before the dw_adamw_dev calls of that step: advances state[1] and derives
+ * lr/(1-beta1^step), sqrt(1-beta2^step).  gate (optional, f32 device scalar): when *gate <= 0 the whole step is skipped
+ * (nothing advances, no parameter changes) -- the trainer passes the loss kernel's n_valid so that a batch without a
+ * single label does not move the weights by momentum / weight decay alone. */
+int dw_adam_tick(double* state, const float* gate, void* stream);
+int dw_adamw_dev(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, const float* sumsq,
+                 float max_norm, float grad_mul, const double* state, double eps, double weight_decay, void* stream);
 
 /* ---- a11: token selection of one greedy-decoding step for the whole batch (TF:generation/logits_process.py processors
  * MinNewTokensLength, SuppressTokensAtBegin, SuppressTokens, WhisperTimeStamp as installed by

@@ -354,3 +354,22 @@ class RefOps:
         p.addcdiv_(m, denom, value=-lr / bc1)
         if shadow is not None:
             shadow.copy_(p)
+
+    # device-resident optimizer scalars (include/dwamd.h dw_adam_tick / dw_adamw_dev): same arithmetic as `adamw`
+    def adam_state(self, lr, beta1, beta2, step=0):
+        return torch.tensor([lr, step, beta1, beta2, 0, 0, 0, 0], dtype=torch.float64, device=self.device)
+
+    def adam_tick(self, state, gate=None):
+        apply = gate is None or float(gate.reshape(-1)[0]) > 0.0
+        if apply:
+            state[1] += 1.0
+        step = max(float(state[1]), 1.0)
+        state[4] = state[0] / (1.0 - float(state[2]) ** step)
+        state[5] = math.sqrt(1.0 - float(state[3]) ** step)
+        state[6] = 1.0 if apply else 0.0
+
+    def adamw_dev(self, p, g, m, v, shadow, sumsq, max_norm, grad_mul, state, eps, weight_decay):
+        if float(state[6]) == 0.0:
+            return
+        self.adamw(p, g, m, v, shadow, sumsq, max_norm, grad_mul, float(state[0]), float(state[2]), float(state[3]),
+                   eps, weight_decay, int(state[1]))

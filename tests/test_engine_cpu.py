@@ -209,3 +209,50 @@ def test_lm_head_backward_over_zero_padded_rows_gives_the_same_gradients():
     l1, g1 = grads(True)
     assert torch.equal(l0, l1)
     assert relerr(g1, g0) < 1e-6     # (dE sums 320 rows instead of 128: zero terms, but the split of K into slices differs)
+
+
+def test_batch_without_labels_skips_the_optimizer_step():
+    """All labels -100: the reference's loss is 0/0 = NaN (run_distillation.py:1486-1493).  Here the losses report NaN,
+    the gradient is zero and the optimizer step is skipped by the device-side gate (dw_adam_tick) -- parameters,
+    moments and the step count stay put instead of drifting by momentum / weight decay; the next normal step equals
+    the step a trainer takes that never saw the empty batch."""
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(seed=6)
+    ops = RefOps("cpu", lowp=torch.float32)
+    f, d, l = batch["input_features"], batch["decoder_input_ids"], batch["labels"]
+    a = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, weight_decay=0.1)
+    b = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, weight_decay=0.1)
+    a.train_step(f, d, l)
+    b.train_step(f, d, l)
+    p1 = a.student_store.P.clone()
+    losses = a.train_step(f, d, torch.full_like(l, -100))
+    assert torch.isnan(losses[:3]).all() and losses[3].item() == 0
+    assert torch.equal(a.student_store.P, p1) and a.step_count == 1
+    a.train_step(f, d, l)
+    b.train_step(f, d, l)
+    assert a.step_count == b.step_count == 2
+    assert torch.equal(a.student_store.P, b.student_store.P)
+    # accumulation: one empty micro-batch neither poisons the reported loss nor blocks the step
+    c = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+    out = c.train_step_accumulated([(f, d, torch.full_like(l, -100)), (f, d, l)])
+    assert torch.isfinite(out[:3]).all() and c.step_count == 1
+
+
+def test_resume_restores_every_hyper_parameter():
+    """load_state_dict restores weight decay (and the per-range decay segments built from it), the clip norm, lr,
+    betas, eps, temperature, kl_weight and the step count: a trainer constructed with DIFFERENT values continues
+    exactly like the one that saved the state."""
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(seed=7)
+    ops = RefOps("cpu", lowp=torch.float32)
+    f, d, l = batch["input_features"], batch["decoder_input_ids"], batch["labels"]
+    a = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, weight_decay=0.2, max_grad_norm=0.05, lr=3e-4,
+                            betas=(0.8, 0.99), eps=1e-6, temperature=3.0, kl_weight=0.5)
+    a.train_step(f, d, l)
+    state = a.state_dict()
+    a.train_step(f, d, l)
+    r = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)       # defaults: wd 0, clip 1.0, lr 1e-4 ...
+    r.load_state_dict(state)
+    assert (r.weight_decay, r.max_grad_norm, r.lr, r.betas, r.eps) == (0.2, 0.05, 3e-4, (0.8, 0.99), 1e-6)
+    assert r.segments == a.segments and any(wd == 0.2 for _, _, wd in r.segments)
+    r.train_step(f, d, l)
+    assert r.step_count == a.step_count == 2
+    assert relerr(r.student_store.P, a.student_store.P) < 1e-7

@@ -567,6 +567,41 @@ def test_adamw_and_clip(ops, ref):
     assert relerr(st["hip"][3], st["ref"][3]) < 1e-3
 
 
+def test_adamw_device_state_equals_host_scalars(ops, ref):
+    """dw_adam_tick + dw_adamw_dev (optimizer scalars resident on the device: lr, step count, betas -- what lets a HIP
+    graph replay the update) against dw_adamw with the host's scalars: same parameters, moments, shadow after three
+    steps with an LR change in between; a closed gate (n_valid = 0) leaves everything, the step count included, as is."""
+    n = 300_007
+    p = rnd((n,), 1.0, torch.float32, seed=92)
+    g = rnd((n,), 0.01, torch.float32, seed=93)
+    ss = torch.zeros(1, device="cuda")
+    ops.sumsq(g, ss)
+    lrs = (1e-3, 1e-3, 5e-4)
+    pa, ma, va = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    sa = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    for step, lr in zip((1, 2, 3), lrs):
+        ops.adamw(pa, g, ma, va, sa, ss, 1.0, 0.5, lr, 0.9, 0.999, 1e-8, 0.01, step)
+    for o in (ops, ref):
+        pb, mb, vb = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+        sb = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+        state = o.adam_state(lrs[0], 0.9, 0.999, 0)
+        open_gate, closed = torch.ones(1, device="cuda"), torch.zeros(1, device="cuda")
+        for i, lr in enumerate(lrs):
+            state[0:1].fill_(lr)
+            o.adam_tick(state, open_gate if i else None)
+            o.adamw_dev(pb, g, mb, vb, sb, ss, 1.0, 0.5, state, 1e-8, 0.01)
+            if i == 1:
+                before = pb.clone()
+                o.adam_tick(state, closed)
+                o.adamw_dev(pb, g, mb, vb, sb, ss, 1.0, 0.5, state, 1e-8, 0.01)
+                assert torch.equal(pb, before) and float(state[1]) == 2.0 and float(state[6]) == 0.0
+        assert float(state[1]) == 3.0
+        tol = 0.0 if o is ops else 1e-5
+        for x, y in ((pa, pb), (ma, mb), (va, vb)):
+            assert relerr(y, x) <= tol
+        assert relerr(sb, sa) <= (0.0 if o is ops else 1e-3)
+
+
 def test_greedy_select_matches_restatement(ops, ref):
     """csrc/decode.hip (logits processors + argmax + EOS bookkeeping in one launch) against the torch restatement whose
     timestamp rules are pinned against transformers' WhisperTimeStampLogitsProcessor (tests/test_longform.py): random

@@ -293,3 +293,59 @@ def test_empty_batch_reports_nan_like_the_reference(ops):
     losses = ops.distill_loss(s, t, labels, 1000, 2.0, 0.8, 1.0, 1.0, True)
     assert torch.isnan(losses[:3]).all() and losses[3].item() == 0
     assert float(s.float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("side_streams", [False, True])
+def test_graph_replayed_step_equals_the_eager_step(ops, side_streams):
+    """train_step_graphed: two eager calls, one capturing call, then replays of ONE HIP graph holding the whole step
+    (log-mel, teacher and student forward on their streams, backward with the weight-gradient stream, clip, AdamW with
+    device-resident scalars) against plain train_step on a twin trainer: five steps with a changing learning rate and
+    changing inputs -- identical losses and parameters (to the float-atomic summation order of the small gradients;
+    bit-equal losses on the first step)."""
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 95)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    kw = dict(overlap_teacher=side_streams, overlap_wgrad=side_streams, weight_decay=0.01)
+    e = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, **kw)
+    g = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, **kw)
+    gen = torch.Generator().manual_seed(11)
+    for i in range(5):
+        b = wo.synthetic_batch(cfg_t, 2, seed=96 + i, T=40, with_audio=False)
+        audio = (0.1 * torch.randn(2, 480000, generator=gen)).cuda()
+        ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+        lr = 1e-3 * (1 + i)
+        le = e.train_step(e.features(audio), ids, labels, lr=lr).clone()
+        lg = g.train_step_graphed(audio, ids, labels, lr=lr).clone()
+        torch.cuda.synchronize()
+        assert (g._graph["graph"] is not None) == (i >= 2)
+        if i == 0:
+            assert torch.equal(le, lg)
+        assert relerr(lg[:3], le[:3]) < 1e-5, (i, le, lg)
+    assert e.step_count == g.step_count == 5
+    assert relerr(g.student_store.P, e.student_store.P) < 2e-6
+    assert relerr(g.student_store.S, e.student_store.S) < 1e-3
+
+
+def test_batch_without_labels_is_skipped_on_the_device(ops):
+    """The HIP loss reports NaN losses and n_valid = 0 for an all-ignored batch; dw_adam_tick's gate then skips the
+    update without a host sync: parameters, moments and the step count are untouched (graph-replayed step included)."""
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 97)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    b = wo.synthetic_batch(cfg_t, 2, seed=98, T=40, with_audio=False)
+    feats = (torch.randn(2, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(4)) * 0.5).cuda()
+    ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, weight_decay=0.1)
+    for _ in range(3):
+        tr.train_step_graphed(feats, ids, labels)
+    torch.cuda.synchronize()
+    st = tr.student_store
+    p0, m0 = st.P.clone(), st.M.clone()
+    losses = tr.train_step_graphed(feats, ids, torch.full_like(labels, -100))
+    torch.cuda.synchronize()
+    assert torch.isnan(losses[:3]).all() and losses[3].item() == 0
+    assert torch.equal(st.P, p0) and torch.equal(st.M, m0) and tr.step_count == 3
+    tr.train_step(feats, ids, torch.full_like(labels, -100))
+    assert torch.equal(st.P, p0) and tr.step_count == 3
+    tr.train_step_graphed(feats, ids, labels)
+    assert tr.step_count == 4 and not torch.equal(st.P, p0)
