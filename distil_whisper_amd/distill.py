@@ -192,6 +192,27 @@ class DistillationTrainer:
         S.join_wgrad_stream()
         return losses
 
+    def eval_step(self, input_features, decoder_input_ids, labels):
+        """Forward-only CE + KL of the reference's `eval_step` (run_distillation.py:1498-1522: both models in eval
+        mode under no_grad, the same loss mix, "temperature is always 1 for eval"): no activation is kept, nothing is
+        written to the gradient buffer, the student logits are left intact.  Returns losses fp32[4] = (ce, kl, loss,
+        n_valid) on the device."""
+        ops, S, T = self.ops, self.student, self.teacher
+        B, Td = decoder_input_ids.shape
+        input_features = input_features.to(torch.float32).contiguous()
+        decoder_input_ids = decoder_input_ids.contiguous()
+        enc_s, _ = S.encode(input_features, save=False)
+        logits_s, _ = S.decode(decoder_input_ids, enc_s, save=False)
+        if self.share_encoder:
+            t_ids = shift_tokens_right(labels, self.tdims.pad_token_id, self.tdims.decoder_start_token_id)
+            logits_t, _ = T.decode(t_ids, enc_s, save=False)
+        else:
+            enc_t, _ = T.encode(input_features, save=False)
+            logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False)
+        R = B * Td
+        return ops.distill_loss(logits_s[:R], logits_t[:R], labels.reshape(-1).contiguous(), self.sdims.vocab,
+                                1.0, 0.8, self.kl_weight, 1.0, False)
+
     def set_lr(self, lr):
         """Learning rate of the next optimizer step(s) (the reference steps `get_scheduler`'s LambdaLR once per step,
         run_distillation.py:1410-1415, 1613): written to the device-resident optimizer state when it changed."""

@@ -34,6 +34,10 @@ class Seq2SeqLMOutput:
     loss: Optional[torch.Tensor] = None
     logits: Optional[torch.Tensor] = None
     encoder_last_hidden_state: Optional[torch.Tensor] = None
+    # handles for the fused loss kernels (not part of the reference surface): the engine's low-precision logits
+    # [rows >= B*T, padded vocabulary] behind `.logits`, and the model that produced them
+    _logits_lowp: Optional[torch.Tensor] = None
+    _model: Optional[object] = None
 
 
 @dataclass
@@ -317,6 +321,7 @@ class _EngineFn(torch.autograd.Function):
         V = eng.dims.vocab
         ctx.model, ctx.ectx, ctx.dctx, ctx.shape = model, ectx, dctx, (B, T, V)
         ctx.logits_buf = logits if train else None
+        model._last_logits_lowp = logits
         Re = B * eng.dims.max_src
         out_logits = logits[: B * T, :V].float().view(B, T, V)       # accelerate upcasts model outputs to fp32
         enc_out = enc[:Re].float().view(B, eng.dims.max_src, -1)
@@ -343,6 +348,50 @@ class _EngineFn(torch.autograd.Function):
         for name, p in zip(model._param_names, model._param_list):
             grads.append(st.g[name].clone() if (p.requires_grad and name in st.g) else None)
         return (None, None, None, None, *grads)
+
+
+class _FusedLossFn(torch.autograd.Function):
+    """CE (+ optionally the KL distillation term against teacher logits) of the engine's low-precision logits in ONE
+    pass of the fused loss kernel (dw_distill_loss) instead of log_softmax / softmax / KLDivLoss over three fp32
+    [B, T, V] temporaries (run_distillation.py:1486-1493, TF:modeling_whisper.py:1083-1087).  `logits` (the fp32 output
+    of the model, same values) only ties the node into the autograd graph; the kernel reads the bf16 buffer.  Backward
+    returns d(loss)/d(logits) -- computed by the same kernel pass -- as an fp32 [B, T, V] tensor, which is what
+    autograd would hand to the model's backward anyway."""
+
+    @staticmethod
+    def forward(ctx, logits, ops, s_buf, t_buf, labels, V, temperature, ce_weight, kl_weight):
+        B, T = labels.shape
+        R = B * T
+        lab = labels.reshape(-1).contiguous()
+        need = ctx.needs_input_grad[0]      # (grad mode is off inside Function.forward; this is the real signal)
+        grad = ops.empty(tuple(s_buf[:R].shape), s_buf.dtype) if need else None
+        t_rows = s_buf[:R] if t_buf is None else t_buf[:R]
+        losses = ops.distill_loss(s_buf[:R], t_rows, lab, V, temperature, ce_weight, kl_weight if t_buf is not None else 0.0,
+                                  1.0, need, grad_out=grad)
+        ctx.grad, ctx.shape = grad, (B, T, V)
+        ctx.mark_non_differentiable(losses)
+        total = losses[2] if t_buf is not None else losses[0]
+        return total.clone(), losses
+
+    @staticmethod
+    def backward(ctx, g_total, _g_losses):
+        B, T, V = ctx.shape
+        g = ctx.grad[:, :V].float().view(B, T, V)
+        return (g * g_total, None, None, None, None, None, None, None, None)
+
+
+def fused_distillation_loss(student_outputs, teacher_outputs, labels, temperature=2.0, kl_weight=1.0, ce_weight=0.8):
+    """One-call replacement for lines 1486-1493 of run_distillation.py (`ce_loss`, the two softmaxes, `kl_divergence`,
+    `loss = 0.8 * ce_loss + kl_weight * kl_loss`) when both models are `distil_whisper_amd` modules: the fused HIP loss
+    kernel reads the two engines' bf16 logits once.  Returns (loss, {"loss", "ce_loss", "kl_loss"}) with the metrics
+    detached, like the reference's `metrics` dict (1494-1495).  `loss.backward()` then runs the student's backward."""
+    s_buf, t_buf = student_outputs._logits_lowp, teacher_outputs._logits_lowp
+    if s_buf is None or t_buf is None:
+        raise ValueError("fused_distillation_loss needs outputs of distil_whisper_amd.WhisperForConditionalGeneration")
+    model = student_outputs._model
+    loss, losses = _FusedLossFn.apply(student_outputs.logits, model.ops, s_buf, t_buf, labels, model.dims.vocab,
+                                      float(temperature), float(ce_weight), float(kl_weight))
+    return loss, {"loss": losses[2], "ce_loss": losses[0], "kl_loss": losses[1]}
 
 
 class WhisperForConditionalGeneration(nn.Module):
@@ -509,10 +558,12 @@ class WhisperForConditionalGeneration(nn.Module):
                              f"{input_features.shape[-1]}. Make sure to pad the input mel features to {2 * d.max_src}.")
         self._sync_shadow()
         logits, enc = _EngineFn.apply(self, input_features, enc_in, decoder_input_ids, *self._param_list)
+        lowp, self._last_logits_lowp = self._last_logits_lowp, None
         loss = None
         if labels is not None:
-            loss = F.cross_entropy(logits.view(-1, d.vocab), labels.reshape(-1))
-        return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc)
+            # token-mean CE over labels != -100 (TF:modeling_whisper.py:1083-1087) by the fused loss kernel
+            loss, _ = _FusedLossFn.apply(logits, self.ops, lowp, None, labels, d.vocab, 1.0, 1.0, 0.0)
+        return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc, _logits_lowp=lowp, _model=self)
 
     @torch.no_grad()
     def generate(self, input_features=None, generation_config=None, logits_processor=None, stopping_criteria=None,

@@ -377,10 +377,13 @@ class HipOps:
         self._t1(e0, "attn_bwd", 10.0 * B * H * Lq * Lk * 64)
         return dq, dk, dv
 
-    def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad):
+    def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad,
+                     grad_out=None):
         """Returns losses f32[4] = (ce, kl, total, n_valid).  With want_grad the gradient w.r.t. the student logits
-        overwrites s_logits in place (bf16)."""
+        overwrites s_logits in place (bf16), or goes to `grad_out` (same shape and dtype) when that is given."""
         rows, ld = s_logits.shape
+        if grad_out is not None:
+            assert want_grad and grad_out.shape == s_logits.shape and grad_out.dtype == torch.bfloat16 and grad_out.is_contiguous()
         assert s_logits.dtype == torch.bfloat16 and t_logits.dtype == torch.bfloat16
         assert s_logits.is_contiguous() and t_logits.is_contiguous() and t_logits.shape == s_logits.shape
         assert labels.dtype == torch.int64 and labels.numel() == rows and labels.is_contiguous()
@@ -390,7 +393,8 @@ class HipOps:
         counts = self.empty((2,), torch.int32)
         self._chk(self.lib.dw_distill_loss(_p(s_logits), _p(t_logits), _p(labels), rows, V, ld, float(temperature),
                                            float(ce_weight), float(kl_weight), float(grad_scale), _p(losses),
-                                           _p(s_logits) if want_grad else None, _p(row_ce), _p(row_kl), _p(counts),
+                                           (_p(s_logits) if grad_out is None else _p(grad_out)) if want_grad else None,
+                                           _p(row_ce), _p(row_kl), _p(counts),
                                            self._stream()), "distill_loss")
         return losses
 

@@ -183,20 +183,23 @@ class RefOps:
         return rq, rk, rv
 
     # run_distillation.py:1453-1462, 1486-1493 + CrossEntropyLoss (TF:modeling_whisper.py:1083-1087), verbatim math
-    def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad):
-        zs = s_logits[:, :V].float().detach().requires_grad_(want_grad)
-        zt = t_logits[:, :V].float()
-        ce = F.cross_entropy(zs, labels, ignore_index=-100)
-        teacher = F.softmax(zt / temperature, dim=-1)
-        student = F.log_softmax(zs / temperature, dim=-1)
-        div = F.kl_div(student, teacher, reduction="none")
-        mask = (labels >= 0).unsqueeze(-1)
-        kl = (div * mask).sum() / mask.sum() * temperature ** 2
-        total = ce_weight * ce + kl_weight * kl
-        if want_grad:
-            (g,) = torch.autograd.grad(total * grad_scale, zs)
-            s_logits.zero_()
-            s_logits[:, :V] = g.to(s_logits.dtype)
+    def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad,
+                     grad_out=None):
+        with torch.enable_grad():      # (callers may sit inside an autograd.Function.forward, where grad mode is off)
+            zs = s_logits[:, :V].float().detach().requires_grad_(want_grad)
+            zt = t_logits[:, :V].float().detach()
+            ce = F.cross_entropy(zs, labels, ignore_index=-100)
+            teacher = F.softmax(zt / temperature, dim=-1)
+            student = F.log_softmax(zs / temperature, dim=-1)
+            div = F.kl_div(student, teacher, reduction="none")
+            mask = (labels >= 0).unsqueeze(-1)
+            kl = (div * mask).sum() / mask.sum() * temperature ** 2
+            total = ce_weight * ce + kl_weight * kl
+            if want_grad:
+                (g,) = torch.autograd.grad(total * grad_scale, zs)
+                dst = s_logits if grad_out is None else grad_out
+                dst.zero_()
+                dst[:, :V] = torch.nan_to_num(g).to(dst.dtype) if float((labels != -100).sum()) == 0 else g.to(dst.dtype)
         n = (labels != -100).sum().float()
         return torch.stack([ce.detach(), kl.detach(), total.detach(), n]).float()
 

@@ -256,3 +256,21 @@ def test_resume_restores_every_hyper_parameter():
     r.train_step(f, d, l)
     assert r.step_count == a.step_count == 2
     assert relerr(r.student_store.P, a.student_store.P) < 1e-7
+
+
+def test_eval_step_is_the_reference_eval_step():
+    """DistillationTrainer.eval_step = run_distillation.py:1498-1522: forward only, temperature 1, 0.8 CE + kl_weight KL;
+    gradients and parameters untouched."""
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(seed=8)
+    ops = RefOps("cpu", lowp=torch.float32)
+    tr = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, temperature=2.0, kl_weight=0.6)
+    tr.teacher_store.load_state_dict(t_sd, round_bf16=False)
+    f, d, l = batch["input_features"], batch["decoder_input_ids"], batch["labels"]
+    g0 = tr.student_store.G.clone()
+    ev = tr.eval_step(f, d, l)
+    params = {k: v.clone() for k, v in s_sd.items()}
+    loss, metrics, *_ = wo.train_step(params, cfg_s, t_sd, cfg_t, batch, 1.0, 0.6, False)
+    assert abs(ev[0].item() - metrics["ce_loss"].item()) < 2e-5 * metrics["ce_loss"].item()
+    assert abs(ev[1].item() - metrics["kl_loss"].item()) < 2e-4 * metrics["kl_loss"].item() + 1e-7
+    assert abs(ev[2].item() - loss.item()) < 2e-5 * loss.item()
+    assert torch.equal(tr.student_store.G, g0)

@@ -135,3 +135,17 @@ def test_collator_matches_oracle_and_lr_schedule():
     for step in range(50):
         assert abs(sched.get_last_lr()[0] - linear_schedule_lr(step, 1e-4, 10, 50, 2)) < 1e-12
         sched.step(); sched.step()
+
+
+def test_returned_gradients_do_not_alias_the_flat_buffer():
+    """torch.autograd.grad results (and anything else that keeps the tensors the backward returns: hooks, DDP bucket
+    views) must survive the next backward, which zeroes and rewrites the engine's flat gradient buffer."""
+    cfg_s, s_sd, model, feats, ids, labels = build()
+    w = model.get_parameter("model.decoder.layers.0.fc1.weight")
+    b = model.get_parameter("model.encoder.layers.0.self_attn.v_proj.bias")
+    loss = model(input_features=feats, decoder_input_ids=ids, labels=labels).loss
+    gw, gb = torch.autograd.grad(loss, [w, b])
+    keep_w, keep_b = gw.clone(), gb.clone()
+    (model(input_features=feats * 0.3, decoder_input_ids=ids, labels=labels).loss * 5.0).backward()
+    assert torch.equal(gw, keep_w) and torch.equal(gb, keep_b)
+    assert not torch.equal(w.grad, keep_w)

@@ -1,0 +1,169 @@
+"""The reference's loop body, VERBATIM (oracle/reference_loop.py: train_step, eval_step, kl_divergence, the AdamW
+parameter groups, backward / clip / step / zero_grad of run_distillation.py:1377-1407, 1453-1522, 1606-1614), driven
+through the drop-in classes of distil_whisper_amd.modeling wrapped in DistributedDataParallel
+(`accelerator.prepare`, run_distillation.py:1449-1451):
+
+  * CPU (`-m "not gpu"`): the same loop over the `transformers` classes and over the drop-in classes (torch restatement of
+    the kernels, fp32) -- metrics, gradient norm and every parameter after two iterations with weight decay and a
+    changing learning rate; shared-encoder mode; eval_step; the one-call fused loss.
+  * GPU: the loop over the drop-in classes on the HIP kernels, DDP over RCCL (one rank), against the fixtures the
+    `transformers` classes produced for BASELINE config 1 (tiny.en 4/4 -> 4/1, B = 2): tests/golden/tiny_fp32.npz and
+    tiny_bf16_autocast.npz (loss within 1e-3 relative, the north-star tolerance).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import whisper_oracle as wo
+from oracle.reference_loop import ReferenceLoop
+from oracle.ref_ops import RefOps
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Group:
+    """One-rank process group for the DistributedDataParallel wrap (gloo on CPU, nccl = RCCL on the GPU)."""
+
+    def __init__(self, backend, **kw):
+        self.backend, self.kw = backend, kw
+
+    def __enter__(self):
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(_free_port())
+        dist.init_process_group(self.backend, rank=0, world_size=1, **self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        dist.destroy_process_group()
+
+
+def _batches(cfg, n, B, T, seed, device="cpu"):
+    out = []
+    for i in range(n):
+        b = wo.synthetic_batch(cfg, B, seed=seed + i, T=T, with_audio=False)
+        feats = torch.randn(B, cfg.n_mels, 3000, generator=torch.Generator().manual_seed(seed + 100 + i)) * 0.5
+        out.append({"input_features": feats.to(device), "decoder_input_ids": b["decoder_input_ids"].to(device),
+                    "labels": b["labels"].to(device)})
+    return out
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_reference_loop_over_drop_in_classes_equals_transformers_cpu(shared):
+    pytest.importorskip("transformers")
+    from transformers.modeling_outputs import BaseModelOutput as HFBaseModelOutput
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from oracle.gen_golden import hf_model
+    from distil_whisper_amd import modeling as M
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 61)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    batches = _batches(cfg_t, 3, 2, 33, seed=62)
+    kw = dict(share_hidden_states=shared, kl_weight=0.7, max_grad_norm=0.5, learning_rate=1e-3, weight_decay=0.1,
+              lr_lambda=lambda step: 1.0 / (1 + step))
+
+    hf_s, hf_t = hf_model(cfg_s, s_sd), hf_model(cfg_t, t_sd)
+    if shared:
+        hf_s.freeze_encoder()
+    ref = ReferenceLoop(hf_s, hf_t, HFBaseModelOutput, **kw)
+    ref_out = [ref.training_iteration(b, temperature=2.0) for b in batches[:2]]
+    ref_eval = ref.eval_step(batches[2])
+
+    def ours(fused):
+        ops = RefOps("cpu", lowp=torch.float32)
+        s = M.WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+        t = M.WhisperForConditionalGeneration(cfg_t, ops=ops, state_dict=t_sd)
+        if shared:
+            s.freeze_encoder()
+        loop = ReferenceLoop(s, t, M.BaseModelOutput, wrap=lambda m: DDP(m),
+                             fused_loss=M.fused_distillation_loss if fused else None, **kw)
+        out = [loop.training_iteration(b, temperature=2.0) for b in batches[:2]]
+        return s, out, loop.eval_step(batches[2])
+
+    with _Group("gloo"):
+        for fused in (False, True):
+            s, out, ev = ours(fused)
+            for (m_ref, gn_ref), (m, gn) in zip(ref_out, out):
+                for k in ("loss", "ce_loss", "kl_loss"):
+                    assert abs(m[k].item() - m_ref[k].item()) < 2e-5 * abs(m_ref[k].item()) + 1e-7, (fused, k)
+                assert abs(gn.item() - gn_ref.item()) < 1e-4 * gn_ref.item(), fused
+            for k in ("loss", "ce_loss", "kl_loss"):
+                assert abs(ev[k].item() - ref_eval[k].item()) < 2e-5 * abs(ref_eval[k].item()) + 1e-7, (fused, k)
+            hf_params = dict(hf_s.named_parameters())
+            for n, p in s.named_parameters():
+                assert relerr(p, hf_params[n]) < 2e-5, (fused, n)      # (two Adam steps at lr 1e-3 amplify fp32 round-off)
+                assert p.requires_grad == hf_params[n].requires_grad, n
+            assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in s.parameters())   # zero_grad reached them
+
+
+@pytest.mark.gpu
+def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fixtures():
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from distil_whisper_amd import modeling as M
+    from distil_whisper_amd.ops_hip import HipOps
+    ops = HipOps("cuda:0")
+    g32 = np.load(os.path.join(GOLD, "tiny_fp32.npz"))
+    gbf = np.load(os.path.join(GOLD, "tiny_bf16_autocast.npz"))
+    seed, B = int(g32["seed"]), int(g32["B"])
+    cfg_t = wo.CONFIGS["tiny.en"]
+    t_sd = wo.init_state_dict(cfg_t, seed)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 4, 1)
+    b = wo.synthetic_batch(cfg_t, B, seed=seed + 1)
+    fe = M.WhisperFeatureExtractor(feature_size=cfg_t.n_mels, ops=ops)
+    feats = fe([a for a in b["audio"]], sampling_rate=16000, return_tensors="pt").input_features
+    assert feats.is_cuda and np.abs(feats[:, ::9, ::97].cpu().numpy() - g32["mel_slice"]).max() < 1e-4
+    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"].cuda(), "labels": b["labels"].cuda()}
+    probe = [str(x) for x in g32["probe_names"]]
+
+    def sample(t):
+        t = t.detach().reshape(-1)
+        return t[:: max(1, t.numel() // 256)][:256].float().cpu()
+
+    results = {}
+    torch.cuda.set_device(0)
+    with _Group("nccl", device_id=torch.device("cuda:0")):
+        for fused in (False, True):
+            student = M.WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)                    # fp32 master, bf16 compute
+            teacher = M.WhisperForConditionalGeneration(cfg_t, ops=ops, state_dict=t_sd, dtype=torch.bfloat16)   # teacher_dtype
+            loop = ReferenceLoop(student, teacher, M.BaseModelOutput, teacher_dtype=torch.bfloat16,
+                                 wrap=lambda m: DDP(m, device_ids=[0]),
+                                 fused_loss=M.fused_distillation_loss if fused else None)
+            assert isinstance(loop.student_model, DDP)
+            ev = loop.eval_step(batch)
+            metrics, gnorm = loop.training_iteration(batch, temperature=2.0)
+            torch.cuda.synchronize()
+            for name, key in (("ce", "ce_loss"), ("kl", "kl_loss"), ("loss", "loss")):
+                tol = 1e-3 if name != "kl" else 1e-2      # kl is a small difference of large terms (0.12 vs ce 10.9)
+                for gold in (g32, gbf):
+                    assert abs(metrics[key].item() - float(gold[name])) < tol * abs(float(gold[name])), (fused, name)
+            assert abs(ev["ce_loss"].item() - float(g32["ce"])) < 1e-3 * float(g32["ce"])     # eval CE = train CE (no dropout)
+            assert abs(gnorm.item() - float(g32["grad_norm"])) < 2e-2 * float(g32["grad_norm"]), (fused, gnorm.item())
+            named = dict(student.named_parameters())
+            for i, n in enumerate(probe):
+                # first AdamW step moves every weight by ~lr * sign(g) = 1e-4
+                assert (sample(named[n]) - torch.tensor(g32[f"param{i}"])).abs().max().item() < 2.1e-4, (fused, n)
+            # the optimizer wrote the fp32 master weights; the next forward must see them (shadow refresh)
+            m2, _ = loop.training_iteration(batch, temperature=2.0)
+            assert m2["loss"].item() < metrics["loss"].item()
+            results[fused] = (metrics, student.state_dict())
+    (ma, sa), (mb, sb) = results[False], results[True]
+    for k in ("loss", "ce_loss", "kl_loss"):
+        assert abs(ma[k].item() - mb[k].item()) < 2e-3 * abs(ma[k].item()) + 1e-6, k       # torch softmaxes vs the fused kernel
+    for n in probe:
+        assert relerr(sb[n], sa[n]) < 1e-4, n
