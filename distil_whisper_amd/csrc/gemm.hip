@@ -54,6 +54,7 @@ static int g_gemm_variant = 2163;   // 115 (8-wave software-pipelined kernels + 
 int g_gemm_strip = 0;
 int g_gemm_cus = 256;
 static int g_gemm_stage_next = 1;   // dw_debug_set key 11: profiling switches of the software-pipelined kernels (bit 4: skip the epilogue)
+static int g_gemm_stagger = 0;   // dw_debug_set key 12: start offsets of the persistent workgroups (S | unit << 8), 0 = none
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
 
 // Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never
@@ -88,6 +89,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 8) { g_skinny_wide = value; return DW_OK; }
     if (key == 10) { g_gemm_dynamic = value; return DW_OK; }
     if (key == 11) { g_gemm_stage_next = value; return DW_OK; }
+    if (key == 12) { g_gemm_stagger = value; return DW_OK; }
     if (key == 9) { if (value < 8 || value > 256 || (value & 7)) return DW_EINVAL; g_gemm_cus = value; return DW_OK; }
     return DW_EINVAL;
 }
@@ -143,6 +145,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.sched = nullptr;
     p.zg_f16 = g->z_is_gelu_grad ? 1 : 0;
     p.stage_next = g_gemm_stage_next;
+    p.stagger = g_gemm_stagger;
     if (p.zg_f16 && g->z_out && g->act != 1) return DW_EINVAL;   // gelu'(z) is a by-product of the GELU epilogue
     p.ln_x = g->ln_x; p.ln_g = g->ln_gamma; p.ln_b = g->ln_beta; p.ld_lnx = g->ld_lnx; p.ln_x_dtype = g->ln_x_dtype;
     p.ln_eps = g->ln_eps;

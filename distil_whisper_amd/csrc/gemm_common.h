@@ -32,6 +32,7 @@ struct GemmP {
     int stage_next;        // debug key 11; bit 4 (16): the software-pipelined kernels skip the epilogue (profiling: tools/gemm_overhead.py)
     int zg_f16;            // z_out / zgrad hold gelu'(z) in fp16 instead of z in bf16 (see DwGemm.z_is_gelu_grad)
     int* sched;            // persistent kernels: 9 device counters of this stream (dynamic job hand-out), or null
+    int stagger;           // debug key 12: start offsets of the persistent workgroups (gemm_wp.h), 0 = none
 };
 
 // Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.

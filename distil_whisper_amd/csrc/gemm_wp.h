@@ -93,6 +93,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     __shared__ int job_slot[2];
     GemmJobs jobs;
     gemm_jobs_begin(p, jobs, job_slot);
+    if (p.stagger > 0) {
+        // Experiment (dw_debug_set key 12 = S | unit << 8): the workgroups of a launch run their tiles in lockstep, so every
+        // tile round ends with 256 CUs storing at once (33 MB in ~6 us = the HBM write rate) while the matrix pipes idle.
+        // Start offsets (local index mod S) x unit x ~4 us spread the bursts; the dynamic job hand-out shares the tiles.
+        const int k = ((blockIdx.x >> 3) % (p.stagger & 255)) * (p.stagger >> 8);
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     while (jobs.cur < jobs.cnt) {
         gemm_jobs_prefetch(p, jobs, job_slot);
         int tm, tn, ks;

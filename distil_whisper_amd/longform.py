@@ -8,6 +8,12 @@ Reference behaviour: run_eval.py:566-576, 726-786 drives the `transformers` ASR 
   * per utterance, the text tokens of consecutive windows are stitched by the sliding longest-common-sequence rule of
     `_find_longest_common_sequence` (TF:models/whisper/tokenization_whisper.py, called from `_decode_asr` when no
     timestamps are requested).
+  * with `return_timestamps=True` (run_eval.py:566-576 passes it through to the pipeline) the windows are decoded under
+    the timestamp rules and `_decode_asr` stitches them by their timestamp tokens instead: a state machine over the
+    windows that places every `<|t|>` on the utterance's time axis (window offset minus left stride), opens a segment at
+    the first usable timestamp and closes it at the next, ignores the timestamps that fall into a stride (the pair that
+    straddles the right stride is resolved by the NEXT window) and merges the text tokens a segment collected from
+    several windows with the same longest-common-sequence rule (`stitch_timestamped` below).
 Here the windows are gathered on the GPU straight into the [B, 480000] buffer of the log-mel kernel, encoded and
 decoded by decoding.GreedyDecoder (HIP-graph replay of the token steps); chunking and stitching are integer host
 logic restated below and pinned against the `transformers` functions in tests/test_longform.py.
@@ -70,12 +76,95 @@ def merge_sequences(sequences):
     return total
 
 
+def stitch_timestamped(windows, timestamp_begin, special_ids=(), prompt_token_id=None, decoder_start_token_id=None,
+                       time_precision=0.02, segment_size=1500):
+    """Timestamp branch of the reference's chunk stitching (`_decode_asr`, TF:models/whisper/tokenization_whisper.py, as
+    the ASR pipeline calls it for Whisper with `return_timestamps=True`), on token ids only.
+
+    windows: [{"tokens": generated ids of one window (a leading <|startofprev|> prompt is dropped up to
+    `decoder_start_token_id`), "stride": (window seconds, left stride seconds, right stride seconds) or None}] in time
+    order.  Returns [{"timestamp": (start, end), "tokens": [...]}]; `end` is None for a trailing segment whose closing
+    timestamp was never produced.  Rules, per window:
+      * a timestamp token t stands for (t - timestamp_begin) * time_precision seconds after the window's first sample;
+        windows overlap by their strides, so the window's origin on the utterance axis is the running offset minus its
+        left stride; within one `generate` output that itself ran the seek loop, a timestamp smaller than its
+        predecessor means the next 30 s segment started (`segment_size` frames, or the last closed pair's end);
+      * timestamps of the right stride are deferred: from the first timestamp token at or beyond (window - right
+        stride) on, every timestamp sets `skip`, and the first timestamp after a skip is swallowed too (timestamps come
+        in end/start pairs); with text pending from an earlier window, timestamps inside the left stride are swallowed;
+      * otherwise a timestamp opens the segment if none is open, is ignored if it repeats the opening time, and else
+        closes it: the text tokens the segment collected over the windows are merged by `merge_sequences`."""
+    special = set(special_ids)
+    segments, pending = [], []
+    seg_start = None
+    offset, skip = 0.0, False
+    for w in windows:
+        toks = [int(t) for t in w["tokens"]]
+        if prompt_token_id is not None and toks and toks[0] == prompt_token_id:
+            toks = toks[toks.index(decoder_start_token_id):] if decoder_start_token_id in toks else []
+        stride = w.get("stride")
+        hold_from = None                      # first deferred timestamp token of the right stride
+        first_usable = timestamp_begin        # timestamps below it lie in the left stride
+        if stride is not None:
+            win, left, right = stride
+            offset -= left
+            if left:
+                first_usable = left / time_precision + timestamp_begin
+            if right:
+                for t in reversed(toks):
+                    if t >= timestamp_begin:
+                        if hold_from is not None and (t - timestamp_begin) * time_precision < win - right:
+                            break
+                        hold_from = t
+        text = []
+        high, before_high, carried = 0.0, 0.0, 0.0      # seek-loop outputs: running / previous maximum, time of earlier segments
+        for i, t in enumerate(toks):
+            if t in special:
+                continue
+            if t < timestamp_begin:
+                text.append(t)
+                continue
+            local = float((t - timestamp_begin) * time_precision)
+            if local < high:
+                lone_end = i >= 2 and not (toks[i - 1] >= timestamp_begin and toks[i - 2] >= timestamp_begin)
+                if lone_end:
+                    carried += time_precision * segment_size
+                else:
+                    high = before_high
+                    carried += before_high
+            before_high, high = high, local
+            when = round((t - timestamp_begin) * time_precision + offset + carried, 2)
+            if hold_from and t >= hold_from:
+                skip = True
+            elif skip or (pending and t < first_usable):
+                skip = False
+            elif seg_start is None:
+                seg_start = when
+            elif when != seg_start:
+                pending.append(text)
+                segments.append({"timestamp": (seg_start, when), "tokens": merge_sequences(pending)})
+                pending, text, seg_start = [], [], None
+        if stride is not None:
+            offset += win - right
+        if text:
+            pending.append(text)
+        elif not any(pending):
+            pending, seg_start = [], None
+    if pending:
+        segments.append({"timestamp": (seg_start, None), "tokens": merge_sequences(pending)})
+    return segments
+
+
 class LongFormTranscriber:
     """audio (list of 1-D float tensors/arrays at 16 kHz, any length) -> list of stitched text-token id lists."""
 
     def __init__(self, model, feature_extractor, batch_size=16, chunk_length_s=30.0, stride_length_s=None,
                  max_new_tokens=128, prompt_ids=None, eos_token_id=None, first_special_id=None, suppress_tokens=None,
-                 begin_suppress_tokens=None, use_graphs=None, rank=0, world=1):
+                 begin_suppress_tokens=None, use_graphs=None, rank=0, world=1, return_timestamps=False,
+                 no_timestamps_token_id=None, max_initial_timestamp_index=50, special_ids=None):
+        """return_timestamps=True: the windows are decoded under the timestamp rules (`prompt_ids` must then not end in
+        <|notimestamps|>; `no_timestamps_token_id` is required) and stitched by their timestamp tokens; the call returns
+        per utterance a list of {"timestamp": (start, end), "tokens": [...]} (`stitch_timestamped`)."""
         self.model, self.fe = model, feature_extractor
         self.B = int(batch_size)
         self.rank, self.world = int(rank), int(world)
@@ -100,17 +189,29 @@ class LongFormTranscriber:
         self.prompt = torch.as_tensor([d.decoder_start_token_id] if prompt_ids is None else list(prompt_ids),
                                       dtype=torch.long, device=dev)
         self.max_new = int(max_new_tokens)
+        self.return_timestamps = bool(return_timestamps)
+        rules = None
+        if self.return_timestamps:
+            if no_timestamps_token_id is None or eos_token_id is None:
+                raise ValueError("return_timestamps=True needs no_timestamps_token_id and eos_token_id")
+            self.timestamp_begin = int(no_timestamps_token_id) + 1
+            self.time_precision = feature_extractor.chunk_length / d.max_src          # 30 s / 1500 positions = 0.02 s
+            # every id the tokenizer lists as special and that is not a timestamp: by default the ids from EOS up to
+            # <|notimestamps|> (Whisper's vocabulary keeps them contiguous)
+            self.special_ids = set(range(int(eos_token_id), self.timestamp_begin)) if special_ids is None else set(special_ids)
+            rules = dict(begin_index=len(self.prompt), no_timestamps_token_id=int(no_timestamps_token_id),
+                         max_initial_timestamp_index=max_initial_timestamp_index)
         self.decoder = GreedyDecoder(model.engine, self.B, len(self.prompt) + self.max_new, eos_token_id=eos_token_id,
                                      suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens,
-                                     use_graphs=use_graphs)
+                                     use_graphs=use_graphs, timestamp_rules=rules)
         self._wave = torch.zeros((self.B, feature_extractor.n_samples), dtype=torch.float32, device=dev)
 
     def plan(self, lengths):
         """[(utterance, start, length)] for all windows of all utterances, in pipeline order."""
         jobs = []
         for u, n in enumerate(lengths):
-            for start, length, _, _, _ in chunk_spans(int(n), self.chunk_len, self.stride_left, self.stride_right):
-                jobs.append((u, start, length))
+            for start, length, sl, sr, _ in chunk_spans(int(n), self.chunk_len, self.stride_left, self.stride_right):
+                jobs.append((u, start, length, sl, sr))
         return jobs
 
     def __call__(self, audios, gather=False, group=None):
@@ -131,6 +232,8 @@ class LongFormTranscriber:
         if gather:
             from .gather import gather_token_lists
             rows = gather_token_lists(mine, self.eos if self.eos is not None else 0, self.dev, group=group)
+            if self.return_timestamps:
+                raise NotImplementedError("gather=True exchanges plain id lists; gather timestamped segments per rank")
             if len(rows) != n_all:
                 raise RuntimeError(f"gathered {len(rows)} transcripts for {n_all} utterances: ranks disagree on the input")
             return rows
@@ -144,14 +247,23 @@ class LongFormTranscriber:
         for b0 in range(0, len(jobs), self.B):
             batch = jobs[b0:b0 + self.B]
             self._wave.zero_()
-            for r, (u, start, length) in enumerate(batch):
+            for r, (u, start, length, _, _) in enumerate(batch):
                 self._wave[r, :length].copy_(audios[u][start:start + length])
             feats = model.ops.logmel(self._wave, self.fe._filt)
             enc, _ = model.engine.encode(feats, save=False)
             ids = self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
-            for r, (u, _, _) in enumerate(batch):
+            sr_hz = float(self.fe.sampling_rate)
+            for r, (u, _, length, sl, sr) in enumerate(batch):
                 row = ids[r, self.prompt.numel():]
+                if self.return_timestamps:
+                    # the pipeline hands `_decode_asr` the whole generated row (EOS / padding are special ids) and the
+                    # window's (length, left stride, right stride) in seconds
+                    per_utt[u].append({"tokens": [int(x) for x in row], "stride": (length / sr_hz, sl / sr_hz, sr / sr_hz)})
+                    continue
                 text = [int(x) for x in row if x < self.first_special]
                 if text:                                   # (_decode_asr only keeps windows that produced text tokens)
                     per_utt[u].append(text)
+        if self.return_timestamps:
+            return [stitch_timestamped(w, self.timestamp_begin, self.special_ids, time_precision=self.time_precision)
+                    for w in per_utt]
         return [merge_sequences(seqs) for seqs in per_utt]

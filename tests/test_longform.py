@@ -264,3 +264,119 @@ def test_pseudo_labeller_with_beam_search_equals_generate():
         ref = _seq(model, f, max_new_tokens=5, num_beams=2, eos_token_id=eos)[0, 1:].tolist()
         ref = ref[:ref.index(eos)] if eos in ref else ref
         assert t == ref
+
+
+# ---- chunked long-form WITH timestamps (run_eval.py:566-576 -> pipeline(..., return_timestamps=True) -> _decode_asr) ----
+class _StubTokenizer:
+    """What `_decode_asr` needs of a WhisperTokenizer, over a micro vocabulary: ids >= TS0 are timestamps."""
+    EOS, SOT, PREV, NTS = 900, 901, 909, 911
+    TS0 = NTS + 1
+    all_special_ids = list(range(900, 912))
+
+    def convert_tokens_to_ids(self, tok):
+        return {"<|notimestamps|>": self.NTS, "<|startofprev|>": self.PREV, "<|startoftranscript|>": self.SOT}[tok]
+
+    def _strip_prompt(self, token_ids, prompt_token_id, decoder_start_token_id):
+        from transformers.models.whisper.tokenization_whisper import WhisperTokenizer
+        return WhisperTokenizer._strip_prompt(self, token_ids, prompt_token_id, decoder_start_token_id)
+
+    def decode(self, ids, **_):
+        return "".join(f"<{int(t)}>" for t in ids)
+
+
+def _reference_segments(windows, time_precision=0.02):
+    from transformers.models.whisper.tokenization_whisper import _decode_asr
+    tok = _StubTokenizer()
+    outs = []
+    for w in windows:
+        o = {"tokens": np.asarray([w["tokens"]], dtype=np.int64)}
+        if w.get("stride") is not None:
+            o["stride"] = tuple(w["stride"])
+        outs.append(o)
+    _, opt = _decode_asr(tok, outs, return_timestamps=True, return_language=False, time_precision=time_precision)
+    return [(c["timestamp"], c["text"]) for c in opt["chunks"]]
+
+
+def test_timestamped_stitching_equals_transformers_decode_asr():
+    """`stitch_timestamped` against the reference's `_decode_asr` (imported) on random window sequences: timestamp
+    pairs, lone timestamps, repeats, timestamps inside both strides, windows without text, a <|startofprev|> prompt,
+    special tokens in between, seek-loop style restarts inside one output."""
+    pytest.importorskip("transformers")
+    from distil_whisper_amd.longform import stitch_timestamped
+    T = _StubTokenizer()
+    rng = np.random.default_rng(17)
+    nonempty = 0
+    for case in range(400):
+        n_win = int(rng.integers(1, 6))
+        strided = case % 5 != 0
+        windows = []
+        for wi in range(n_win):
+            toks = []
+            if rng.random() < 0.15:
+                toks += [T.PREV, 5, 6, T.SOT]
+            elif rng.random() < 0.5:
+                toks += [T.SOT, 902]
+            t = int(rng.integers(0, 200))
+            for _ in range(int(rng.integers(0, 6))):
+                kind = rng.random()
+                if kind < 0.75:
+                    toks.append(T.TS0 + t)                                   # <|start|> text <|end|>
+                    toks += rng.integers(0, 40, size=int(rng.integers(0, 5))).tolist()
+                    t = min(1500, t + int(rng.integers(0, 300)))
+                    toks.append(T.TS0 + t)
+                    if rng.random() < 0.2:
+                        toks.append(T.TS0 + t)                               # repeated timestamp
+                elif kind < 0.9:
+                    toks += rng.integers(0, 40, size=int(rng.integers(1, 4))).tolist()
+                else:
+                    t = int(rng.integers(0, 100))                            # restart: the seek loop moved on
+            toks.append(T.EOS)
+            stride = None
+            if strided:
+                left = 0.0 if wi == 0 else 5.0
+                right = 0.0 if wi == n_win - 1 else 5.0
+                stride = (30.0 if wi < n_win - 1 else float(rng.integers(11, 31)), left, right)
+            windows.append({"tokens": toks, "stride": stride})
+        want = _reference_segments(windows)
+        got = stitch_timestamped(windows, T.TS0, T.all_special_ids, prompt_token_id=T.PREV, decoder_start_token_id=T.SOT)
+        got = [(g["timestamp"], T.decode(g["tokens"])) for g in got]
+        assert got == want, (case, windows, got, want)
+        nonempty += bool(want)
+    assert nonempty > 300
+
+
+def test_transcriber_with_timestamps_equals_per_window_decode_plus_decode_asr():
+    """LongFormTranscriber(return_timestamps=True): windows batched through the graph-capable decoder under the
+    timestamp rules, stitched by `stitch_timestamped` == the same windows decoded one at a time, stitched by the
+    reference's `_decode_asr`."""
+    pytest.importorskip("transformers")
+    cfg = wo.OracleConfig(128, 2, 256, 2, 2, 1000, 80, pad_token_id=900, decoder_start_token_id=901)
+    T = _StubTokenizer()
+    sd = wo.init_state_dict(cfg, 23, std=0.1)
+    ops = RefOps("cpu", lowp=torch.float32)
+    model = WhisperForConditionalGeneration(cfg, ops=ops, state_dict=sd)
+    fe = WhisperFeatureExtractor(feature_size=80, ops=ops)
+    rng = np.random.default_rng(6)
+    audios = [0.1 * rng.standard_normal(n).astype(np.float32) for n in (1_100_000, 480_000, 700_000)]
+    suppress = list(range(902, 912))
+    kw = dict(batch_size=2, chunk_length_s=30.0, max_new_tokens=12, prompt_ids=[T.SOT], eos_token_id=T.EOS,
+              suppress_tokens=suppress, use_graphs=False)
+    tr = LongFormTranscriber(model, fe, return_timestamps=True, no_timestamps_token_id=T.NTS, **kw)
+    got = tr(audios)
+    assert len(got) == 3
+    one = GreedyDecoder(model.engine, 1, 1 + 12, eos_token_id=T.EOS, suppress_tokens=suppress, use_graphs=False,
+                        timestamp_rules=dict(begin_index=1, no_timestamps_token_id=T.NTS, max_initial_timestamp_index=50))
+    n_ts = 0
+    for a, segs in zip(audios, got):
+        windows = []
+        for start, length, sl, sr, _ in chunk_spans(len(a), 480000, 80000, 80000):
+            f = fe(a[start:start + length], sampling_rate=16000, return_tensors="pt").input_features
+            enc, _ = model.engine.encode(f, save=False)
+            row = one.run(enc, torch.tensor([[T.SOT]]), 12)[0, 1:].tolist()
+            n_ts += sum(t >= T.TS0 for t in row)
+            windows.append({"tokens": row, "stride": (length / 16000.0, sl / 16000.0, sr / 16000.0)})
+        want = _reference_segments(windows)
+        assert [(g["timestamp"], T.decode(g["tokens"])) for g in segs] == want
+    assert n_ts >= 6          # the timestamp rules were active: the windows carry timestamp tokens
+    with pytest.raises(ValueError, match="no_timestamps_token_id"):
+        LongFormTranscriber(model, fe, return_timestamps=True, **kw)

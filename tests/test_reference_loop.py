@@ -166,4 +166,6 @@ def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fix
     for k in ("loss", "ce_loss", "kl_loss"):
         assert abs(ma[k].item() - mb[k].item()) < 2e-3 * abs(ma[k].item()) + 1e-6, k       # torch softmaxes vs the fused kernel
     for n in probe:
-        assert relerr(sb[n], sa[n]) < 1e-4, n
+        # two Adam steps at lr 1e-4 are sign-like (m / sqrt(v) ~ +-1): elements whose tiny gradient changes sign between
+        # the two ways of rounding d(loss)/d(logits) to bf16 move by 2e-4 in opposite directions
+        assert relerr(sb[n], sa[n]) < 2e-3, n

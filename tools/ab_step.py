@@ -27,6 +27,8 @@ for r in range(4):
     for c in configs:
         ops.lib.dw_debug_set(0, c[0]); ops.lib.dw_debug_set(1, c[1]); ops.lib.dw_debug_set(3, c[2] if len(c) > 2 else 5); ops.lib.dw_debug_set(6, c[3] if len(c) > 3 else 8); ops.lib.dw_debug_set(10, c[4] if len(c) > 4 else 1)
         ops.lib.dw_debug_set(11, c[6] if len(c) > 6 else 1)
+        ops.lib.dw_debug_set(9, c[10] if len(c) > 10 else 256)             # CUs the persistent GEMM grids occupy
+        ops.lib.dw_debug_set(12, c[11] if len(c) > 11 else 0)              # start offsets of the persistent workgroups
         type(tr.student).ffn_keeps_gelu_grad = bool(c[5]) if len(c) > 5 else True
         tr.set_overlap_wgrad(bool(c[7]) if len(c) > 7 else False)          # weight-gradient GEMMs on a second stream
         tr.overlap_teacher = bool(c[8]) if len(c) > 8 else False           # teacher forward on a second stream
