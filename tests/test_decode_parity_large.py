@@ -21,9 +21,10 @@ from oracle import gen_golden_decode_large as gl
 PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decode_large_v3.json")
 GOLD = json.load(open(PATH))
 SC = {s["name"]: s for s in GOLD["scenarios"]}
-# largest |logit - reference| / sigma allowed at the reference's top-8 ids: fp32 restatement on CPU, bf16 HIP kernels with
-# an fp32 or bf16 residual stream (measured on the MI355X: see the prints of the GPU test)
-TOL = {"cpu": 2e-4, "student_2_layer_decoder": 0.04, "teacher_32_layer_decoder": 0.12}
+# largest |logit - reference| / sigma allowed at the reference's top-8 ids: fp32 restatement on CPU; bf16 HIP kernels
+# (measured on the MI355X, maximum over 384 values: 0.037 sigma with the fp32 residual stream, 0.040 with the bf16 one,
+# for the 2-layer decoder -- a third of the free run's smallest margin; the bounds leave 1.5x)
+TOL = {"cpu": 2e-4, "student_2_layer_decoder": 0.06, "teacher_32_layer_decoder": 0.15}
 
 
 def _build(ops, s, dtype):

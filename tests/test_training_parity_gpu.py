@@ -350,3 +350,39 @@ def test_batch_without_labels_is_skipped_on_the_device(ops):
     assert torch.equal(st.P, p0) and tr.step_count == 3
     tr.train_step_graphed(feats, ids, labels)
     assert tr.step_count == 4 and not torch.equal(st.P, p0)
+
+
+def test_large_v3_batch_7_with_the_bench_configuration_matches_the_reference_losses(ops):
+    """The benchmark's models (large-v3-shaped 32/32 teacher -> 32/2 student) at batch 7 against the losses the
+    `transformers` classes computed on CPU (tests/golden/large_v3_b7.npz from oracle/gen_golden_large_step.py: fp32, and
+    student under bf16 autocast with a bf16 teacher), with EVERY option bench.py switches on, together: teacher stream,
+    weight-gradient stream, teacher decoder GEMMs over padded rows (3129 -> 3200), zero-padded LM-head rows, and the
+    whole step replayed from a HIP graph.  Tolerance: 1e-3 relative on ce and loss (north_star), 1e-2 on kl."""
+    import numpy as np
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_v3_b7.npz")
+    g = np.load(path)
+    seed, B = int(g["seed"]), int(g["B"])
+    cfg_t = wo.CONFIGS["large-v3"]
+    t_sd = wo.init_state_dict(cfg_t, seed)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 32, 2)
+    b = wo.synthetic_batch(cfg_t, B, seed=seed + 1, with_audio=False)
+    feats = (torch.randn(B, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(seed + 2)) * 0.5).cuda()
+    ids, labels = b["decoder_input_ids"].cuda(), b["labels"].cuda()
+    tr = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, overlap_teacher=True, overlap_wgrad=True, pad_teacher_rows=True)
+    del t_sd, s_sd
+    assert tr.teacher._gemm_rows(B * 447, False) == 3200 and tr.student.pad_lm_rows
+    ev = tr.eval_step(feats, ids, labels).cpu()           # temperature 1: only the CE is comparable with the fixture
+    assert abs(ev[0].item() - float(g["ce_bf16"])) < 1e-3 * float(g["ce_bf16"])
+    losses = []
+    for _ in range(3):                                     # eager, eager, captured + replayed
+        losses.append(tr.train_step_graphed(feats, ids, labels, lr=0.0).clone())
+    torch.cuda.synchronize()
+    assert tr._graph["graph"] is not None
+    for i, l in enumerate(losses):
+        l = l.cpu()
+        for name, idx, tol in (("ce", 0, 1e-3), ("kl", 1, 1e-2), ("loss", 2, 1e-3)):
+            for ref in (float(g[f"{name}_fp32"]), float(g[f"{name}_bf16"])):
+                assert abs(l[idx].item() - ref) < tol * abs(ref), (i, name, l[idx].item(), ref)
+        assert l[3].item() == float((labels != -100).sum())
+    assert torch.equal(losses[0], losses[1])               # lr = 0: the same step three times (weights unchanged)
+    assert relerr(losses[2][:3], losses[0][:3]) < 1e-6
