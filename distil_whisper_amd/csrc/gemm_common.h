@@ -184,19 +184,38 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, i
 // store, GELU, GELU' with the prefetched z, residual add with the prefetched r, C store).  `v` holds the fp32
 // accumulator values; the caller guarantees the 4 columns are in range and every pointer allows 4-wide accesses.
 // `cdst` / `zdst`: addresses of the 4 output elements in C (element size per c_dtype) and in z_out (2-byte elements).
+// F >= 0: the epilogue flavour is a compile-time bit set (EPI_*) and every test below folds away; F < 0: the tests read the
+// parameter block at run time (general walk, rare flavours).  The unrolled interior walk is instantiated per flavour and
+// the flavour is chosen ONCE per tile (gemm_epilogue): the run-time version inlined 32 times per wave tile put the GELU
+// arithmetic, both residual forms and every store variant into each of the 32 row groups -- ~16 000 instructions
+// (>100 KB) of which a plain epilogue executed ~400, scattered over the whole range behind 600 branches: more than the
+// 64 KiB instruction cache two CUs share, re-fetched from L2 every tile.
+enum { EPI_BIAS = 1, EPI_ZBF16 = 2, EPI_GELU = 4, EPI_STOREG = 8, EPI_ZG16 = 16, EPI_ZGBF = 32, EPI_RES = 64, EPI_RES_F32 = 128,
+       EPI_ROUND = 256, EPI_OUT_F32 = 512 };
+__device__ __forceinline__ int gemm_epi_flavour(const GemmP& p) {
+    return (p.bias ? EPI_BIAS : 0) | ((p.z_out && !p.zg_f16) ? EPI_ZBF16 : 0) | (p.act == 1 ? EPI_GELU : 0) |
+           ((p.z_out && p.zg_f16) ? EPI_STOREG : 0) | ((p.zgrad && p.zg_f16) ? EPI_ZG16 : 0) |
+           ((p.zgrad && !p.zg_f16) ? EPI_ZGBF : 0) | (p.r ? EPI_RES : 0) | ((p.r && p.r_dtype == DW_F32) ? EPI_RES_F32 : 0) |
+           ((p.r && p.round_res) ? EPI_ROUND : 0) | (p.c_dtype == DW_F32 ? EPI_OUT_F32 : 0);
+}
+template <int F = -1>
 __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], const f32x4& b4, bool plain, bool have_side,
                                               const bf16x4& zs, const f32x4& rs, char* cdst, char* zdst) {
-    if (!plain) {
+    constexpr bool RT = F < 0;
+    const bool any = RT ? !plain : (F & ~EPI_OUT_F32) != 0;
+    if (any) {
+        if (RT || (F & EPI_BIAS)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += b4[e];
-        if (p.z_out && !p.zg_f16) {
+            for (int e = 0; e < 4; ++e) v[e] += b4[e];
+        }
+        if (RT ? (p.z_out && !p.zg_f16) : bool(F & EPI_ZBF16)) {
             bf16x4 z4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
             *(bf16x4*)zdst = z4;
         }
-        if (p.act == 1) {
-            const bool store_g = p.z_out && p.zg_f16;
+        if (RT ? p.act == 1 : bool(F & EPI_GELU)) {
+            const bool store_g = RT ? (p.z_out && p.zg_f16) : bool(F & EPI_STOREG);
             f16x4 g4;
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
@@ -211,12 +230,12 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
             }
             if (store_g) *(f16x4*)zdst = g4;
         }
-        if (have_side) {
-            if (p.zgrad && p.zg_f16) {                    // the forward stored gelu'(z) (fp16 bits in the bf16-typed slots)
+        if (RT ? have_side : (F & (EPI_ZG16 | EPI_ZGBF | EPI_RES)) != 0) {
+            if (RT ? (p.zgrad && p.zg_f16) : bool(F & EPI_ZG16)) {    // the forward stored gelu'(z) (fp16 bits in the bf16-typed slots)
                 const f16x4 g4 = __builtin_bit_cast(f16x4, zs);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= (float)g4[e];
-            } else if (p.zgrad) {
+            } else if (RT ? p.zgrad != nullptr : bool(F & EPI_ZGBF)) {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     f32x2 x2; x2[0] = bf2f(zs[e]); x2[1] = bf2f(zs[e + 1]);
@@ -224,9 +243,9 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
                     v[e] *= g2[0]; v[e + 1] *= g2[1];
                 }
             }
-            if (p.r) {
+            if (RT ? p.r != nullptr : bool(F & EPI_RES)) {
                 float rv[4];
-                if (p.r_dtype == DW_F32) {
+                if (RT ? p.r_dtype == DW_F32 : bool(F & EPI_RES_F32)) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rv[e] = rs[e];
                 } else {
@@ -234,12 +253,13 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
                     rv[0] = __uint_as_float(u0 << 16); rv[1] = __uint_as_float(u0 & 0xffff0000u);
                     rv[2] = __uint_as_float(u1 << 16); rv[3] = __uint_as_float(u1 & 0xffff0000u);
                 }
+                const bool rnd = RT ? p.round_res != 0 : bool(F & EPI_ROUND);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (p.round_res ? round_bf16(v[e]) : v[e]) + rv[e];
+                for (int e = 0; e < 4; ++e) v[e] = (rnd ? round_bf16(v[e]) : v[e]) + rv[e];
             }
         }
     }
-    if (p.c_dtype == DW_F32) {
+    if (RT ? p.c_dtype == DW_F32 : bool(F & EPI_OUT_F32)) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[e];
@@ -341,25 +361,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
         const unsigned l_r = (unsigned)((pr * (int)p.ldr + pc) * es_r);
         bf16x4 zq[PFD];
         f32x4 rq[PFD];                             // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
-        auto side_load = [&](auto gc) __attribute__((always_inline)) {   // gc: linear row-group index = slab * NIT + group
-            constexpr int gi = decltype(gc)::value;
-            constexpr int slot = gi % PFD;
-            constexpr long rg = (gi / NIT) * 32 + (gi % NIT) * RPI;              // first row of the row group in the wave tile
-            if (pf_z) zq[slot] = *(const bf16x4*)(zg_u + rg * p.ldzg * 2 + l_zg);
-            if (pf_r) {
-                const char* src = r_u + rg * p.ldr * es_r + l_r;
-                if (p.r_dtype == DW_F32) rq[slot] = *(const f32x4*)src;
-                else {
-                    const f32x2 t = *(const f32x2*)src;
-                    rq[slot][0] = t[0]; rq[slot][1] = t[1];
+        // One copy of the slab walk per epilogue flavour (F >= 0: compile-time; -1: run-time tests, everything else).
+        // (run-time form: F = -1 with side inputs, F = -2 without -- two copies, so that the copy without them does not
+        // carry the prefetch registers through the GELU arithmetic)
+        auto walk = [&](auto fc) __attribute__((always_inline)) {
+            constexpr int F = decltype(fc)::value;
+            constexpr bool RT = F < 0;
+            constexpr bool side = RT ? F == -1 : (F & (EPI_ZG16 | EPI_ZGBF | EPI_RES)) != 0;
+            const bool want_z = RT ? pf_z : (F & (EPI_ZG16 | EPI_ZGBF)) != 0;
+            const bool want_r = RT ? pf_r : (F & EPI_RES) != 0;
+            const bool r_f32 = RT ? p.r_dtype == DW_F32 : (F & EPI_RES_F32) != 0;
+            const int esc = RT ? es_c : ((F & EPI_OUT_F32) ? 4 : 2), esr = RT ? es_r : ((F & EPI_RES_F32) ? 4 : 2);
+            auto side_load = [&](auto gc) __attribute__((always_inline)) {   // gc: linear row-group index = slab * NIT + group
+                constexpr int gi = decltype(gc)::value;
+                constexpr int slot = gi % PFD;
+                constexpr long rg = (gi / NIT) * 32 + (gi % NIT) * RPI;              // first row of the row group in the wave tile
+                if (want_z) zq[slot] = *(const bf16x4*)(zg_u + rg * p.ldzg * 2 + l_zg);
+                if (want_r) {
+                    const char* src = r_u + rg * p.ldr * esr + l_r;
+                    if (r_f32) rq[slot] = *(const f32x4*)src;
+                    else {
+                        const f32x2 t = *(const f32x2*)src;
+                        rq[slot][0] = t[0]; rq[slot][1] = t[1];
+                    }
                 }
-            }
-        };
-        // Two copies of the slab walk, with and without side inputs (block-uniform choice): the copy without them
-        // does not carry the prefetch registers through the GELU arithmetic.
-        auto walk = [&](auto side_c) __attribute__((always_inline)) {
-            constexpr bool SIDE = decltype(side_c)::value;
-            if constexpr (SIDE) static_for<0, PFD>([&](auto gc) __attribute__((always_inline)) { side_load(gc); });
+            };
+            if constexpr (side) static_for<0, PFD>([&](auto gc) __attribute__((always_inline)) { side_load(gc); });
             hook();
             __syncthreads();                       // every wave is done reading the operand tiles
             static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
@@ -372,19 +399,50 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                     const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
                     bf16x4 zs;
                     f32x4 rs;
-                    if constexpr (SIDE) {
+                    if constexpr (side) {
                         constexpr int gi = i * NIT + it;
                         zs = zq[gi % PFD]; rs = rq[gi % PFD];
                         if constexpr (gi + PFD < FM * NIT) side_load(std::integral_constant<int, gi + PFD>{});
                     }
                     float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                    gemm_epi_vec4(p, v, b4, plain, SIDE, zs, rs, c_u + rg * p.ldc * es_c + l_c, z_u + rg * p.ldz * 2 + l_z);
+                    gemm_epi_vec4<(F < 0 ? -1 : F)>(p, v, b4, plain, side, zs, rs, c_u + rg * p.ldc * esc + l_c, z_u + rg * p.ldz * 2 + l_z);
                 });
             });
         };
-        if (pf_z || pf_r) walk(std::true_type{});
-        else walk(std::false_type{});
-        return;
+#define DW_EPI_CASE(F) case (F): walk(std::integral_constant<int, (F)>{}); return
+        if constexpr (FM == 4 || FM == 2) {
+            // 256-row kernels (8 waves: FM = 4; 16 waves and the 128-tile variant: FM = 2): one compact walk per flavour the step uses; any other flavour (the conv stem's GEMMs: two
+            // launches per step) takes the looped general walk below -- there is NO unrolled run-time copy in the image.
+            switch (gemm_epi_flavour(p)) {
+                DW_EPI_CASE(0);                                                               // dX GEMMs, LM head
+                DW_EPI_CASE(EPI_BIAS);                                                        // QKV / Q / KV projections
+                DW_EPI_CASE(EPI_BIAS | EPI_GELU);                                             // teacher fc1
+                DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);                                // student fc1 (keeps gelu'(z))
+                DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);      // student out-proj / fc2
+                DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROUND);                                  // teacher out-proj / fc2
+                DW_EPI_CASE(EPI_ZG16);                                                        // dX of fc2 (x gelu'(z))
+                DW_EPI_CASE(EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);                 // d(encoder output) accumulation
+                DW_EPI_CASE(EPI_OUT_F32);                                                     // fp32 partial slabs of the dW GEMMs
+                default: break;
+            }
+        } else {
+            // (the 320-row tile -- FM = 5, 160 accumulator registers -- and the 16-wave kernels keep the run-time walk for
+            // the flavours with side inputs: with one walk per flavour the 320-row kernel's register allocation falls
+            // apart, 763 spills against 12)
+            if constexpr (FM == 5) {
+                switch (gemm_epi_flavour(p)) {
+                    DW_EPI_CASE(0);
+                    DW_EPI_CASE(EPI_BIAS);
+                    DW_EPI_CASE(EPI_BIAS | EPI_GELU);
+                    DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);
+                    default: break;
+                }
+            }
+            if (pf_z || pf_r) walk(std::integral_constant<int, -1>{});
+            else walk(std::integral_constant<int, -2>{});
+            return;
+        }
+#undef DW_EPI_CASE
     }
 
     // ---- general walk (ragged tile edges, unaligned pointers, atomic accumulation): looped, loads at use ----

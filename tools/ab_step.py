@@ -21,10 +21,19 @@ def step():
 # (GEMM variant, strip[, attention-backward mode]); variant 3 = default, 4 = phase-pipelined kernel; strip 0 = auto rule;
 # attention mode = dw_debug_set key 3 (default 1)
 configs = eval(os.environ.get("DW_AB", "[(115,0,5),(2163,0,5)]"))
+# optional 13th field: 1 = run the config on distil_whisper_amd/libdwamd_base.so (a build of another commit, copied there by
+# hand) instead of libdwamd.so -- the only way to compare two BUILDS on one box (boxes of the pool differ by up to 10 %)
+import ctypes
+from distil_whisper_amd import ops_hip as _oh
+_libs = {0: ops.lib}
+_base = os.path.join(os.path.dirname(_oh.LIB_PATH), "libdwamd_base.so")
+if os.path.exists(_base):
+    _libs[1] = _oh.load_library(_base)
 step(); torch.cuda.synchronize()
 res = {c: [] for c in configs}
 for r in range(4):
     for c in configs:
+        ops.lib = _libs[c[12] if len(c) > 12 else 0]
         ops.lib.dw_debug_set(0, c[0]); ops.lib.dw_debug_set(1, c[1]); ops.lib.dw_debug_set(3, c[2] if len(c) > 2 else 5); ops.lib.dw_debug_set(6, c[3] if len(c) > 3 else 8); ops.lib.dw_debug_set(10, c[4] if len(c) > 4 else 1)
         ops.lib.dw_debug_set(11, c[6] if len(c) > 6 else 1)
         ops.lib.dw_debug_set(9, c[10] if len(c) > 10 else 256)             # CUs the persistent GEMM grids occupy
