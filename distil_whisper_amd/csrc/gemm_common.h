@@ -435,6 +435,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                     DW_EPI_CASE(EPI_BIAS);
                     DW_EPI_CASE(EPI_BIAS | EPI_GELU);
                     DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);
+                    DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);
+                    DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROUND);
                     default: break;
                 }
             }
