@@ -55,6 +55,7 @@ int g_gemm_strip = 0;
 int g_gemm_cus = 256;
 static int g_gemm_stage_next = 1;   // dw_debug_set key 11: profiling switches of the software-pipelined kernels (bit 4: skip the epilogue)
 static int g_gemm_stagger = 0;   // dw_debug_set key 12: start offsets of the persistent workgroups (S | unit << 8), 0 = none
+static unsigned g_gemm_trace_lo = 0, g_gemm_trace_hi = 0;   // dw_debug_set keys 13 / 14: device pointer of the phase-trace buffer
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
 
 // Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never
@@ -90,6 +91,8 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 10) { g_gemm_dynamic = value; return DW_OK; }
     if (key == 11) { g_gemm_stage_next = value; return DW_OK; }
     if (key == 12) { g_gemm_stagger = value; return DW_OK; }
+    if (key == 13) { g_gemm_trace_lo = (unsigned)value; return DW_OK; }
+    if (key == 14) { g_gemm_trace_hi = (unsigned)value; return DW_OK; }
     if (key == 9) { if (value < 8 || value > 256 || (value & 7)) return DW_EINVAL; g_gemm_cus = value; return DW_OK; }
     return DW_EINVAL;
 }
@@ -146,6 +149,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.zg_f16 = g->z_is_gelu_grad ? 1 : 0;
     p.stage_next = g_gemm_stage_next;
     p.stagger = g_gemm_stagger;
+    p.trace = (long long*)(((unsigned long long)g_gemm_trace_hi << 32) | g_gemm_trace_lo);
     if (p.zg_f16 && g->z_out && g->act != 1) return DW_EINVAL;   // gelu'(z) is a by-product of the GELU epilogue
     p.ln_x = g->ln_x; p.ln_g = g->ln_gamma; p.ln_b = g->ln_beta; p.ld_lnx = g->ld_lnx; p.ln_x_dtype = g->ln_x_dtype;
     p.ln_eps = g->ln_eps;

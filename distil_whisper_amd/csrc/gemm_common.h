@@ -33,6 +33,8 @@ struct GemmP {
     int zg_f16;            // z_out / zgrad hold gelu'(z) in fp16 instead of z in bf16 (see DwGemm.z_is_gelu_grad)
     int* sched;            // persistent kernels: 9 device counters of this stream (dynamic job hand-out), or null
     int stagger;           // debug key 12: start offsets of the persistent workgroups (gemm_wp.h), 0 = none
+    long long* trace;      // debug keys 13 / 14 (low / high half of a device pointer): per-workgroup phase timestamps of
+                           // the first 8 tiles (gemm_wp.h DW_TRACE; tools/gemm_phase_trace.py), null = off
 };
 
 // Persistent workgroups: the grid holds at most one workgroup per CU; each walks a list of output-tile jobs.
@@ -190,6 +192,7 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, i
 // arithmetic, both residual forms and every store variant into each of the 32 row groups -- ~16 000 instructions
 // (>100 KB) of which a plain epilogue executed ~400, scattered over the whole range behind 600 branches: more than the
 // 64 KiB instruction cache two CUs share, re-fetched from L2 every tile.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 enum { EPI_BIAS = 1, EPI_ZBF16 = 2, EPI_GELU = 4, EPI_STOREG = 8, EPI_ZG16 = 16, EPI_ZGBF = 32, EPI_RES = 64, EPI_RES_F32 = 128,
        EPI_ROUND = 256, EPI_OUT_F32 = 512 };
 __device__ __forceinline__ int gemm_epi_flavour(const GemmP& p) {
@@ -273,11 +276,30 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
 }
 
 struct GemmNoHook { __device__ __forceinline__ void operator()() const {} };
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release/acquire fence too: hipcc puts
+// `s_waitcnt vmcnt(0)` in front of its s_barrier, which waits for EVERY outstanding vector-memory operation of the wave --
+// the epilogue's stores and the operand DMA already in flight for the next tile.  Nothing in these kernels communicates
+// through global memory inside a workgroup, so the barriers around the LDS patches / operand buffers need lgkmcnt only.
+__device__ __forceinline__ void gemm_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 // `hook` runs once per wave after the epilogue's leading loads are issued and before its first barrier (the software
 // pipelined kernels request the next job's first operand tile there).
-template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook>
+// SWZ: the wave's patch is 32 rows x TN floats WITHOUT padding, its 16-byte slots XOR-swizzled by (row & 15) instead
+// (conflict-free for the transposing b128 writes -- 16 consecutive rows hit 16 different slots -- and for the row-major
+// b128 reads -- a row's 16 slots are a permutation): 8 waves x 8 KiB = exactly one 64 KiB operand buffer, so the
+// software-pipelined kernels can keep the patches in buffer 1 while the NEXT tile's first operand tile is already
+// arriving in buffer 0 (gemm_wp.h).
+template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
-                                              int m0_, int wm0_, int n0_, int wn0_, int ks_, Hook hook = Hook()) {
+                                              int m0_, int wm0_, int n0_, int wn0_, int ks_, Hook hook = Hook(),
+                                              const float* lds_bias = nullptr) {
+    // lds_bias: the tile's bias slice (BN floats from column n0) staged in LDS by the caller at the start of the tile
+    // (interior tiles only).  A bias read from global memory here is an ordinary load whose vmcnt wait also drains every
+    // operand DMA the caller has in flight for the NEXT tile (the counter retires in order).
+    static_assert(!SWZ || TN == 64, "swizzled patch: 16 slots of 16 bytes per row");
     // tile and wave coordinates are the same in every lane: say so (the job index comes out of an LDS slot, which the
     // compiler must otherwise treat as a per-lane value, and every row address would be 64-bit vector arithmetic)
     const int m0 = __builtin_amdgcn_readfirstlane(m0_), wm0 = __builtin_amdgcn_readfirstlane(wm0_);
@@ -298,7 +320,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     //     per-element code.  Keeping the general code out of the unrolled walk is what keeps the kernel's
     //     instruction footprint small: unrolled, it was >90 % of a 600 KB kernel image and the 4-wave kernel spent
     //     ~40 us per tile fetching instructions.
-    constexpr int PLD = TN + 4;                    // patch row stride in floats (TN = 64 -> 68: 8 rows x 4 banks)
+    constexpr int PLD = SWZ ? TN : TN + 4;         // patch row stride in floats (TN = 64 -> 68: 8 rows x 4 banks; SWZ: 64)
     constexpr int LPR = TN / 4;                    // lanes per row in the row-major walk
     constexpr int RPI = 64 / LPR;                  // rows per instruction
     constexpr int NIT = 32 / RPI;                  // row groups of a 32-row slab
@@ -312,7 +334,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     const bool full = p.vec && n + 3 < p.n;
     const bool interior = p.vec && !p.atomic && p.r_row_mod <= 0 && n0 + wn0 + TN <= p.n && m0 + wm0 + FM * 32 <= p.m;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && n_in) {
+    if (p.bias && lds_bias && interior) b4 = *(const f32x4*)(lds_bias + wn0 + pc);
+    else if (p.bias && n_in) {
         if (full) b4 = *(const f32x4*)(p.bias + n);
         else {
 #pragma unroll
@@ -328,7 +351,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                 f32x4 v4;
                 v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1];
                 v4[2] = acc[i][j][g * 4 + 2]; v4[3] = acc[i][j][g * 4 + 3];
-                *(f32x4*)(patch + ln * PLD + j * 32 + g * 8 + hi * 4) = v4;
+                if constexpr (SWZ) *(f32x4*)(patch + ln * PLD + (((j * 8 + g * 2 + hi) ^ (ln & 15)) << 2)) = v4;
+                else *(f32x4*)(patch + ln * PLD + j * 32 + g * 8 + hi * 4) = v4;
             });
         });
         // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads that follow)
@@ -388,7 +412,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             };
             if constexpr (side) static_for<0, PFD>([&](auto gc) __attribute__((always_inline)) { side_load(gc); });
             hook();
-            __syncthreads();                       // every wave is done reading the operand tiles
+            if constexpr (SWZ) gemm_lds_barrier(); else __syncthreads();   // every wave is done reading the operand tiles
             static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 to_patch(ic);
@@ -396,7 +420,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                     constexpr int it = decltype(itc)::value;
                     const int rl = it * RPI + pr;
                     constexpr long rg = i * 32 + it * RPI;
-                    const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
+                    const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + (SWZ ? (((pc >> 2) ^ (rl & 15)) << 2) : pc));
                     bf16x4 zs;
                     f32x4 rs;
                     if constexpr (side) {
@@ -414,10 +438,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             // 256-row kernels (8 waves: FM = 4; 16 waves and the 128-tile variant: FM = 2): one compact walk per flavour the step uses; any other flavour (the conv stem's GEMMs: two
             // launches per step) takes the looped general walk below -- there is NO unrolled run-time copy in the image.
             switch (gemm_epi_flavour(p)) {
-                DW_EPI_CASE(0);                                                               // dX GEMMs, LM head
-                DW_EPI_CASE(EPI_BIAS);                                                        // QKV / Q / KV projections
-                DW_EPI_CASE(EPI_BIAS | EPI_GELU);                                             // teacher fc1
-                DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);                                // student fc1 (keeps gelu'(z))
+                DW_EPI_CASE(0);                                                              // dX GEMMs, LM head
+                DW_EPI_CASE(EPI_BIAS);                                                       // QKV / Q / KV projections
+                DW_EPI_CASE(EPI_BIAS | EPI_GELU);                                            // teacher fc1
+                DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);                               // student fc1 (keeps gelu'(z))
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);      // student out-proj / fc2
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROUND);                                  // teacher out-proj / fc2
                 DW_EPI_CASE(EPI_ZG16);                                                        // dX of fc2 (x gelu'(z))
@@ -449,7 +473,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
 
     // ---- general walk (ragged tile edges, unaligned pointers, atomic accumulation): looped, loads at use ----
     hook();
-    __syncthreads();
+    if constexpr (SWZ) gemm_lds_barrier(); else __syncthreads();
     static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         to_patch(ic);
@@ -457,7 +481,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
         for (int it = 0; it < NIT; ++it) {
             const int rl = it * RPI + pr;
             const int m = m0 + wm0 + i * 32 + rl;
-            const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + pc);
+            const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + (SWZ ? (((pc >> 2) ^ (rl & 15)) << 2) : pc));
             if (m >= p.m || !n_in) continue;
             float v[4] = {a4[0], a4[1], a4[2], a4[3]};
             if (p.atomic) {

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     constexpr int NH0 = NA0 + NB0, NH1 = CPA + CPB - NH0;      // loads a wave issues per half
     constexpr int STAGE = (BM + BN) * 128;            // one K tile: A [256][64] | B [256][64] (or their k-major images)
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) float bias_lds[BN];     // this tile's bias slice (see gemm_epilogue lds_bias)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,7 +101,16 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         const int k = ((blockIdx.x >> 3) % (p.stagger & 255)) * (p.stagger >> 8);
         for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    // phase timestamps (100 MHz constant clock) of the first 8 tiles of every workgroup: 0 tile start, 1 first operand tile
+    // landed, 2 K loop done, 3 epilogue returned (wave 0: its stores are issued), 4 behind the tile's last barrier
+#define DW_TRACE(slot)                                                                                             \
+    do {                                                                                                           \
+        if (p.trace && tid == 0 && jobs.iter < 8)                                                                  \
+            p.trace[((long)blockIdx.x * 8 + jobs.iter) * 8 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    bool prefetched = false;     // this tile's first operand tile was requested before the previous tile's epilogue
     while (jobs.cur < jobs.cnt) {
+        DW_TRACE(0);
         gemm_jobs_prefetch(p, jobs, job_slot);
         int tm, tn, ks;
         gemm_job_decode(p, jobs.start + jobs.cur, tm, tn, ks);
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
 
         // load j of half h (NH0 / NH1 loads per wave) of the K tile at (kA, kB) into LDS buffer `buf`: A and B pieces
         // alternate (A first) until one operand's share of the half is used up
-        auto dma1 = [&](auto hc, auto jc, int buf) __attribute__((always_inline)) {
+        // (the descriptors travel as arguments, not as captures: with rsA / rsB captured by reference the 320-row kernel's
+        // register allocation degrades -- 600 spilled SGPRs, 80 spilled VGPRs against 290 / 25)
+        auto dma1x = [&](const i32x4_t& ra, const i32x4_t& rb, auto hc, auto jc, int buf) __attribute__((always_inline)) {
             constexpr int h = decltype(hc)::value, j = decltype(jc)::value;
             constexpr int na = h ? CPA - NA0 : NA0, nb = h ? CPB - NB0 : NB0, nmin = na < nb ? na : nb;
             constexpr bool isA = j < 2 * nmin ? (j & 1) == 0 : na > nb;
@@ -195,8 +207,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             const char* tA = smem + ((DBG & 2) ? (buf & 1) : buf) * STAGE + wave * 1024 + i * (NW * 1024);
             if constexpr ((DBG & 2) != 0) { if (buf < 8) return; }                  // ablation: no operand DMA in the loop
             if constexpr (ASMDMA) {
-                if constexpr (isA) wp_dma16(rsA, tA, offA[UNI ? 0 : i], UNI ? kA + i * pieceA : kA);
-                else wp_dma16(rsB, tA + BM * 128, offB[UNI ? 0 : i], UNI ? kB + i * pieceB : kB);
+                if constexpr (isA) wp_dma16(ra, tA, offA[UNI ? 0 : i], UNI ? kA + i * pieceA : kA);
+                else wp_dma16(rb, tA + BM * 128, offB[UNI ? 0 : i], UNI ? kB + i * pieceB : kB);
             } else {
                 const auto bA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);
                 const auto bB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, 0x7fffffff, 0x00020000);
@@ -206,6 +218,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(bB, (lds_void_t*)(tA + BM * 128), 16, offB[i], kB, 0, 0);
             }
         };
+        auto dma1 = [&](auto hc, auto jc, int buf) __attribute__((always_inline)) { dma1x(rsA, rsB, hc, jc, buf); };
         auto dma = [&](auto hc, int buf) __attribute__((always_inline)) {
             static_for<0, (decltype(hc)::value ? NH1 : NH0)>([&](auto jc) __attribute__((always_inline)) { dma1(hc, jc, buf); });
         };
@@ -271,7 +284,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         (void)sizeof(I8);
 
         // ---- prologue: tile 0 whole, first half of tile 1, fragments of (0, 0) ----
-        dma(I0{}, (DBG & 2) ? 8 : 0); dma(I1{}, (DBG & 2) ? 8 : 0);
+        const bool tile_in = m0 + BM <= p.m && n0 + BN <= p.n;
+        if (p.bias && tile_in && wave == 0) glds16(p.bias + n0 + lane * 4, bias_lds);   // (issued first: lands with tile 0)
+        if (!prefetched) { dma(I0{}, (DBG & 2) ? 8 : 0); dma(I1{}, (DBG & 2) ? 8 : 0); }
         kA += stepA; kB += stepB;
         if (nt > 1) dma(I0{}, (DBG & 2) ? 9 : 1);
         if (nt > 1) {      // tile 0 has landed when only the NH0 loads of tile 1's first half are outstanding
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             else { static_assert(NH0 == 4 || NH0 == 8 || NH0 == 5, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         } else wait_vm0();
         __syncthreads();
+        DW_TRACE(1);
         frags(I0{}, I0{}, (DBG & 1) ? 8 : 0);
         if constexpr ((DBG & 1) != 0) frags(I1{}, I1{}, 8);
         __builtin_amdgcn_sched_barrier(0);
@@ -319,7 +335,36 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         if (nt >= 2) { body(std::true_type{}, std::false_type{}, t); ++t; }
         body(std::false_type{}, std::false_type{}, t);
 
-        if (!(p.stage_next & 16)) gemm_epilogue<FM, FN, TN, (BM == 256 ? 8 : EPF)>(p, acc, smem, wave, lane, m0, wm0, n0, wn0, ks);
+        DW_TRACE(2);
+        // ---- optional (dw_debug_set key 11 bit 128, OFF by default): the NEXT tile's first operand tile, requested before
+        // this tile's epilogue.  The epilogue's LDS patches live in operand buffer 1 only (swizzled, unpadded: 8 waves x
+        // 8 KiB), so the next job's tile 0 can stream into buffer 0 while this tile's results are transposed and stored;
+        // safe without a barrier when the K loop had an even number of tiles (its last tile sat in buffer 1; every wave
+        // left buffer 0 behind the barrier inside the last-but-one tile) and both tiles are interior (same per-lane DMA
+        // offsets, only the descriptors change).  Measured (profiles/r3_gemm_epilogue.md): the prologue wait shrinks from
+        // 2.7 to 1.2 us and the epilogue grows by as much -- vmcnt retires in order and counts stores, so whichever wait
+        // comes first after the epilogue's 32 stores sits out their acknowledgement; operand latency was never what the
+        // prologue waited for.  Hence off.
+        prefetched = false;
+        if constexpr (ASMDMA && DBG == 0 && TN == 64) {
+            const int nxt = jobs.dynamic ? job_slot[(jobs.iter + 1) & 1] : jobs.cur + jobs.step;
+            if ((p.stage_next & 128) && (nt & 1) == 0 && nt >= 2 && nxt < jobs.cnt && tile_in && !p.zgrad && !p.r) {
+                int tm2, tn2, ks2;
+                gemm_job_decode(p, jobs.start + nxt, tm2, tn2, ks2);
+                if ((tm2 + 1) * BM <= p.m && (tn2 + 1) * BN <= p.n) {
+                    const int ntall = p.k >> 6, base2 = ntall / p.split_k, rem2 = ntall - base2 * p.split_k;
+                    const long first2 = (long)ks2 * base2 + (ks2 < rem2 ? ks2 : rem2);
+                    const char* a2 = (const char*)(TA ? p.a + tm2 * BM : p.a + (long)tm2 * BM * p.lda) + first2 * stepA;
+                    const char* b2 = (const char*)(TB ? p.b + tn2 * BN : p.b + (long)tn2 * BN * p.ldb) + first2 * stepB;
+                    const i32x4_t ra2 = wp_rsrc(a2), rb2 = wp_rsrc(b2);
+                    kA = 0; kB = 0;
+                    static_for<0, NH0>([&](auto jc) __attribute__((always_inline)) { dma1x(ra2, rb2, I0{}, jc, 0); });
+                    static_for<0, NH1>([&](auto jc) __attribute__((always_inline)) { dma1x(ra2, rb2, I1{}, jc, 0); });
+                    prefetched = true;
+                }
+            }
+        }
+        if (!(p.stage_next & 16)) gemm_epilogue<FM, FN, TN, (BM == 256 ? 8 : EPF), GemmNoHook, TN == 64>(p, acc, smem + (TN == 64 ? STAGE : 0), wave, lane, m0, wm0, n0, wn0, ks, GemmNoHook(), tile_in ? bias_lds : nullptr);
         else { float t = 0.f;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -328,7 +373,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
 #pragma unroll
                     for (int r = 0; r < 16; ++r) t += acc[i][j][r];
             if (t == 123.456f) *(float*)p.c = t; }
-        __syncthreads();   // the LDS patches are reused as operand buffers by the next job
+        DW_TRACE(3);
+        gemm_lds_barrier();   // the LDS patches are reused as operand buffers by the next job (no vmcnt wait: the stores and
+                              // the next tile's operand DMA stay in flight)
+        DW_TRACE(4);
         gemm_jobs_advance(jobs, job_slot);
     }
     gemm_jobs_end(p, jobs);
