@@ -147,6 +147,8 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     p.slice_stride = 0;
     p.sched = nullptr;
     p.zg_f16 = g->z_is_gelu_grad ? 1 : 0;
+    p.colsum = g->colsum_out;
+    if (g->colsum_out && (g->split_k > 1 || g->atomic_acc || ((uintptr_t)g->colsum_out & 3))) return DW_EINVAL;
     p.stage_next = g_gemm_stage_next;
     p.stagger = g_gemm_stagger;
     p.trace = (long long*)(((unsigned long long)g_gemm_trace_hi << 32) | g_gemm_trace_lo);
@@ -184,7 +186,10 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // decode regime (M = batch rows): weight-streaming kernel; tile = 16 requests it explicitly
     if (tile == 16 && !dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return DW_EINVAL;
-    if ((tile == 0 || tile == 16) && dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) return dw_gemm_skinny_launch(p, s);
+    if ((tile == 0 || tile == 16) && dw_gemm_skinny_ok(p, g->trans_a, g->trans_b)) {
+        if (g->colsum_out) return DW_EINVAL;      // (column sums are a tile-kernel epilogue)
+        return dw_gemm_skinny_launch(p, s);
+    }
     if (fused) return DW_EINVAL;                  // the fusions exist in the skinny-M kernel only
     bool one_round_320 = false;
     if (tile != 128 && tile != 256) {

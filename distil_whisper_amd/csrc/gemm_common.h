@@ -33,6 +33,7 @@ struct GemmP {
     int zg_f16;            // z_out / zgrad hold gelu'(z) in fp16 instead of z in bf16 (see DwGemm.z_is_gelu_grad)
     int* sched;            // persistent kernels: 9 device counters of this stream (dynamic job hand-out), or null
     int stagger;           // debug key 12: start offsets of the persistent workgroups (gemm_wp.h), 0 = none
+    float* colsum;         // f32 [n] += column sums of the stored C (DwGemm.colsum_out), or null
     long long* trace;      // debug keys 13 / 14 (low / high half of a device pointer): per-workgroup phase timestamps of
                            // the first 8 tiles (gemm_wp.h DW_TRACE; tools/gemm_phase_trace.py), null = off
 };
@@ -194,18 +195,19 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const char* tile, int x, int kk, i
 // 64 KiB instruction cache two CUs share, re-fetched from L2 every tile.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 enum { EPI_BIAS = 1, EPI_ZBF16 = 2, EPI_GELU = 4, EPI_STOREG = 8, EPI_ZG16 = 16, EPI_ZGBF = 32, EPI_RES = 64, EPI_RES_F32 = 128,
-       EPI_ROUND = 256, EPI_OUT_F32 = 512 };
+       EPI_ROUND = 256, EPI_OUT_F32 = 512, EPI_COLSUM = 1024 };
 __device__ __forceinline__ int gemm_epi_flavour(const GemmP& p) {
     return (p.bias ? EPI_BIAS : 0) | ((p.z_out && !p.zg_f16) ? EPI_ZBF16 : 0) | (p.act == 1 ? EPI_GELU : 0) |
            ((p.z_out && p.zg_f16) ? EPI_STOREG : 0) | ((p.zgrad && p.zg_f16) ? EPI_ZG16 : 0) |
            ((p.zgrad && !p.zg_f16) ? EPI_ZGBF : 0) | (p.r ? EPI_RES : 0) | ((p.r && p.r_dtype == DW_F32) ? EPI_RES_F32 : 0) |
-           ((p.r && p.round_res) ? EPI_ROUND : 0) | (p.c_dtype == DW_F32 ? EPI_OUT_F32 : 0);
+           ((p.r && p.round_res) ? EPI_ROUND : 0) | (p.c_dtype == DW_F32 ? EPI_OUT_F32 : 0) | (p.colsum ? EPI_COLSUM : 0);
 }
 template <int F = -1>
 __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], const f32x4& b4, bool plain, bool have_side,
-                                              const bf16x4& zs, const f32x4& rs, char* cdst, char* zdst) {
+                                              const bf16x4& zs, const f32x4& rs, char* cdst, char* zdst, float (&cs)[4]) {
     constexpr bool RT = F < 0;
-    const bool any = RT ? !plain : (F & ~EPI_OUT_F32) != 0;
+    const bool any = RT ? !plain : (F & ~(EPI_OUT_F32 | EPI_COLSUM)) != 0;
+    const bool colsum = RT ? p.colsum != nullptr : bool(F & EPI_COLSUM);
     if (any) {
         if (RT || (F & EPI_BIAS)) {
 #pragma unroll
@@ -267,11 +269,35 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[e];
         *(f32x4*)cdst = o;
+        if (colsum) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[e] += v[e];
+        }
     } else {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
         *(bf16x4*)cdst = o;
+        if (colsum) {                              // (the values as stored: what a column sum over C would read)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[e] += bf2f(o[e]);
+        }
+    }
+}
+
+// The lanes of a wave that own the same 4 columns in the row-major walks (lane % LPR equal) combine their partial column
+// sums; one of them adds the result to DwGemm.colsum_out.
+template <int LPR>
+__device__ __forceinline__ void gemm_colsum_flush(const GemmP& p, float (&cs)[4], int lane, int n) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) cs[e] += __shfl_xor(cs[e], o);
+    }
+    if (lane < LPR) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (n + e < p.n) atomicAdd(p.colsum + n + e, cs[e]);
     }
 }
 
@@ -385,6 +411,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
         const unsigned l_r = (unsigned)((pr * (int)p.ldr + pc) * es_r);
         bf16x4 zq[PFD];
         f32x4 rq[PFD];                             // fp32 residual: 4 values; bf16 residual: raw bits in [0], [1]
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};        // this lane's 4 columns summed over the wave tile's rows (EPI_COLSUM)
         // One copy of the slab walk per epilogue flavour (F >= 0: compile-time; -1: run-time tests, everything else).
         // (run-time form: F = -1 with side inputs, F = -2 without -- two copies, so that the copy without them does not
         // carry the prefetch registers through the GELU arithmetic)
@@ -429,9 +456,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                         if constexpr (gi + PFD < FM * NIT) side_load(std::integral_constant<int, gi + PFD>{});
                     }
                     float v[4] = {a4[0], a4[1], a4[2], a4[3]};
-                    gemm_epi_vec4<(F < 0 ? -1 : F)>(p, v, b4, plain, side, zs, rs, c_u + rg * p.ldc * esc + l_c, z_u + rg * p.ldz * 2 + l_z);
+                    gemm_epi_vec4<(F < 0 ? -1 : F)>(p, v, b4, plain, side, zs, rs, c_u + rg * p.ldc * esc + l_c, z_u + rg * p.ldz * 2 + l_z, cs);
                 });
             });
+            if (RT ? p.colsum != nullptr : (F & EPI_COLSUM) != 0) gemm_colsum_flush<LPR>(p, cs, lane, n);
         };
 #define DW_EPI_CASE(F) case (F): walk(std::integral_constant<int, (F)>{}); return
         if constexpr (FM == 4 || FM == 2) {
@@ -445,6 +473,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);      // student out-proj / fc2
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROUND);                                  // teacher out-proj / fc2
                 DW_EPI_CASE(EPI_ZG16);                                                        // dX of fc2 (x gelu'(z))
+                DW_EPI_CASE(EPI_ZG16 | EPI_COLSUM);                                           // ... + fc1.bias gradient
                 DW_EPI_CASE(EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);                 // d(encoder output) accumulation
                 DW_EPI_CASE(EPI_OUT_F32);                                                     // fp32 partial slabs of the dW GEMMs
                 default: break;
@@ -474,6 +503,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     // ---- general walk (ragged tile edges, unaligned pointers, atomic accumulation): looped, loads at use ----
     hook();
     if constexpr (SWZ) gemm_lds_barrier(); else __syncthreads();
+    float gcs[4] = {0.f, 0.f, 0.f, 0.f};
     static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         to_patch(ic);
@@ -504,7 +534,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                 }
                 gemm_epi_vec4(p, v, b4, plain, true, zs, rs,
                               p.c_dtype == DW_F32 ? (char*)(cf + (long)m * p.ldc + n) : (char*)((bf16*)p.c + (long)m * p.ldc + n),
-                              (char*)(p.z_out + (long)m * p.ldz + n));
+                              (char*)(p.z_out + (long)m * p.ldz + n), gcs);
             } else {
                 // ragged / unaligned columns: scalar path
 #pragma unroll 1
@@ -529,9 +559,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                         }
                     }
                     if (p.c_dtype == DW_F32) cf[(long)m * p.ldc + nn] = x;
-                    else ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x);
+                    else { ((bf16*)p.c)[(long)m * p.ldc + nn] = f2bf(x); x = round_bf16(x); }
+                    if (p.colsum) {                  // (compile-time indices: a run-time index would demote gcs to scratch)
+                        if (e == 0) gcs[0] += x; else if (e == 1) gcs[1] += x; else if (e == 2) gcs[2] += x; else gcs[3] += x;
+                    }
                 }
             }
         }
     });
+    if (p.colsum) gemm_colsum_flush<LPR>(p, gcs, lane, n);
 }

@@ -475,6 +475,7 @@ class WhisperEngine:
     # the FFN's saved by-product is gelu'(z) in fp16 (the backward epilogue multiplies) instead of z in bf16 (it
     # evaluates erf/exp again): same bytes, no transcendentals in the dX GEMM of fc2
     ffn_keeps_gelu_grad = True
+    fuse_fc1_bias_grad = True   # fc1.bias gradient from the epilogue of the dX GEMM of fc2 (DwGemm.colsum_out)
     use_c_decode = True     # HIP path: one library call per decoder pass instead of ~30 per-kernel calls
 
     def _decode_desc(self, cache, n):
@@ -635,10 +636,13 @@ class WhisperEngine:
         cross = "x1" in lc
         # --- feed forward
         dz = self.act(R, d.ffn)
-        ops.gemm(dy[:R], st.s[f"{p}.fc2.weight"], trans_b=True, zgrad=lc["z"], out=dz[:R])
+        # (fc1.bias gradient = column sums of dz: accumulated by this GEMM's epilogue, no separate pass over dz)
+        fuse_cs = tr and self.fuse_fc1_bias_grad and R > 64
+        ops.gemm(dy[:R], st.s[f"{p}.fc2.weight"], trans_b=True, zgrad=lc["z"], out=dz[:R],
+                 colsum=st.g[f"{p}.fc1.bias"] if fuse_cs else None)
         if tr:
             self._wgrad(dy, lc["a"], st.g[f"{p}.fc2.weight"], None, R)
-            self._wgrad(dz, lc["h2"], st.g[f"{p}.fc1.weight"], st.g[f"{p}.fc1.bias"], R)
+            self._wgrad(dz, lc["h2"], st.g[f"{p}.fc1.weight"], None if fuse_cs else st.g[f"{p}.fc1.bias"], R)
         dh = ops.gemm(dz[:R], st.s[f"{p}.fc1.weight"], trans_b=True)
         nb = f"{p}.encoder_attn.out_proj.bias" if cross else f"{p}.self_attn.out_proj.bias"
         dres, dy = self._ln_bwd(f"{p}.final_layer_norm", dh, lc["x2"], lc["mu2"], lc["rs2"], dres, R, emit=True,

@@ -31,7 +31,7 @@ class DwGemm(C.Structure):
         ("ld_lnx", C.c_int64), ("kv_ld", C.c_int64),
         ("ln_x_dtype", C.c_int32), ("kv_split", C.c_int32), ("kv_rows_per_batch", C.c_int32),
         ("kv_batch_pitch", C.c_int32), ("kv_row0", C.c_int32), ("ln_eps", C.c_float),
-        ("z_is_gelu_grad", C.c_int32),
+        ("z_is_gelu_grad", C.c_int32), ("colsum_out", C.c_void_p),
     ]
 
 
@@ -205,7 +205,7 @@ class HipOps:
 
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
              r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
-             kv_append=None):
+             kv_append=None, colsum=None):
         """C = op(a) @ op(b) with the fused epilogue of dw_gemm_bf16.  a: [M,K] (or [K,M] if trans_a);
         b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1.
         atomic_acc: out (fp32) += result via float atomics, with the K range split over several workgroups when the
@@ -290,6 +290,9 @@ class HipOps:
             assert not (want_z and (zgrad.dtype == torch.float16) != (want_z == "grad"))
             g.zgrad_in, g.ldzg = zgrad.data_ptr(), zgrad.stride(0)
             g.z_is_gelu_grad = int(zgrad.dtype == torch.float16)
+        if colsum is not None:      # f32 [N] += column sums of the stored output (bias gradient of the producing Linear)
+            assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous() and not atomic_acc and M > 64
+            g.colsum_out = colsum.data_ptr()
         if residual is not None:
             assert residual.stride(1) == 1 and residual.shape[1] == N
             g.r, g.ldr, g.r_dtype = residual.data_ptr(), residual.stride(0), _dt(residual)

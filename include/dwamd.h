@@ -94,6 +94,9 @@ typedef struct DwGemm {
     int32_t z_is_gelu_grad;  /* 1: z_out (with act = 1) receives gelu'(z) in fp16 instead of z in bf16, and zgrad_in is read as
                                 such: the backward epilogue multiplies by the stored derivative instead of evaluating it
                                 (same bytes; the derivative is rounded to 11 bits where the reference keeps fp32) */
+    float* colsum_out;       /* f32 [N] or NULL: the column sums of the stored C (as rounded to its dtype) are ADDED to it with
+                                float atomics -- the bias gradient of the Linear whose output gradient this GEMM produces
+                                (dX of fc2 -> fc1.bias), without a separate pass over C.  Tile kernels only, no K slices. */
 } DwGemm;
 int dw_gemm_bf16(const DwGemm* g, void* stream);
 /* out[i] (+)= sum over slices of part[s*stride + i]; n, stride multiples of 4 (split-K combination, deterministic). */

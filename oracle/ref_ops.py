@@ -57,7 +57,7 @@ class RefOps:
     # nn.Linear under bf16 autocast: bf16 operands, fp32 accumulation (TF:modeling_whisper.py:279-282 etc.)
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
              r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
-             kv_append=None):
+             kv_append=None, colsum=None):
         out_dtype = self.lowp if out_dtype is None else out_dtype
         if ln is not None:                     # operand = bf16(LayerNorm(a)) (decode-step fusion of the HIP kernel)
             a = self.layernorm_fwd(a, ln[0], ln[1], ln[2] if len(ln) > 2 else 1e-5, save_stats=False)[0]
@@ -87,6 +87,8 @@ class RefOps:
                 r = r[idx]
             v = (self._bf(v).float() if round_res else v) + r
         v = v.to(out_dtype)
+        if colsum is not None:                 # bias gradient of the producing Linear: column sums of the stored values
+            colsum += v.float().sum(0)
         if kv_append is not None:              # columns >= split go to the K/V cache rows of their positions
             cache, split, rpb, pitch, row0 = kv_append
             m = torch.arange(v.shape[0], device=v.device)

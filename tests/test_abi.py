@@ -31,8 +31,8 @@ def test_binding_covers_header_and_struct_layout():
     from distil_whisper_amd import ops_hip
     assert set(declared()) == set(ops_hip.EXPORTED_SYMBOLS)
     # DwGemm: 7 pointers, 6 int64, 13 int32 (padded to 8), 1 int64; decode fusions: 4 pointers, 2 int64, 5 int32 + float;
-    # z_is_gelu_grad int32 (+4 padding)
-    assert ctypes.sizeof(ops_hip.DwGemm) == 7 * 8 + 6 * 8 + 14 * 4 + 8 + 4 * 8 + 2 * 8 + 6 * 4 + 8
+    # z_is_gelu_grad int32 (+4 padding); colsum_out pointer
+    assert ctypes.sizeof(ops_hip.DwGemm) == 7 * 8 + 6 * 8 + 14 * 4 + 8 + 4 * 8 + 2 * 8 + 6 * 4 + 8 + 8
 
 
 def test_invalid_arguments_are_rejected_without_touching_the_gpu():

@@ -548,6 +548,26 @@ def test_small_streaming(ops, ref):
     assert torch.equal(y, (x + x.bfloat16().float()).bfloat16())
 
 
+@pytest.mark.parametrize("M", [1024, 520, 2000])
+def test_gemm_column_sums_of_the_output_in_the_epilogue(ops, ref, M):
+    """DwGemm.colsum_out: the dX GEMM of fc2 (k-major B, x gelu'(z) epilogue) also ADDS the column sums of its bf16
+    output to the fc1.bias gradient -- interior tiles through the flavoured walk, ragged last row tile through the
+    general one; also with the plain bf16 and the fp32-output epilogues and on the 128-tile kernel."""
+    N, K = 768, 256
+    dy = rnd((M, K), 1.0, torch.bfloat16, seed=61)
+    w = rnd((K, N), 0.05, torch.bfloat16, seed=62)
+    g = rnd((M, N), 0.5, torch.float16, seed=63)
+    for kw in (dict(zgrad=g), dict(), dict(out_dtype=torch.float32)):
+        for tile in (256, 128):
+            acc = torch.full((N,), 0.25, device="cuda")
+            out = ops.gemm(dy, w, trans_b=True, colsum=acc, tile=tile, **kw)
+            want = 0.25 + out.float().sum(0)
+            assert relerr(acc, want) < 2e-5, (kw.keys(), tile)
+            r_acc = torch.zeros(N, device="cuda")
+            r_out = ref.gemm(dy, w, trans_b=True, colsum=r_acc, **kw)
+            assert relerr(out, r_out) < 1e-2 and relerr(acc - 0.25, r_acc) < 2e-2
+
+
 def test_adamw_and_clip(ops, ref):
     n = 1_000_003
     p = rnd((n,), 1.0, torch.float32, seed=90)

@@ -7,12 +7,12 @@ timeout 120 python tools/hipblaslt_probe.py > $O/hipblaslt.log 2>&1
 timeout 150 rocprofv3 --kernel-trace --stats -d $O/probe_prof -o p -- python tools/hipblaslt_probe.py > /dev/null 2>&1
 python tools/rocprof_summary.py $O/probe_prof/p_results.db $O/probe_kernels.md > /dev/null 2>&1
 rm -rf $O/probe_prof
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err
-timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-overlap > $O/bench_prof.log 2>&1
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err     # the driver's command
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-overlap --graph off --no-ab > $O/bench_prof.log 2>&1
 python tools/rocprof_summary.py $O/prof/bench_results.db $O/kernel_stats.md > /dev/null 2>&1
 rm -rf $O/prof
-timeout 90 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -o b -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_f.log 2>&1
-timeout 90 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_w -o b -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/pmc_w.log 2>&1
+timeout 90 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_f -o b -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --graph off --no-ab > $O/pmc_f.log 2>&1
+timeout 90 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_w -o b -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --graph off --no-ab > $O/pmc_w.log 2>&1
 python tools/pmc_traffic.py $O/pmc_f/b_results.db $O/pmc_w/b_results.db $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1
 rm -rf $O/pmc_f $O/pmc_w
 cat $O/hipblaslt.log; tail -3 $O/pmc_traffic.log; tail -c 600 $O/bench.json
