@@ -224,9 +224,14 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
             const long r256 = (((g->m + 255) / 256) * tn + g_gemm_cus - 1) / g_gemm_cus * 4;
             const long r320 = ((g->m / 320) * tn + g_gemm_cus - 1) / g_gemm_cus * 5;
             const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
+            // (round 3: with one epilogue walk per flavour the 320-row kernel also wins at N = K = 1280 -- out-proj with the
+            // fp32 residual 262 -> 227 us (it used to go to the 16-wave kernel), with the bf16 residual 216 -> 195, dX of
+            // out-proj 178 -> 165 -- so the K / N / epilogue conditions of round 2 are gone (bit 8192 restores them);
+            // the x gelu'(z) epilogue has no flavoured walk in the 320-row kernel and keeps the 256-row tile)
+            const bool r2rule = (v & 8192) != 0;
             if ((v & 4096) || one_round_320) use320 = true;
-            else if (!g->trans_b) use320 = r320 <= r256 && !epi_bound && (g->k >= 2560 || g->n >= 2560);
-            else use320 = r320 < r256 && g->k >= 2560;
+            else if (!g->trans_b) use320 = r320 <= r256 && (!r2rule || (!epi_bound && (g->k >= 2560 || g->n >= 2560)));
+            else use320 = r320 < r256 && (r2rule ? g->k >= 2560 : !g->zgrad_in);
         }
         auto launch256 = [&](const GemmP& q) -> int {
             if (use320) return g->trans_b ? dw_gemm_wp8_nt320_launch(q, s) : dw_gemm_wp8_nn320_launch(q, s);
