@@ -61,12 +61,15 @@ def main():
     ap.add_argument("--mode", default="full", choices=["full", "recipe"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="everything on the main stream: no teacher stream, no weight-gradient stream (default: both side streams)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="teacher forward and weight-gradient GEMMs on their own HIP streams (round 2's default; since the "
+                         "round-3 epilogue work the single-stream step is ~1 %% faster in the same-process A/B, `ab` below)")
+    ap.add_argument("--no-overlap", action="store_true", help="(default now) everything on the main stream")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
-                    help="weight-gradient GEMMs of the backward on the main stream (default: second stream)")
+                    help="with --overlap: weight-gradient GEMMs of the backward stay on the main stream")
     ap.add_argument("--no-pad-teacher-rows", action="store_true",
                     help="teacher decoder GEMMs over exactly B*T rows (default: padded to a multiple of 320 rows)")
-    ap.add_argument("--no-teacher-overlap", action="store_true", help="teacher forward on the main stream only")
+    ap.add_argument("--no-teacher-overlap", action="store_true", help="with --overlap: teacher forward stays on the main stream")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -106,8 +109,8 @@ def main():
     recipe = args.mode == "recipe"
     tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
-                             mel_filters=filt, overlap_teacher=not (args.no_overlap or args.no_teacher_overlap),
-                             overlap_wgrad=not (args.no_wgrad_overlap or args.no_overlap),
+                             mel_filters=filt, overlap_teacher=args.overlap and not (args.no_overlap or args.no_teacher_overlap),
+                             overlap_wgrad=args.overlap and not (args.no_wgrad_overlap or args.no_overlap),
                              pad_teacher_rows=not args.no_pad_teacher_rows)
     del t_sd, s_sd
     torch.cuda.empty_cache()

@@ -24,6 +24,8 @@ struct AttnP {
     long ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, Lq, Lk;
     long q_rows, kv_rows;  // rows between consecutive batches in memory (= Lq / Lk unless reading a padded KV cache)
+    float* dq_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dq (q_proj.bias gradient), or null
+    float* dv_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dv (v_proj.bias gradient), or null
     int coff;              // causal mask: key <= query + coff (0 = top-left aligned, Lk - Lq = bottom-right aligned)
     float scale;
 };
@@ -51,6 +53,19 @@ __device__ __forceinline__ void store_t(bf16* base, long ld, long row, bool ok, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = f2bf(a[g * 4 + e] * mul);
         *(bf16x4*)(base + row * ld + cb * 32 + g * 8 + hi * 4) = w;
+    }
+}
+
+// Column sums of a transposed 32x32 accumulator block as it is stored (bf16-rounded, rows that are not `ok` excluded),
+// added to colsum[cb*32 + ...]: the bias gradient of the projection whose output gradient the block is -- one pass of
+// lane exchanges at the end of the kernel instead of a separate kernel reading the whole dq / dv matrix again.
+__device__ __forceinline__ void colsum_t(float* colsum, bool ok, int cb, int hi, int ln, const f32x16& a, float mul) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = ok ? bf2f(f2bf(a[r] * mul)) : 0.f;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+        if (ln == 0) atomicAdd(colsum + cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, v);
     }
 }
 
@@ -426,6 +441,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
     bf16* DQ = p.dq + (long)b * p.Lq * p.lddq + h * 64;
     store_t(DQ, p.lddq, q, q_ok, 0, hi, acc[0], p.scale);
     store_t(DQ, p.lddq, q, q_ok, 1, hi, acc[1], p.scale);
+    if (p.dq_colsum) {
+        colsum_t(p.dq_colsum + ((long)b * p.H + h) * 64, q_ok, 0, hi, ln, acc[0], p.scale);
+        colsum_t(p.dq_colsum + ((long)b * p.H + h) * 64, q_ok, 1, hi, ln, acc[1], p.scale);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -542,6 +561,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
     store_t(DK, p.lddk, key, k_ok, 1, hi, ak[1], p.scale);
     store_t(DV, p.lddv, key, k_ok, 0, hi, av[0], 1.0f);
     store_t(DV, p.lddv, key, k_ok, 1, hi, av[1], 1.0f);
+    if (p.dv_colsum) {
+        colsum_t(p.dv_colsum + ((long)b * p.H + h) * 64, k_ok, 0, hi, ln, av[0], 1.0f);
+        colsum_t(p.dv_colsum + ((long)b * p.H + h) * 64, k_ok, 1, hi, ln, av[1], 1.0f);
+    }
 }
 
 // bit 0: dq kernel, bit 1: dkv kernel use the 32-bit-offset tile staging; bit 2: dkv kernel compiled for 3 waves per
@@ -598,10 +621,24 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     return DW_OK;
 }
 
+extern "C" int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                              const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk,
+                              int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                              int64_t lddk, int64_t lddv, int causal, float scale, float* dq_colsum, float* dv_colsum,
+                              void* stream);
 extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o,
                            const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
                            int64_t lddk, int64_t lddv, int causal, float scale, void* stream) {
+    return dw_attn_bwd_ex(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Lq, Lk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv,
+                          causal, scale, nullptr, nullptr, stream);
+}
+
+extern "C" int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                              const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk,
+                              int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                              int64_t lddk, int64_t lddv, int causal, float scale, float* dq_colsum, float* dv_colsum,
+                              void* stream) {
     DW_CLEAR_ERR();
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv) return DW_EINVAL;
     if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return DW_EINVAL;
@@ -619,6 +656,7 @@ extern "C" int dw_attn_bwd(const void* q, const void* k, const void* v, const vo
     p.d_o = (const bf16*)d_o; p.delta = delta; p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
+    p.dq_colsum = dq_colsum; p.dv_colsum = dv_colsum;
     hipStream_t s = (hipStream_t)stream;
     const long rows = (long)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((rows * 8 + 255) / 256), dim3(256), 0, s, p);

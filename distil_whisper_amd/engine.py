@@ -476,6 +476,10 @@ class WhisperEngine:
     # evaluates erf/exp again): same bytes, no transcendentals in the dX GEMM of fc2
     ffn_keeps_gelu_grad = True
     fuse_fc1_bias_grad = True   # fc1.bias gradient from the epilogue of the dX GEMM of fc2 (DwGemm.colsum_out)
+    # q_proj / v_proj bias gradients from the attention-backward kernels (dw_attn_bwd_ex): correct and tested, but OFF --
+    # 64 cross-lane reductions per wave at the end of every attention-backward workgroup cost more (+4 ms per step) than
+    # the two column-sum launches per layer they replace (profiles/r3_gemm_epilogue.md section 5)
+    fuse_attn_bias_grad = False
     use_c_decode = True     # HIP path: one library call per decoder pass instead of ~30 per-kernel calls
 
     def _decode_desc(self, cache, n):
@@ -655,12 +659,14 @@ class WhisperEngine:
             do = ops.gemm(dy[:R], cv["wo"], trans_b=True)
             dq = self.act(R, D)
             dkv = self.act(Re, 2 * D)
+            fb = tr and self.fuse_attn_bias_grad      # q / v bias gradients from the attention-backward kernels
             ops.attn_bwd(lc["q1"][:R], lc["kv1"][:Re, :D], lc["kv1"][:Re, D:], lc["o1"][:R], do, lc["lse1"], B, H, L,
-                         Lk, False, 0.125, dq=dq[:R], dk=dkv[:Re, :D], dv=dkv[:Re, D:])
+                         Lk, False, 0.125, dq=dq[:R], dk=dkv[:Re, :D], dv=dkv[:Re, D:],
+                         dq_colsum=cv["g_bqkv"][:D] if fb else None, dv_colsum=cv["g_bqkv"][2 * D:] if fb else None)
             if tr:
                 self._wgrad(dy, lc["o1"], cv["g_wo"], None, R)
-                self._wgrad(dq, lc["h1"], cv["g_wqkv"][:D], cv["g_bqkv"][:D], R)
-                self._wgrad(dkv, lc["enc_out"], cv["g_wqkv"][D:], cv["g_bqkv"][D:], Re, bias_cols=[(D, 2 * D)])
+                self._wgrad(dq, lc["h1"], cv["g_wqkv"][:D], None if fb else cv["g_bqkv"][:D], R)
+                self._wgrad(dkv, lc["enc_out"], cv["g_wqkv"][D:], None if fb else cv["g_bqkv"][D:], Re, bias_cols=[(D, 2 * D)])
             if denc is not None:
                 ops.gemm(dkv[:Re], cv["wqkv"][D:], trans_b=True, residual=denc, round_res=True,
                          out_dtype=torch.float32, out=denc)
@@ -673,11 +679,13 @@ class WhisperEngine:
         do = ops.gemm(dy[:R], av["wo"], trans_b=True)
         dqkv = self.act(R, 3 * D)
         qkv = lc["qkv"]
+        fb = tr and self.fuse_attn_bias_grad
         ops.attn_bwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], lc["o0"][:R], do, lc["lse0"], B, H, L, L, causal,
-                     0.125, dq=dqkv[:R, :D], dk=dqkv[:R, D:2 * D], dv=dqkv[:R, 2 * D:])
+                     0.125, dq=dqkv[:R, :D], dk=dqkv[:R, D:2 * D], dv=dqkv[:R, 2 * D:],
+                     dq_colsum=av["g_bqkv"][:D] if fb else None, dv_colsum=av["g_bqkv"][2 * D:] if fb else None)
         if tr:
             self._wgrad(dy, lc["o0"], av["g_wo"], None, R)
-            self._wgrad(dqkv, lc["h0"], av["g_wqkv"], av["g_bqkv"], R, bias_cols=[(0, D), (2 * D, 3 * D)])
+            self._wgrad(dqkv, lc["h0"], av["g_wqkv"], None if fb else av["g_bqkv"], R, bias_cols=[(0, D), (2 * D, 3 * D)])
         dh = ops.gemm(dqkv[:R], av["wqkv"], trans_b=True)
         return self._ln_bwd(f"{p}.self_attn_layer_norm", dh, lc["x0"], lc["mu0"], lc["rs0"], dres, R, emit=emit_last,
                             colsum_to=colsum_last)

@@ -61,6 +61,7 @@ _SIGS = {
     "dw_attn_fwd": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_fwd_ex": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 6 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_bwd": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
+    "dw_attn_bwd_ex": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float] + [C.c_void_p] * 3, C.c_int),
     "dw_distill_loss": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float,
                          C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                          C.c_void_p], C.c_int),
@@ -362,7 +363,9 @@ class HipOps:
         self._t1(e0, "attn_fwd", 4.0 * B * H * Lq * Lk * 64)
         return o, lse
 
-    def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None):
+    def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None, dq_colsum=None,
+                 dv_colsum=None):
+        """dq_colsum / dv_colsum: f32 [H*64] += column sums of dq / dv (the q_proj / v_proj bias gradients)."""
         if dq is None:
             dq = self.empty((B * Lq, H * 64), torch.bfloat16)
         if dk is None:
@@ -373,10 +376,27 @@ class HipOps:
         for t in (q, k, v, o, do, dq, dk, dv):
             assert t.dtype == torch.bfloat16 and t.stride(1) == 1
         e0 = self._t0()
-        self._chk(self.lib.dw_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv),
-                                       B, H, Lq, Lk, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
-                                       dq.stride(0), dk.stride(0), dv.stride(0), int(causal), float(scale),
-                                       self._stream()), "attn_bwd")
+        for t in (dq_colsum, dv_colsum):
+            assert t is None or (t.dtype == torch.float32 and t.numel() == H * 64 and t.is_contiguous())
+        part = None
+        if dq_colsum is not None or dv_colsum is not None:
+            # per-batch-row partial sums [2][B][H*64] (zeroed here, filled by the kernels' atomics, added up below)
+            key = (B, H)
+            if not hasattr(self, "_attn_cs"):
+                self._attn_cs = {}
+            if key not in self._attn_cs:
+                self._attn_cs[key] = self.zeros((2, B, H * 64), torch.float32)
+            part = self._attn_cs[key]
+            part.zero_()
+        self._chk(self.lib.dw_attn_bwd_ex(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv),
+                                          B, H, Lq, Lk, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0),
+                                          dq.stride(0), dk.stride(0), dv.stride(0), int(causal), float(scale),
+                                          _p(part[0]) if dq_colsum is not None else None,
+                                          _p(part[1]) if dv_colsum is not None else None, self._stream()), "attn_bwd")
+        for i, dst in enumerate((dq_colsum, dv_colsum)):
+            if dst is not None:
+                self._chk(self.lib.dw_reduce_slices(_p(part[i]), H * 64, B, _p(dst), H * 64, 1, self._stream()),
+                          "reduce_slices")
         self._t1(e0, "attn_bwd", 10.0 * B * H * Lq * Lk * 64)
         return dq, dk, dv
 

@@ -134,6 +134,16 @@ int dw_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int causal,
                 float scale, void* stream);
+/* The same, plus (optional, may be NULL) the bias gradients of the projections that produced q and v: dq_colsum /
+ * dv_colsum f32 [B][H*64] receive (ADDED with float atomics) the PER-BATCH-ROW column sums of the dq / dv matrices as
+ * stored, from the kernels that write dq / dv instead of a separate pass over them; the caller adds the B partial rows
+ * (dw_reduce_slices) into q_proj.bias.grad / v_proj.bias.grad.  Per batch row because every 32-row wave tile of a
+ * (batch, head) adds to the same 64 addresses: one [H*64] target for the whole batch serialises 1 500 atomics per
+ * address and cost more than the pass it replaced.  (k_proj has no bias, TF:modeling_whisper.py:279.) */
+int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                   float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int64_t ldq, int64_t ldk,
+                   int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int causal,
+                   float scale, float* dq_colsum, float* dv_colsum, void* stream);
 
 /* ---- a7: fused CE + temperature-KL distillation loss (run_distillation.py:1453-1462, 1486-1493 and
  * TF:modeling_whisper.py:1083-1087).  s/t logits bf16 [rows][ld] (V valid columns), labels int64 [rows] (-100 =

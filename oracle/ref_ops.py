@@ -157,7 +157,8 @@ class RefOps:
             o = out
         return o, lse
 
-    def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None):
+    def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None, dq_colsum=None,
+                 dv_colsum=None):
         qh, kh, vh = self._heads(q, B, Lq, H), self._heads(k, B, Lk, H), self._heads(v, B, Lk, H)
         oh, doh = self._heads(o, B, Lq, H), self._heads(do, B, Lq, H)
         s = (qh @ kh.transpose(-1, -2)) * scale
@@ -182,6 +183,10 @@ class RefOps:
             dk.copy_(rk); rk = dk
         if dv is not None:
             dv.copy_(rv); rv = dv
+        if dq_colsum is not None:
+            dq_colsum += rq.float().sum(0)
+        if dv_colsum is not None:
+            dv_colsum += rv.float().sum(0)
         return rq, rk, rv
 
     # run_distillation.py:1453-1462, 1486-1493 + CrossEntropyLoss (TF:modeling_whisper.py:1083-1087), verbatim math

@@ -408,6 +408,12 @@ def test_attention_fwd_bwd(ops, ref, B, H, Lq, Lk, causal):
     assert relerr(dv, rdv) < 1.5e-2, relerr(dv, rdv)
     assert relerr(dq, rdq) < 1.5e-2, relerr(dq, rdq)
     assert relerr(dk, rdk) < 1.5e-2, relerr(dk, rdk)
+    # dw_attn_bwd_ex: the q / v bias gradients (column sums of the stored dq / dv) come out of the same kernels, ADDED to
+    # their buffers; the matrices themselves are unchanged by it
+    bq, bv = torch.full((D,), 0.5, device="cuda"), torch.full((D,), -0.25, device="cuda")
+    dq2, dk2, dv2 = ops.attn_bwd(q, k, v, ro, do, rlse, B, H, Lq, Lk, causal, 0.125, dq_colsum=bq, dv_colsum=bv)
+    assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
+    assert relerr(bq - 0.5, dq.float().sum(0)) < 1e-4 and relerr(bv + 0.25, dv.float().sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,pitch", [(2, 2, 6, 37, 48), (3, 1, 1, 9, 16), (1, 2, 70, 200, 200), (2, 1, 33, 33, 40),
