@@ -321,7 +321,9 @@ __device__ __forceinline__ void gemm_lds_barrier() {
 template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook, bool SWZ = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
                                               int m0_, int wm0_, int n0_, int wn0_, int ks_, Hook hook = Hook(),
-                                              const float* lds_bias = nullptr) {
+                                              const float* lds_bias = nullptr, long long* tslot = nullptr) {
+    // tslot (phase trace, tools/gemm_phase_trace.py; thread 0 only, or null): [5] behind the leading barrier, [6] first slab
+    // transposed and its stores issued
     // lds_bias: the tile's bias slice (BN floats from column n0) staged in LDS by the caller at the start of the tile
     // (interior tiles only).  A bias read from global memory here is an ordinary load whose vmcnt wait also drains every
     // operand DMA the caller has in flight for the NEXT tile (the counter retires in order).
@@ -440,8 +442,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             if constexpr (side) static_for<0, PFD>([&](auto gc) __attribute__((always_inline)) { side_load(gc); });
             hook();
             if constexpr (SWZ) gemm_lds_barrier(); else __syncthreads();   // every wave is done reading the operand tiles
+            if (tslot) tslot[5] = (long long)__builtin_amdgcn_s_memrealtime();
             static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
+                if (i == 1 && tslot) tslot[6] = (long long)__builtin_amdgcn_s_memrealtime();
                 to_patch(ic);
                 static_for<0, NIT>([&](auto itc) __attribute__((always_inline)) {
                     constexpr int it = decltype(itc)::value;

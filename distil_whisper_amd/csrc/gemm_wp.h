@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
                 }
             }
         }
-        if (!(p.stage_next & 16)) gemm_epilogue<FM, FN, TN, (BM == 256 ? 8 : EPF), GemmNoHook, TN == 64>(p, acc, smem + (TN == 64 ? STAGE : 0), wave, lane, m0, wm0, n0, wn0, ks, GemmNoHook(), tile_in ? bias_lds : nullptr);
+        if (!(p.stage_next & 16)) gemm_epilogue<FM, FN, TN, (BM == 256 ? 8 : EPF), GemmNoHook, TN == 64>(p, acc, smem + (TN == 64 ? STAGE : 0), wave, lane, m0, wm0, n0, wn0, ks, GemmNoHook(), tile_in ? bias_lds : nullptr,
+                                                           (p.trace && tid == 0 && jobs.iter < 8) ? p.trace + ((long)blockIdx.x * 8 + jobs.iter) * 8 : nullptr);
         else { float t = 0.f;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
