@@ -70,6 +70,12 @@ def main():
     ap.add_argument("--no-pad-teacher-rows", action="store_true",
                     help="teacher decoder GEMMs over exactly B*T rows (default: padded to a multiple of 320 rows)")
     ap.add_argument("--no-teacher-overlap", action="store_true", help="with --overlap: teacher forward stays on the main stream")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the gradient all-reduce: nccl = RCCL over xGMI (default); gloo "
+                         "(through the host) exists to exercise the N-rank path on a box with fewer GPUs")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device); a test of the "
+                         "launcher, the rank plumbing and the data-parallel step, not a measurement")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -85,6 +91,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.share_device:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py: --share-device needs --backend gloo")
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs cuda:{local_rank}, {torch.cuda.device_count()} device(s) visible")
     import torch.distributed as dist
@@ -92,7 +102,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -257,7 +270,7 @@ def main():
                "config": {"workload": f"whisper-{args.model} teacher ({tdims.enc_layers}/{tdims.dec_layers}) -> "
                                       f"{le}/{ld} student KD step, mode={args.mode}",
                           "global_batch": B * world, "per_gpu_batch": B, "clip_seconds": 30, "decoder_len": T,
-                          "parallelism": f"dp{world}", "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
+                          "parallelism": f"dp{world}" + (f" ({args.backend}, ranks share cuda:0: plumbing test)" if args.share_device else ""), "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
                           "bwd+allreduce+clip+adamw", "loss": loss_val},
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
                "flops_per_sample": fl, "step_mode": "hip_graph" if use_graph else "eager", "step_stats": step_stats,
@@ -272,7 +285,7 @@ def spawn_ranks(n):
     N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`)."""
     import socket
     import subprocess
-    if torch.cuda.device_count() < n:
+    if torch.cuda.device_count() < n and "--share-device" not in sys.argv:
         print(f"bench.py: --gpus {n} requested but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:

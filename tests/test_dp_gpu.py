@@ -91,3 +91,29 @@ def test_two_ranks_on_one_gpu_stay_identical_and_match_the_averaged_gradient_run
     a, b = tr.student_store.P.cpu(), r0["P"]
     rel = ((a - b).norm() / b.norm()).item()
     assert rel < 5e-6, rel
+
+
+@pytest.mark.timeout(900)
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher around it (how the driver calls it) starts two ranks under
+    torch.distributed.run, runs the data-parallel step and the replica check, and rank 0 prints ONE JSON line for the
+    whole job.  Both ranks share cuda:0 over gloo here (one GPU on the test box); the 8-GPU run differs in the backend
+    argument only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--model", "tiny.en", "--backend", "gloo", "--share-device", "--no-roofline",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["step_mode"] == "eager"
+    assert "replica check: parameters bit-identical on all ranks" in r.stderr
+    # and a request for more GPUs than the box has fails loudly instead of silently running one rank
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "1"],
+                        capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "GPU(s) are visible" in r2.stderr
