@@ -28,12 +28,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_kernel.h"), os.path.join(CSRC, "gemm_wp.h"),
                os.path.join(HERE, "..", "include", "dwamd.h")]
     objs, procs = [], []
+    flags = FLAGS + (["-DDW_ABLATE"] if os.environ.get("DW_ABLATE") else [])   # timing-experiment kernels (tools/attn_ablate.py)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

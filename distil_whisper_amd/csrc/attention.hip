@@ -26,6 +26,7 @@ struct AttnP {
     long q_rows, kv_rows;  // rows between consecutive batches in memory (= Lq / Lk unless reading a padded KV cache)
     float* dq_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dq (q_proj.bias gradient), or null
     float* dv_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dv (v_proj.bias gradient), or null
+    int plain_order;       // 1 = workgroups take (tile, head, batch) in launch order (A/B switch of attn_workgroup)
     int coff;              // causal mask: key <= query + coff (0 = top-left aligned, Lk - Lq = bottom-right aligned)
     float scale;
 };
@@ -69,17 +70,36 @@ __device__ __forceinline__ void colsum_t(float* colsum, bool ok, int cb, int hi,
     }
 }
 
+// Workgroup -> (tile of stationary rows, head, batch).  The dispatcher places workgroup L of a 1-D grid on XCD L % 8 and
+// every XCD has a private 4 MiB L2: each XCD gets a contiguous range of (batch, head) pairs with ALL their tiles, in
+// dispatch order, so the rows a pair streams (K/V, or Q/dO in the dK/dV pass) are fetched from the fabric into one L2
+// instead of into up to eight (a 3-D grid, tile index fastest, sprayed the 12 tiles of a pair over all XCDs: 3.6x the
+// algorithmic fetch bytes, profiles/r3_pmc_traffic.json).
+__device__ __forceinline__ void attn_workgroup(int ntile, int H, bool plain, int& tile, int& h, int& b) {
+    const int n = gridDim.x, L = blockIdx.x;
+    const int xcd = L & 7, slot = L >> 3, q = n >> 3, r = n & 7;
+    const int logical = plain ? L : xcd * q + min(xcd, r) + slot;   // (plain: dw_debug_set key 18, the A/B switch)
+    tile = logical % ntile;
+    const int bh = logical / ntile;
+    h = bh % H;
+    b = bh / H;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// forward: block = 4 waves x 32 queries; key/value tiles of 64 rows double-buffered in LDS
+// forward: block = NW waves x 32 queries; key/value tiles of 64 rows double-buffered in LDS
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL>
-__global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const AttnP p) {
+// ABL (builds with -DDW_ABLATE only, tools/attn_ablate.py): timing experiments that leave out one resource user each and
+// compute garbage -- 1 no exp, 2 / 4 K / V fragments from registers instead of LDS, 8 no operand staging inside the loop,
+// 16 no barrier, 32 / 64 without the QK / PV MFMAs.
+template <bool CAUSAL, int NW = 4, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const AttnP p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];  // [buf][K tile 8K | V tile 8K]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, ln = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int qb0 = blockIdx.x * 128;
+    int tile, h, b;
+    attn_workgroup((p.Lq + 32 * NW - 1) / (32 * NW), p.H, p.plain_order, tile, h, b);
+    const int qb0 = tile * (32 * NW);
     const int q = qb0 + wave * 32 + ln;          // this lane's query (column of S^T)
     const bool q_ok = q < p.Lq;
     const int qc = q_ok ? q : p.Lq - 1;
@@ -93,7 +113,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 
     int nkt = (p.Lk + 63) >> 6;
     if (CAUSAL) {
-        const int lim = ((min(qb0 + 127, p.Lq - 1) + p.coff) >> 6) + 1;
+        const int lim = ((min(qb0 + 32 * NW - 1, p.Lq - 1) + p.coff) >> 6) + 1;
         nkt = min(nkt, lim);
     }
     const float c = p.scale * 1.4426950408889634f;
@@ -102,15 +122,17 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
 
-    stage_tile64<4>(K, p.ldk, 0, p.Lk, smem, wave, lane);
-    stage_tile64<4>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
+    stage_tile64<NW>(K, p.ldk, 0, p.Lk, smem, wave, lane);
+    stage_tile64<NW>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        wait_vm0();
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            stage_tile64<4>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
-            stage_tile64<4>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
+        if (!(ABL & 16) || kt == 0) {
+            wait_vm0();
+            __syncthreads();
+        }
+        if (kt + 1 < nkt && !(ABL & 8)) {
+            stage_tile64<NW>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
+            stage_tile64<NW>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
         }
         const char* tK = smem + buf * 16384;
         const char* tV = tK + 8192;
@@ -118,10 +140,12 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[kb][r] = (ABL & 32) ? o[kb][r] : 0.f;
+            if (!(ABL & 32)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, kb, kk, lane), qf[kk], s[kb], 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ABL & 2) ? qf[kk ^ kb] : frag_rows(tK, kb, kk, lane), qf[kk], s[kb], 0, 0, 0);
+            }
         }
         // mask (key tail / causal diagonal) only on the tiles that need it -- a wave-uniform test
         const int wq0 = qb0 + wave * 32 + (CAUSAL ? p.coff : 0);   // last key the wave's first query may see
@@ -145,15 +169,24 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         const float mc = m_new * c;
-        float rs = 0.f;
+        // two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32): the softmax's vector
+        // instructions, not the matrix pipe, bound this loop at head_dim 64
+        f32x2 rs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        const f32x2 c2 = {c, c}, mc2 = {mc, mc};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c, -mc));
-                s[kb][r] = pv;
-                rs += pv;
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 t = {s[kb][r], s[kb][r + 1]};
+                t = t * c2 - mc2;
+                f32x2 pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                if (ABL & 1) pv = t;
+                s[kb][r] = pv[0];
+                s[kb][r + 1] = pv[1];
+                rs2[(r >> 1) & 1] += pv;
             }
+        rs2[0] += rs2[1];
+        float rs = rs2[0][0] + rs2[0][1];
         rs += __shfl_xor(rs, 32);
         if (__any(m_new != m_run)) {  // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
@@ -170,9 +203,13 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 4) void attn_fwd_kernel(const Att
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pf = pack8(s[kb], s2);
                 const int rb = kb * 32 + s2 * 16 + hi * 4;
+                if (ABL & 64) {
+                    o[kb][s2] += bf2f(pf[0]) + bf2f(pf[2]) + bf2f(pf[4]) + bf2f(pf[6]);
+                    continue;
+                }
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tV, db, rb, rb + 8, lane), pf, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((ABL & 4) ? qf[db * 2 + s2] : frag_tr(tV, db, rb, rb + 8, lane), pf, o[db], 0, 0, 0);
             }
     }
     const float inv = 1.0f / l_run;
@@ -361,14 +398,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
 // backward dQ: stationary = 32 queries per wave (Q, dO fragments + lse, delta in registers); stream K, V tiles
 //   S^T = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T[d][q] += K^T . dS^T
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL, bool FS>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
+template <bool CAUSAL, bool FS, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, ln = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int qb0 = blockIdx.x * 128;
+    int tile, h, b;
+    attn_workgroup((p.Lq + 32 * NW - 1) / (32 * NW), p.H, p.plain_order, tile, h, b);
+    const int qb0 = tile * (32 * NW);
     const int q = qb0 + wave * 32 + ln;
     const bool q_ok = q < p.Lq;
     const int qc = q_ok ? q : p.Lq - 1;
@@ -385,24 +423,26 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
     }
     const long sidx = ((long)b * p.H + h) * p.Lq + qc;
     const float c = p.scale * 1.4426950408889634f;
-    const float lse2 = p.lse[sidx] * 1.4426950408889634f;
-    const float dl = -p.delta[sidx];
+    // the S and dP accumulators start from -lse / scale and -delta of the lane's query (the tables the delta pre-pass
+    // writes for the dK/dV kernel), so P = exp2(c * S) and dS = P * dP are packed multiplies with nothing to subtract
+    const float s0 = p.delta[(long)p.B * p.H * p.Lq + sidx];
+    const float dp0 = p.delta[sidx];
 
     int nkt = (p.Lk + 63) >> 6;
-    if (CAUSAL) nkt = min(nkt, (min(qb0 + 127, p.Lq - 1) >> 6) + 1);
+    if (CAUSAL) nkt = min(nkt, (min(qb0 + 32 * NW - 1, p.Lq - 1) >> 6) + 1);
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 
-    stage_tile64<4, FS>(K, p.ldk, 0, p.Lk, smem, wave, lane);
-    stage_tile64<4, FS>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
+    stage_tile64<NW, FS>(K, p.ldk, 0, p.Lk, smem, wave, lane);
+    stage_tile64<NW, FS>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         wait_vm0();
         __syncthreads();
         if (kt + 1 < nkt) {
-            stage_tile64<4, FS>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
-            stage_tile64<4, FS>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
+            stage_tile64<NW, FS>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
+            stage_tile64<NW, FS>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
         }
         const char* tK = smem + buf * 16384;
         const char* tV = tK + 8192;
@@ -413,20 +453,29 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = s0; dp[r] = dp0; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, kb, kk, lane), qf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tV, kb, kk, lane), gf[kk], dp, 0, 0, 0);
             }
+            const f32x2 c2 = {c, c};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(fmaf(s[r], c, -lse2));
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 t = {s[r], s[r + 1]};
+                t = t * c2;
+                f32x2 pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
                 if (need_mask) {
-                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    pv = (key < p.Lk && (!CAUSAL || key <= q)) ? pv : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int key = kt * 64 + kb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hi;
+                        pv[e] = (key < p.Lk && (!CAUSAL || key <= q)) ? pv[e] : 0.f;
+                    }
                 }
-                s[r] = pv * (dp[r] - dl);  // dS^T
+                const f32x2 d2 = {dp[r], dp[r + 1]};
+                pv = pv * d2;  // dS^T = P^T * (dP^T - delta)
+                s[r] = pv[0];
+                s[r + 1] = pv[1];
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -452,16 +501,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP p) {
 //   S = Q.K^T, dP = dO.V^T  (rows = queries in registers, column = key = lane&31)
 //   dV^T[d][key] += dO^T . P,   dK^T[d][key] += Q^T . dS
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CAUSAL, bool FS, int OCC>
-__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
+template <bool CAUSAL, bool FS, int OCC, int NW = 4>
+__global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
     // [buf][Q tile 8K | dO tile 8K | lse 64 f32 | delta 64 f32]
     constexpr int STG = 16384 + 512;
     __shared__ __attribute__((aligned(1024))) char smem[2 * 17408];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, ln = lane & 31;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int kb0 = blockIdx.x * 128;
+    int tile, h, b;
+    attn_workgroup((p.Lk + 32 * NW - 1) / (32 * NW), p.H, p.plain_order, tile, h, b);
+    const int kb0 = tile * (32 * NW);
     const int key = kb0 + wave * 32 + ln;
     const bool k_ok = key < p.Lk;
     const int kc = k_ok ? key : p.Lk - 1;
@@ -488,8 +538,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
 
     auto stage = [&](int qt, int buf) {
         char* base = smem + buf * 17408;
-        stage_tile64<4, FS>(Q, p.ldq, qt * 64, p.Lq, base, wave, lane);
-        stage_tile64<4, FS>(DO, p.lddo, qt * 64, p.Lq, base + 8192, wave, lane);
+        stage_tile64<NW, FS>(Q, p.ldq, qt * 64, p.Lq, base, wave, lane);
+        stage_tile64<NW, FS>(DO, p.lddo, qt * 64, p.Lq, base + 8192, wave, lane);
         if (threadIdx.x < 128) {  // waves 0,1: 64 lse + 64 delta values through the same async path (4 B per lane)
             const int i = threadIdx.x & 63;
             int qi = qt * 64 + i;
@@ -532,15 +582,25 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tG, qb, kk, lane), vf[kk], dp, 0, 0, 0);
             }
             f32x16 pr;
+            const f32x2 c2 = {c, c};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(s[r] * c);           // P = exp(scale * S - lse)
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 t = {s[r], s[r + 1]};
+                t = t * c2;
+                f32x2 pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};   // P = exp(scale * S - lse)
                 if (need_mask) {
-                    const int qi = qt * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    pv = (qi < p.Lq && k_ok && (!CAUSAL || key <= qi)) ? pv : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int qi = qt * 64 + qb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hi;
+                        pv[e] = (qi < p.Lq && k_ok && (!CAUSAL || key <= qi)) ? pv[e] : 0.f;
+                    }
                 }
-                pr[r] = pv;
-                s[r] = pv * dp[r];                                     // dS = P * (dP - delta)
+                pr[r] = pv[0];
+                pr[r + 1] = pv[1];
+                const f32x2 d2 = {dp[r], dp[r + 1]};
+                pv = pv * d2;                                          // dS = P * (dP - delta)
+                s[r] = pv[0];
+                s[r + 1] = pv[1];
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -570,6 +630,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP p) {
 // bit 0: dq kernel, bit 1: dkv kernel use the 32-bit-offset tile staging; bit 2: dkv kernel compiled for 3 waves per
 // SIMD (168 registers; since the accumulators start from the -lse/-delta tables it spills 1-2 registers instead of 14)
 int g_attn_bwd_stage = 5;  // (dw_debug_set key 3; 5 measured best: 1.65 vs 1.75 ms per encoder-layer backward)
+int g_attn_bwd_waves = 4;  // dw_debug_set key 17: 4 / 12 waves per workgroup of the non-causal backward kernels (12: 384 stationary
+                           // rows per workgroup, a third of the tile staging -- measured neutral at the encoder shape, slower at 448 x 1500)
+int g_attn_fwd_waves = 4;  // dw_debug_set key 16: 4 / 8 waves (x 32 queries) per workgroup of the non-causal forward kernel (8: half
+                           // the K/V staging per query -- measured neutral: the kernel is not bound by the staging traffic)
+int g_attn_plain_order = 0; // dw_debug_set key 18
+int g_attn_ablate = 0;     // dw_debug_set key 15 (DW_ABLATE builds)
 int g_attn_decode = 1;     // dw_debug_set key 4: 1 = single-query attention runs the streaming decode kernel
 static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
 
@@ -614,8 +680,26 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
         DW_CHECK_LAUNCH();
         return DW_OK;
     }
-    dim3 grid((Lq + 127) / 128, H, B), block(256);
+    const int g4 = (Lq + 127) / 128;
+    dim3 grid(g4 * H * B), block(256);
+    p.plain_order = g_attn_plain_order;
+#ifdef DW_ABLATE
+    if (!causal && g_attn_ablate) {
+        switch (g_attn_ablate) {
+#define ABLC(v) case v: hipLaunchKernelGGL((attn_fwd_kernel<false, 4, v>), grid, block, 0, s, p); break;
+            ABLC(1) ABLC(2) ABLC(4) ABLC(6) ABLC(8) ABLC(24) ABLC(32) ABLC(64) ABLC(7) ABLC(31) ABLC(30)
+#undef ABLC
+            default: return DW_EINVAL;
+        }
+        return DW_OK;
+    }
+#endif
+    // 256 queries per workgroup (8 waves) where that pads no more than 128 would and still fills the chip: the K/V tiles
+    // are fetched and written to LDS once per 256 queries (1500 -> 1536 and 448 -> 512 either way)
+    const int g8 = (Lq + 255) / 256;
     if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, p);
+    else if (g_attn_fwd_waves == 8 && g8 * 2 == g4 && (long)g8 * H * B >= 512)
+        hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), dim3(g8 * H * B), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
@@ -661,16 +745,25 @@ extern "C" int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const
     const long rows = (long)B * H * Lq;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((rows * 8 + 255) / 256), dim3(256), 0, s, p);
     DW_CHECK_LAUNCH();
-    dim3 gq((Lq + 127) / 128, H, B), gk((Lk + 127) / 128, H, B), block(256);
+    const int q4 = (Lq + 127) / 128, k4 = (Lk + 127) / 128;
+    dim3 gq(q4 * H * B), gk(k4 * H * B), block(256);
+    p.plain_order = g_attn_plain_order;
     const int fs = g_attn_bwd_stage;
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, block, 0, s, p);
         if (fs & 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 3>), gk, block, 0, s, p);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 2>), gk, block, 0, s, p);
     } else {
-        if (fs & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, block, 0, s, p);
+        // 384 stationary rows (12 waves = the three waves per SIMD the registers allow, as ONE workgroup) where that pads
+        // no more than 128 would: the streamed tiles are fetched and written to LDS once per 384 rows (1500 -> 1536)
+        const int q12 = (Lq + 383) / 384, k12 = (Lk + 383) / 384;
+        const bool dq12 = g_attn_bwd_waves == 12 && q12 * 3 == q4 && (long)q12 * H * B >= 256;
+        const bool dkv12 = g_attn_bwd_waves == 12 && k12 * 3 == k4 && (long)k12 * H * B >= 256;
+        if (dq12) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true, 12>), dim3(q12 * H * B), dim3(768), 0, s, p);
+        else if (fs & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), gq, block, 0, s, p);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), gq, block, 0, s, p);
-        if ((fs & 6) == 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true, 3>), gk, block, 0, s, p);
+        if (dkv12) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 3, 12>), dim3(k12 * H * B), dim3(768), 0, s, p);
+        else if ((fs & 6) == 6) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true, 3>), gk, block, 0, s, p);
         else if (fs & 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 3>), gk, block, 0, s, p);
         else if (fs & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true, 2>), gk, block, 0, s, p);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, 2>), gk, block, 0, s, p);

@@ -35,6 +35,10 @@ int dw_gemm_wp8_tt_launch(const GemmP& p, hipStream_t s);
 
 extern int g_attn_bwd_stage;  // attention.hip
 extern int g_attn_decode;
+extern int g_attn_ablate;
+extern int g_attn_fwd_waves;
+extern int g_attn_plain_order;
+extern int g_attn_bwd_waves;
 extern int g_logmel_mfma;     // logmel.hip
 extern int g_decode_fuse_off; // decode.hip
 extern int g_skinny_wide;     // gemm_skinny.hip
@@ -93,6 +97,10 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 12) { g_gemm_stagger = value; return DW_OK; }
     if (key == 13) { g_gemm_trace_lo = (unsigned)value; return DW_OK; }
     if (key == 14) { g_gemm_trace_hi = (unsigned)value; return DW_OK; }
+    if (key == 17) { g_attn_bwd_waves = value; return DW_OK; }
+    if (key == 18) { g_attn_plain_order = value; return DW_OK; }
+    if (key == 16) { g_attn_fwd_waves = value; return DW_OK; }
+    if (key == 15) { g_attn_ablate = value; return DW_OK; }
     if (key == 9) { if (value < 8 || value > 256 || (value & 7)) return DW_EINVAL; g_gemm_cus = value; return DW_OK; }
     return DW_EINVAL;
 }

@@ -115,12 +115,12 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16* x, const
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <bool XBF, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void* x, const float* mean,
+template <bool XBF, int NV, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const void* x, const float* mean,
                                                      const float* rstd, const float* gamma, float* dres,
                                                      int accumulate, float* dgamma, float* dbeta, bf16* dres_lowp,
                                                      float* dres_colsum, int rows, int cols) {
-    __shared__ float red[3 * 4 * 512];  // [dgamma|dbeta|colsum][wave][512-column window]
+    __shared__ float red[3 * NW * 512];  // [dgamma|dbeta|colsum][wave][512-column window]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nvec = cols >> 2;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void*
         for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 0.f; ac[j][e] = 0.f; }
         if (idx < nvec) gm[j] = *(const f32x4*)(gamma + idx * 4);
     }
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[NV], g[NV];
         float c1 = 0.f, c2 = 0.f;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void*
     }
     // block reduction of the per-wave dgamma / dbeta partials, then one atomic per column per block
     float* r0 = red;
-    float* r1 = red + 2048;
-    float* r2 = red + 4096;
+    float* r1 = red + NW * 512;
+    float* r2 = red + 2 * NW * 512;
     // windows of 512 columns: red[k][wave][col - base]
     for (int base = 0; base < cols; base += 512) {
 #pragma unroll
@@ -200,13 +200,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy, const void*
             }
         }
         __syncthreads();
-        for (int cidx = threadIdx.x; cidx < 512 && base + cidx < cols; cidx += 256) {
-            const float sg = r0[cidx] + r0[512 + cidx] + r0[1024 + cidx] + r0[1536 + cidx];
-            const float sb = r1[cidx] + r1[512 + cidx] + r1[1024 + cidx] + r1[1536 + cidx];
+        for (int cidx = threadIdx.x; cidx < 512 && base + cidx < cols; cidx += NW * 64) {
+            float sg = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { sg += r0[w * 512 + cidx]; sb += r1[w * 512 + cidx]; sc += r2[w * 512 + cidx]; }
             atomicAdd(dgamma + base + cidx, sg);
             atomicAdd(dbeta + base + cidx, sb);
-            if (dres_colsum)
-                atomicAdd(dres_colsum + base + cidx, r2[cidx] + r2[512 + cidx] + r2[1024 + cidx] + r2[1536 + cidx]);
+            if (dres_colsum) atomicAdd(dres_colsum + base + cidx, sc);
         }
         __syncthreads();
     }
@@ -253,21 +253,28 @@ extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, cons
     if (rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int nv = ((cols >> 2) + 63) / 64;
-    // grid = exactly the workgroups that are resident at once (registers: 4 / 3 / 1 per CU for <=3 / 5 / 8 vectors
-    // per lane): a grid-stride loop over rows on a grid of 1.33 rounds left a third of the chip idle in the tail
-    int nb = (rows + 3) / 4;
-    const int resident = 256 * (nv <= 3 ? 4 : nv <= 5 ? 3 : 1);
-    if (nb > resident) nb = resident;
-#define LN_BWD(NVV)                                                                                                   \
+    // grid = exactly the workgroups that are resident at once: a grid-stride loop over rows on a grid of 1.33 rounds left
+    // a third of the chip idle in the tail.  Registers allow 16 / 12 / 4 waves per CU for <=3 / 5 / 8 vectors per lane; at 5
+    // (cols = 1280) the twelve waves are ONE workgroup, so that a CU issues a third of the dgamma / dbeta / column-sum
+    // atomics of four-wave workgroups: the atomics are rate-limited (2.9 M of them were 21 us of a 248 us launch; measured
+    // with them switched off), 249 -> 238 us.  Requesting the residual gradient with the other operands instead of after the
+    // reductions costs a wave per SIMD in registers and is slower (279 us), and so are LDS accumulators (ds_add_f32: 948 us)
+    // and one lane per column segment with the row statistics exchanged through LDS (295 us).
+#define LN_BWD(NVV, NWW)                                                                                              \
     do {                                                                                                              \
+        int nb = (rows + NWW - 1) / NWW;                                                                              \
+        const int resident = 256 * ((NVV <= 3 ? 16 : NVV <= 5 ? 12 : 4) / NWW);                                       \
+        if (nb > resident) nb = resident;                                                                             \
         if (x_dtype == DW_BF16)                                                                                       \
-            hipLaunchKernelGGL((ln_bwd_kernel<true, NVV>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, x, mean, rstd, \
-                               gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols);  \
+            hipLaunchKernelGGL((ln_bwd_kernel<true, NVV, NWW>), dim3(nb), dim3(NWW * 64), 0, s, (const bf16*)dy, x,   \
+                               mean, rstd, gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum,     \
+                               rows, cols);                                                                           \
         else                                                                                                          \
-            hipLaunchKernelGGL((ln_bwd_kernel<false, NVV>), dim3(nb), dim3(256), 0, s, (const bf16*)dy, x, mean,      \
-                               rstd, gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols); \
+            hipLaunchKernelGGL((ln_bwd_kernel<false, NVV, NWW>), dim3(nb), dim3(NWW * 64), 0, s, (const bf16*)dy, x,  \
+                               mean, rstd, gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum,     \
+                               rows, cols);                                                                           \
     } while (0)
-    if (nv <= 2) LN_BWD(2); else if (nv <= 3) LN_BWD(3); else if (nv <= 5) LN_BWD(5); else LN_BWD(8);
+    if (nv <= 2) LN_BWD(2, 4); else if (nv <= 3) LN_BWD(3, 4); else if (nv <= 5) LN_BWD(5, 12); else LN_BWD(8, 4);
 #undef LN_BWD
     DW_CHECK_LAUNCH();
     return DW_OK;
