@@ -31,9 +31,10 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
 
-def step_flops(d, mode):
-    """Algorithmic FLOPs per 30 s sample (2 x MAC, causal attention counted full, no recompute): SURVEY.md section 8(d)."""
-    S, T = 1500, 447
+def step_flops(d, mode, T=447):
+    """Algorithmic FLOPs per 30 s sample (2 x MAC, causal attention counted full, no recompute): SURVEY.md section 8(d).
+    T = decoder positions the step computes (447, or the live ones when the dead tail of the batch is left out)."""
+    S = 1500
     D, V, M = d.d_model, d.vocab, d.n_mels
 
     def enc(le):
@@ -56,6 +57,10 @@ def main():
                          "ranks issue their RCCL buckets from the host and run eagerly)")
     ap.add_argument("--no-ab", action="store_true", help="skip the in-process A/B legs (graph / eager / eager without "
                                                          "side streams, 10 steps each) reported under `ab`")
+    ap.add_argument("--dense", action="store_true",
+                    help="compute all 447 decoder positions like the reference does; default: the positions behind the last "
+                         "labelled one of the batch (labels -100 for L~U{32..224} onwards, BASELINE.md) are left out -- same "
+                         "loss and gradients (distill.trim_dead_positions), reported as decoder_positions_computed")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of 30 s clips")
     ap.add_argument("--model", default="large-v3", choices=["tiny.en", "small.en", "large-v3"])
     ap.add_argument("--mode", default="full", choices=["full", "recipe"])
@@ -137,17 +142,21 @@ def main():
     dec_in = ids[:, :-1].contiguous()
     labels = ids[:, 1:].clone()
     labels[torch.arange(T, device=dev)[None, :] >= lens[:, None]] = -100
+    # host integer, known from the label lengths before a batch goes to the device (collator.report_valid_len); read
+    # here once, outside the timed region
+    valid_len = None if args.dense else min(T, int(lens.max().item()))
+    Te = T if valid_len is None else valid_len
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     if use_graph and world > 1:
         raise SystemExit("bench.py: --graph on needs one rank (data-parallel steps run eagerly)")
 
-    def eager_step():
+    def eager_step(vl=valid_len):
         feats = tr.features(audio)
-        return tr.train_step(feats, dec_in, labels)
+        return tr.train_step(feats, dec_in, labels, valid_len=vl)
 
-    def graph_step():
-        return tr.train_step_graphed(audio, dec_in, labels)
+    def graph_step(vl=valid_len):
+        return tr.train_step_graphed(audio, dec_in, labels, valid_len=vl)
 
     one_step = graph_step if use_graph else eager_step
 
@@ -156,7 +165,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"engine ready: {args.model} {args.mode} B={B} world={world} graph={use_graph}; warm-up x{args.warmup}")
+    log(f"engine ready: {args.model} {args.mode} B={B} world={world} graph={use_graph} decoder positions {Te}/{T}; "
+        f"warm-up x{args.warmup}")
     if use_graph:
         for _ in range(3):            # two eager steps on the capture stream, then the capture (untimed, before the warm-up)
             one_step()
@@ -212,16 +222,17 @@ def main():
     value = world * B * 30.0 * args.steps / dt
     loss_val = float(losses[2].item())
 
-    enc, dec, head = step_flops(tdims, args.mode)
-    if recipe:
-        fl = enc(tdims.enc_layers) + (dec(tdims.dec_layers) + head) + 3 * (dec(ld) + head)
-    else:
-        fl = (enc(tdims.enc_layers) + dec(tdims.dec_layers) + head) + 3 * (enc(le) + dec(ld) + head)
+    def sample_flops(Tc):
+        enc, dec, head = step_flops(tdims, args.mode, Tc)
+        if recipe:
+            return enc(tdims.enc_layers) + (dec(tdims.dec_layers) + head) + 3 * (dec(ld) + head)
+        return (enc(tdims.enc_layers) + dec(tdims.dec_layers) + head) + 3 * (enc(le) + dec(ld) + head)
+    fl = sample_flops(Te)               # the flops the step EXECUTES (the fraction of peak is priced on these)
     step_tflops = value / 30.0 * fl / 1e12 / world
 
     ab = None
     if world == 1 and not args.no_ab:
-        ab = ab_legs(tr, eager_step, graph_step, B)
+        ab = ab_legs(tr, eager_step, graph_step, B, dense=None if args.dense else (lambda: graph_step(None)))
         log("A/B (median ms/step over 10 steps, same process): " + json.dumps(ab))
     tr.drop_graph()
     torch.cuda.empty_cache()
@@ -270,10 +281,11 @@ def main():
                "config": {"workload": f"whisper-{args.model} teacher ({tdims.enc_layers}/{tdims.dec_layers}) -> "
                                       f"{le}/{ld} student KD step, mode={args.mode}",
                           "global_batch": B * world, "per_gpu_batch": B, "clip_seconds": 30, "decoder_len": T,
+                          "decoder_positions_computed": Te,
                           "parallelism": f"dp{world}" + (f" ({args.backend}, ranks share cuda:0: plumbing test)" if args.share_device else ""), "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
                           "bwd+allreduce+clip+adamw", "loss": loss_val},
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
-               "flops_per_sample": fl, "step_mode": "hip_graph" if use_graph else "eager", "step_stats": step_stats,
+               "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": "hip_graph" if use_graph else "eager", "step_stats": step_stats,
                "ab": ab, "roofline": roofline, "cpu_baseline": cpu_baseline}
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -297,9 +309,10 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3):
+def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None):
     """The same process, the same weights and inputs, seconds apart: median GPU ms per step (HIP events around each
-    step on the main stream) of the three ways to issue the step."""
+    step on the main stream) of the ways to issue the step; `dense`: the graphed step over all 447 decoder positions
+    (what the reference computes) when the main run leaves the dead ones out."""
     def leg(step_fn, pre=0):
         for _ in range(pre + warm):
             step_fn()
@@ -317,6 +330,10 @@ def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3):
     tr.drop_graph()
     torch.cuda.empty_cache()
     out["hip_graph_side_streams" if (ov_t or ov_w) else "hip_graph_single_stream"] = leg(graph_step, pre=3)
+    if dense is not None:
+        tr.drop_graph()
+        torch.cuda.empty_cache()
+        out["hip_graph_all_447_decoder_positions"] = leg(dense, pre=3)
     tr.drop_graph()
     torch.cuda.empty_cache()
     out["eager_side_streams" if (ov_t or ov_w) else "eager_single_stream"] = leg(eager_step)

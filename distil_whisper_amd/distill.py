@@ -80,6 +80,24 @@ class GradReducer:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
 
 
+def trim_dead_positions(decoder_input_ids, labels, valid_len):
+    """Decoder positions behind the LAST labelled position of the whole batch are dead: the decoder is causal, so they
+    reach no labelled position; the cross-entropy ignores label -100 and the KL term is masked by `labels >= 0`
+    (run_distillation.py:1453-1462, 1486-1493), so they add nothing to the loss and their rows of every gradient GEMM are
+    zero.  The reference still computes them (its collator pads every batch to max_label_length = 448,
+    run_distillation.py:405-478); here the decoders, the LM heads and the loss run over the first `valid_len` positions
+    only -- same loss, same gradients.  `valid_len` is a HOST integer (1 + the index of the last label != -100 over the
+    batch; the collator knows the label lengths before the batch goes to the device,
+    collator.DataCollatorSpeechSeq2SeqWithPadding.report_valid_len); None keeps every position."""
+    if valid_len is None:
+        return decoder_input_ids, labels
+    T = decoder_input_ids.shape[1]
+    Te = max(1, min(T, int(valid_len)))
+    if Te == T:
+        return decoder_input_ids, labels
+    return decoder_input_ids[:, :Te], labels[:, :Te]
+
+
 class DistillationTrainer:
     def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
@@ -110,7 +128,8 @@ class DistillationTrainer:
         self._adam = ops.adam_state(lr, betas[0], betas[1], 0)
         self._lr_dev = lr
         self._gate = None            # f32[1] on the device: labels counted in the micro-batches of the current step
-        self._graph = None           # captured whole-step HIP graph (train_step_graphed)
+        self._graph = None           # the captured whole-step HIP graph in use (train_step_graphed)
+        self._graphs, self._graph_inputs = {}, None   # every captured plan by (shapes, live decoder positions); shared inputs
         self.reducer = GradReducer(st.G, process_group, bucket_bytes, always_reduce) if st.G is not None else None
         self.world = self.reducer.world if self.reducer else 1
         self.mel_filters = mel_filters
@@ -141,11 +160,13 @@ class DistillationTrainer:
         """fp32 waveforms [B, 480000] on the device -> log-mel input_features [B, n_mels, 3000]."""
         return self.ops.logmel(audio, self.mel_filters)
 
-    def forward_backward(self, input_features, decoder_input_ids, labels, zero_grad=True, sync_grads=True):
+    def forward_backward(self, input_features, decoder_input_ids, labels, zero_grad=True, sync_grads=True, valid_len=None):
         """One micro-batch: returns losses fp32[4] = (ce, kl, loss, n_valid) on the device (no host sync).
         zero_grad=False accumulates onto the gradients already in the flat buffer and sync_grads=False skips the
-        all-reduce (gradient accumulation, `accelerator.accumulate` / DDP no_sync of run_distillation.py:1607)."""
+        all-reduce (gradient accumulation, `accelerator.accumulate` / DDP no_sync of run_distillation.py:1607).
+        `valid_len`: see trim_dead_positions."""
         ops, S, T = self.ops, self.student, self.teacher
+        decoder_input_ids, labels = trim_dead_positions(decoder_input_ids, labels, valid_len)
         B, Td = decoder_input_ids.shape
         input_features = input_features.to(torch.float32).contiguous()
         decoder_input_ids = decoder_input_ids.contiguous()
@@ -192,12 +213,13 @@ class DistillationTrainer:
         S.join_wgrad_stream()
         return losses
 
-    def eval_step(self, input_features, decoder_input_ids, labels):
+    def eval_step(self, input_features, decoder_input_ids, labels, valid_len=None):
         """Forward-only CE + KL of the reference's `eval_step` (run_distillation.py:1498-1522: both models in eval
         mode under no_grad, the same loss mix, "temperature is always 1 for eval"): no activation is kept, nothing is
         written to the gradient buffer, the student logits are left intact.  Returns losses fp32[4] = (ce, kl, loss,
         n_valid) on the device."""
         ops, S, T = self.ops, self.student, self.teacher
+        decoder_input_ids, labels = trim_dead_positions(decoder_input_ids, labels, valid_len)
         B, Td = decoder_input_ids.shape
         input_features = input_features.to(torch.float32).contiguous()
         decoder_input_ids = decoder_input_ids.contiguous()
@@ -252,13 +274,13 @@ class DistillationTrainer:
             st.repack_conv()
         self._gate = None
 
-    def train_step(self, input_features, decoder_input_ids, labels, lr=None):
-        losses = self.forward_backward(input_features, decoder_input_ids, labels)
+    def train_step(self, input_features, decoder_input_ids, labels, lr=None, valid_len=None):
+        losses = self.forward_backward(input_features, decoder_input_ids, labels, valid_len=valid_len)
         self.optimizer_step(lr)
         return losses
 
     # ---- the whole step as ONE captured HIP graph --------------------------------------------------------------
-    def train_step_graphed(self, inputs, decoder_input_ids, labels, lr=None, eager_steps=2):
+    def train_step_graphed(self, inputs, decoder_input_ids, labels, lr=None, eager_steps=2, valid_len=None):
         """`train_step` (preceded by the log-mel front end when `inputs` are waveforms [B, n_samples] instead of
         features [B, n_mels, 3000]) replayed from one HIP graph.  The shapes of a step are static, so its ~2 700
         launches on three streams (main, frozen teacher, weight gradients), every buffer address and the cross-stream
@@ -268,33 +290,48 @@ class DistillationTrainer:
         lifetimes of one step, no allocator call and no host-side stream bookkeeping remain afterwards -- and every
         later call is three small device copies into the static input buffers plus one graph launch.  Every call
         performs exactly one optimizer step; the returned losses tensor is static (overwritten by the next call).
-        Data-parallel runs keep the eager path (`train_step`): the bucketed RCCL all-reduce is issued between the
-        backward's layers from the host."""
+        `valid_len` (trim_dead_positions) is part of the plan: one graph per number of live decoder positions, at most
+        `max_graphs` of them, all replaying out of the SAME pool (they never run concurrently) and the same static input
+        buffers.  Data-parallel runs keep the eager path (`train_step`): the bucketed RCCL all-reduce is issued between
+        the backward's layers from the host."""
         if self.reducer is not None and self.reducer.active:
             raise RuntimeError("train_step_graphed: data-parallel steps run eagerly (RCCL buckets are issued from the host)")
         dev = self.student_store.P.device
-        key = (tuple(inputs.shape), inputs.dtype, tuple(decoder_input_ids.shape), self.overlap_teacher,
-               self.student.wgrad_stream is not None)
+        T = decoder_input_ids.shape[1]
+        Te = T if valid_len is None else max(1, min(T, int(valid_len)))
+        in_key = (tuple(inputs.shape), inputs.dtype, tuple(decoder_input_ids.shape), self.overlap_teacher,
+                  self.student.wgrad_stream is not None)
+        key = in_key + (Te,)
+        ins = self._graph_inputs
+        if ins is None or ins["key"] != in_key:
+            self._graphs.clear()
+            self._graph = None
+            ins = self._graph_inputs = {"key": in_key, "stream": torch.cuda.Stream(device=dev), "pool": None,
+                                        "x": torch.empty_like(inputs), "ids": torch.empty_like(decoder_input_ids),
+                                        "labels": torch.empty_like(labels)}
         g = self._graph
         if g is None or g["key"] != key:
-            g = self._graph = {"key": key, "calls": 0, "graph": None, "stream": torch.cuda.Stream(device=dev),
-                               "x": torch.empty_like(inputs), "ids": torch.empty_like(decoder_input_ids),
-                               "labels": torch.empty_like(labels), "losses": None}
+            g = self._graphs.get(key)
+            if g is None:
+                while len(self._graphs) >= self.max_graphs:
+                    self._graphs.pop(next(iter(self._graphs)))
+                g = self._graphs[key] = {"key": key, "calls": 0, "graph": None, "losses": None}
+            self._graph = g
         self.set_lr(self.lr if lr is None else lr)
-        g["x"].copy_(inputs)
-        g["ids"].copy_(decoder_input_ids)
-        g["labels"].copy_(labels)
+        ins["x"].copy_(inputs)
+        ins["ids"].copy_(decoder_input_ids)
+        ins["labels"].copy_(labels)
 
         def body():
-            feats = self.features(g["x"]) if g["x"].dim() == 2 else g["x"]
-            losses = self.forward_backward(feats, g["ids"], g["labels"])
+            feats = self.features(ins["x"]) if ins["x"].dim() == 2 else ins["x"]
+            losses = self.forward_backward(feats, ins["ids"], ins["labels"], valid_len=Te)
             self.optimizer_step(_write_lr=False)
             return losses
 
         if g["graph"] is not None:
             g["graph"].replay()
         elif g["calls"] < eager_steps:
-            cur, cs = torch.cuda.current_stream(dev), g["stream"]
+            cur, cs = torch.cuda.current_stream(dev), ins["stream"]
             cs.wait_stream(cur)
             with torch.cuda.stream(cs):
                 g["losses"] = body()
@@ -304,16 +341,22 @@ class DistillationTrainer:
                 raise RuntimeError("train_step_graphed: per-launch profiling events cannot be captured")
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=g["stream"]):
+            with torch.cuda.graph(graph, pool=ins["pool"], stream=ins["stream"]):
                 g["losses"] = body()
+            if ins["pool"] is None:
+                ins["pool"] = graph.pool()
             g["graph"] = graph
             graph.replay()
         g["calls"] += 1
         return g["losses"]
 
+    max_graphs = 8    # captured steps kept (one per number of live decoder positions; the oldest plan is dropped)
+
     def drop_graph(self):
-        """Forget the captured step (its private memory pool is released with it)."""
+        """Forget every captured step (their shared memory pool is released with them)."""
         self._graph = None
+        self._graphs.clear()
+        self._graph_inputs = None
 
     def train_step_accumulated(self, micro_batches, lr=None):
         """Gradient accumulation over a list of (input_features, decoder_input_ids, labels): gradients are summed in
@@ -323,8 +366,9 @@ class DistillationTrainer:
         out = []
         self._accum = n
         try:
-            for i, (f, d, l) in enumerate(micro_batches):
-                out.append(self.forward_backward(f, d, l, zero_grad=(i == 0), sync_grads=(i == n - 1)))
+            for i, mb in enumerate(micro_batches):      # (input_features, decoder_input_ids, labels[, valid_len])
+                out.append(self.forward_backward(mb[0], mb[1], mb[2], zero_grad=(i == 0), sync_grads=(i == n - 1),
+                                                 valid_len=mb[3] if len(mb) > 3 else None))
             self.optimizer_step(lr)
         finally:
             self._accum = 1
@@ -370,4 +414,4 @@ class DistillationTrainer:
         self.segments = st.adam_segments(self.weight_decay)       # per-range weight decay follows the restored value
         self._adam = self.ops.adam_state(self.lr, self.betas[0], self.betas[1], int(state["step"]))
         self._lr_dev = self.lr
-        self._graph = None        # (a captured step has the old hyper-parameters baked in: re-planned on next use)
+        self.drop_graph()         # (a captured step has the old hyper-parameters baked in: re-planned on next use)

@@ -274,3 +274,51 @@ def test_eval_step_is_the_reference_eval_step():
     assert abs(ev[1].item() - metrics["kl_loss"].item()) < 2e-4 * metrics["kl_loss"].item() + 1e-7
     assert abs(ev[2].item() - loss.item()) < 2e-5 * loss.item()
     assert torch.equal(tr.student_store.G, g0)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_dead_decoder_positions_can_be_left_out(shared):
+    """trim_dead_positions: with every label behind position `valid_len` equal to -100, running the decoders, the LM
+    heads and the loss over the first `valid_len` positions only gives the loss and the gradients of the full-length
+    step (the reference's collator pads every batch to 448 positions, run_distillation.py:405-478).  Prompt positions
+    masked at the START of a row are not dead (later positions attend to them) and stay."""
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(T=37)
+    labels = batch["labels"].clone()
+    labels[0, 19:] = -100
+    labels[1, 11:] = -100
+    labels[1, :3] = -100                       # a masked prompt prefix
+    valid_len = 19
+    ops = RefOps("cpu", lowp=torch.float32)
+
+    def run(vl):
+        tr = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t, freeze_encoder=shared, share_encoder=shared)
+        losses = tr.forward_backward(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=vl)
+        return tr, losses.clone(), tr.student_store.G.clone()
+    tr0, l0, g0 = run(None)
+    tr1, l1, g1 = run(valid_len)
+    assert l0[3].item() == l1[3].item() == float((labels != -100).sum())
+    assert torch.allclose(l0[:3], l1[:3], rtol=1e-6, atol=0)
+    assert relerr(g1, g0) < 1e-6
+    # the embedding rows of the dead positions get exactly zero gradient either way
+    gp = tr1.student_store.g["model.decoder.embed_positions.weight"]
+    assert float(gp[valid_len:].abs().max()) == 0.0 and float(gp[:valid_len].abs().max()) > 0.0
+    # eval_step and a whole optimizer step agree too; a too-long valid_len is clamped
+    e0 = tr0.eval_step(batch["input_features"], batch["decoder_input_ids"], labels)
+    e1 = tr1.eval_step(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=valid_len)
+    assert torch.allclose(e0[:3], e1[:3], rtol=1e-6, atol=0)
+    tr0.train_step(batch["input_features"], batch["decoder_input_ids"], labels)
+    tr1.train_step(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=10 ** 6)
+    tr2 = run(None)[0]
+    tr2.train_step(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=valid_len)
+    assert torch.equal(tr0.student_store.P, tr1.student_store.P)
+    assert relerr(tr2.student_store.P, tr0.student_store.P) < 1e-7
+
+
+def test_collator_reports_the_last_labelled_position():
+    from distil_whisper_amd.collator import DataCollatorSpeechSeq2SeqWithPadding
+    feats = [{"labels": [50257, 50362, 11, 12, 13, 50256]}, {"labels": [50257, 50362, 21, 50256]}]
+    col = DataCollatorSpeechSeq2SeqWithPadding(max_target_length=16, device="cpu", report_valid_len=True)
+    b = col(feats)
+    last = int((b["labels"] != -100).any(0).nonzero().max())
+    assert b["valid_len"] == last + 1 == 5
+    assert "valid_len" not in DataCollatorSpeechSeq2SeqWithPadding(max_target_length=16, device="cpu")(feats)

@@ -327,6 +327,52 @@ def test_graph_replayed_step_equals_the_eager_step(ops, side_streams):
     assert relerr(g.student_store.S, e.student_store.S) < 2e-3
 
 
+def test_dead_decoder_positions_left_out_on_the_device(ops):
+    """distill.trim_dead_positions on the HIP path: the step over the live decoder positions only (valid_len from the
+    label lengths) gives the loss and the gradients of the step over all positions -- every kernel between the embedding
+    and the loss is row-local or causal, so the dead tail never reaches a labelled row.  Then graphs: two plans (two
+    valid_len values) captured into one shared pool and replayed alternately follow the eager trajectory."""
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 131)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    T = 72
+    b = wo.synthetic_batch(cfg_t, 3, seed=132, T=T, with_audio=False)
+    feats = (torch.randn(3, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(5)) * 0.5).cuda()
+    ids = b["decoder_input_ids"].cuda()
+
+    def labels_with(lens):
+        lab = b["labels"].clone()
+        for i, n in enumerate(lens):
+            lab[i, n:] = -100
+        lab[0, :2] = -100                                   # a masked prompt prefix is NOT dead
+        return lab.cuda()
+    lab = labels_with([33, 17, 25])
+    d = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    t = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    ld = d.forward_backward(feats, ids, lab).clone()
+    lt = t.forward_backward(feats, ids, lab, valid_len=33).clone()
+    torch.cuda.synchronize()
+    assert ld[3].item() == lt[3].item() == float((lab != -100).sum())
+    assert relerr(lt[:3], ld[:3]) < 1e-6, (ld, lt)
+    # bias / LayerNorm gradients are summed with float atomics (order varies between two runs of ANY path)
+    assert relerr(t.student_store.G, d.student_store.G) < 2e-5
+    gp = t.student_store.g["model.decoder.embed_positions.weight"]
+    assert float(gp[33:].abs().max()) == 0.0
+    # graphs: alternate two batches with different live lengths; the eager twin gets the same valid_len
+    e = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    g = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    batches = [(labels_with([33, 17, 25]), 33), (labels_with([9, 48, 20]), 48)]
+    for i in range(10):
+        lab_i, vl = batches[i % 2]
+        le = e.train_step(feats, ids, lab_i, valid_len=vl).clone()
+        lg = g.train_step_graphed(feats, ids, lab_i, valid_len=vl).clone()
+        torch.cuda.synchronize()
+        assert relerr(lg[:3], le[:3]) < 2e-4, (i, le, lg)
+    assert len(g._graphs) == 2 and all(r["graph"] is not None for r in g._graphs.values())
+    assert e.step_count == g.step_count == 10
+    assert relerr(g.student_store.P, e.student_store.P) < 1e-5
+
+
 def test_batch_without_labels_is_skipped_on_the_device(ops):
     """The HIP loss reports NaN losses and n_valid = 0 for an all-ignored batch; dw_adam_tick's gate then skips the
     update without a host sync: parameters, moments and the step count are untouched (graph-replayed step included)."""
