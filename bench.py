@@ -31,19 +31,23 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
 
-def step_flops(d, mode, T=447):
+def step_flops(d, mode, T=447, rows=None):
     """Algorithmic FLOPs per 30 s sample (2 x MAC, causal attention counted full, no recompute): SURVEY.md section 8(d).
-    T = decoder positions the step computes (447, or the live ones when the dead tail of the batch is left out)."""
+    T = decoder positions the step computes (447, or the live ones when the dead tail of the batch is left out);
+    rows = average packed rows per sample of the passes that run over live rows only (frozen teacher decoder: its
+    row-local work; both LM heads), T when nothing is packed."""
     S = 1500
     D, V, M = d.d_model, d.vocab, d.n_mels
+    rows = T if rows is None else rows
 
     def enc(le):
         return 6 * M * D * 3000 + 6 * D * D * 1500 + le * (24 * S * D * D + 4 * S * S * D)
 
-    def dec(ld):
-        return ld * (28 * T * D * D + 4 * S * D * D + 4 * T * T * D + 4 * T * S * D)
+    def dec(ld, packed=False):
+        r = rows if packed else T
+        return ld * (28 * r * D * D + 4 * S * D * D + 4 * T * T * D + 4 * T * S * D)
 
-    head = 2 * T * D * V
+    head = 2 * rows * D * V
     return enc, dec, head
 
 
@@ -61,6 +65,9 @@ def main():
                     help="compute all 447 decoder positions like the reference does; default: the positions behind the last "
                          "labelled one of the batch (labels -100 for L~U{32..224} onwards, BASELINE.md) are left out -- same "
                          "loss and gradients (distill.trim_dead_positions), reported as decoder_positions_computed")
+    ap.add_argument("--no-pack", action="store_true",
+                    help="leave out only the common dead tail (one length for the batch); default: per-sequence label lengths, "
+                         "the teacher decoder, the LM heads and the loss run over the packed live rows (engine.LiveRows)")
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of 30 s clips")
     ap.add_argument("--model", default="large-v3", choices=["tiny.en", "small.en", "large-v3"])
     ap.add_argument("--mode", default="full", choices=["full", "recipe"])
@@ -144,8 +151,10 @@ def main():
     labels[torch.arange(T, device=dev)[None, :] >= lens[:, None]] = -100
     # host integer, known from the label lengths before a batch goes to the device (collator.report_valid_len); read
     # here once, outside the timed region
-    valid_len = None if args.dense else min(T, int(lens.max().item()))
-    Te = T if valid_len is None else valid_len
+    lens_host = [min(T, int(x)) for x in lens.tolist()]
+    valid_len = None if args.dense else (max(lens_host) if args.no_pack else lens_host)
+    Te = T if valid_len is None else max(lens_host)
+    rows_avg = sum(lens_host) / B if isinstance(valid_len, list) and sum(lens_host) < tr.pack_live_rows_below * B * Te else Te
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     if use_graph and world > 1:
@@ -165,7 +174,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"engine ready: {args.model} {args.mode} B={B} world={world} graph={use_graph} decoder positions {Te}/{T}; "
+    log(f"engine ready: {args.model} {args.mode} B={B} world={world} graph={use_graph} decoder positions {Te}/{T}, "
+        f"{rows_avg:.1f} packed rows per sample; "
         f"warm-up x{args.warmup}")
     if use_graph:
         for _ in range(3):            # two eager steps on the capture stream, then the capture (untimed, before the warm-up)
@@ -222,17 +232,18 @@ def main():
     value = world * B * 30.0 * args.steps / dt
     loss_val = float(losses[2].item())
 
-    def sample_flops(Tc):
-        enc, dec, head = step_flops(tdims, args.mode, Tc)
+    def sample_flops(Tc, rows=None):
+        enc, dec, head = step_flops(tdims, args.mode, Tc, rows)
         if recipe:
-            return enc(tdims.enc_layers) + (dec(tdims.dec_layers) + head) + 3 * (dec(ld) + head)
-        return (enc(tdims.enc_layers) + dec(tdims.dec_layers) + head) + 3 * (enc(le) + dec(ld) + head)
-    fl = sample_flops(Te)               # the flops the step EXECUTES (the fraction of peak is priced on these)
+            return enc(tdims.enc_layers) + (dec(tdims.dec_layers, True) + head) + 3 * (dec(ld) + head)
+        return (enc(tdims.enc_layers) + dec(tdims.dec_layers, True) + head) + 3 * (enc(le) + dec(ld) + head)
+    fl = sample_flops(Te, rows_avg)     # the flops the step EXECUTES (the fraction of peak is priced on these)
     step_tflops = value / 30.0 * fl / 1e12 / world
 
     ab = None
     if world == 1 and not args.no_ab:
-        ab = ab_legs(tr, eager_step, graph_step, B, dense=None if args.dense else (lambda: graph_step(None)))
+        ab = ab_legs(tr, eager_step, graph_step, B, dense=None if args.dense else (lambda: graph_step(None)),
+                     trimmed=(lambda: graph_step(Te)) if isinstance(valid_len, list) else None)
         log("A/B (median ms/step over 10 steps, same process): " + json.dumps(ab))
     tr.drop_graph()
     torch.cuda.empty_cache()
@@ -281,7 +292,7 @@ def main():
                "config": {"workload": f"whisper-{args.model} teacher ({tdims.enc_layers}/{tdims.dec_layers}) -> "
                                       f"{le}/{ld} student KD step, mode={args.mode}",
                           "global_batch": B * world, "per_gpu_batch": B, "clip_seconds": 30, "decoder_len": T,
-                          "decoder_positions_computed": Te,
+                          "decoder_positions_computed": Te, "packed_rows_per_sample": rows_avg,
                           "parallelism": f"dp{world}" + (f" ({args.backend}, ranks share cuda:0: plumbing test)" if args.share_device else ""), "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
                           "bwd+allreduce+clip+adamw", "loss": loss_val},
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
@@ -309,7 +320,7 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None):
+def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None, trimmed=None):
     """The same process, the same weights and inputs, seconds apart: median GPU ms per step (HIP events around each
     step on the main stream) of the ways to issue the step; `dense`: the graphed step over all 447 decoder positions
     (what the reference computes) when the main run leaves the dead ones out."""
@@ -334,6 +345,10 @@ def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None):
         tr.drop_graph()
         torch.cuda.empty_cache()
         out["hip_graph_all_447_decoder_positions"] = leg(dense, pre=3)
+    if trimmed is not None:
+        tr.drop_graph()
+        torch.cuda.empty_cache()
+        out["hip_graph_common_dead_tail_only"] = leg(trimmed, pre=3)
     tr.drop_graph()
     torch.cuda.empty_cache()
     out["eager_side_streams" if (ov_t or ov_w) else "eager_single_stream"] = leg(eager_step)

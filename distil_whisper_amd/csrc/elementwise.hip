@@ -287,6 +287,21 @@ __global__ void selftest_tr16_kernel(int32_t* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+
+// Rows of a matrix through an index list, 16 bytes per lane: gather dst[i] = src[idx[i]], scatter dst[idx[i]] = src[i].
+// The packed (padding-free) teacher decoder keeps its activations as [live rows][D]; only attention wants the
+// (batch, position) layout back (engine._layer_fwd).
+__global__ __launch_bounds__(256) void move_rows_kernel(const char* src, long src_pitch, char* dst, long dst_pitch,
+                                                        const int* idx, int n, int vpr, int scatter) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = v / vpr;
+    if (i >= n) return;
+    const int c = (int)(v - i * vpr) * 16;
+    const long r = idx[i];
+    const long sr = scatter ? i : r, dr = scatter ? r : i;
+    *(f32x4*)(dst + dr * dst_pitch + c) = *(const f32x4*)(src + sr * src_pitch + c);
+}
+
 extern "C" int dw_version(void) {
     DW_CLEAR_ERR(); return 100; }
 
@@ -421,6 +436,20 @@ extern "C" int dw_add(const void* a, int a_dtype, const void* b, int b_dtype, vo
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(add_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, a_dtype, b, b_dtype, y, y_dtype,
                        (long)n);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
+extern "C" int dw_move_rows(const void* src, int64_t src_pitch_bytes, void* dst, int64_t dst_pitch_bytes,
+                            const int32_t* idx, int n, int row_bytes, int scatter, void* stream) {
+    DW_CLEAR_ERR();
+    if (!src || !dst || !idx || n <= 0 || row_bytes <= 0 || (row_bytes & 15) || (src_pitch_bytes & 15) ||
+        (dst_pitch_bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+        return DW_EINVAL;
+    const int vpr = row_bytes >> 4;
+    const long nv = (long)n * vpr;
+    hipLaunchKernelGGL(move_rows_kernel, dim3((nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const char*)src,
+                       (long)src_pitch_bytes, (char*)dst, (long)dst_pitch_bytes, idx, n, vpr, scatter);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -13,7 +13,7 @@ in layer-ordered buckets on a side stream while the backward of earlier layers i
 """
 import torch
 
-from .engine import ParamStore, WhisperDims, WhisperEngine
+from .engine import LiveRows, ParamStore, WhisperDims, WhisperEngine
 
 
 def shift_tokens_right(labels, pad_token_id, decoder_start_token_id):
@@ -81,21 +81,32 @@ class GradReducer:
 
 
 def trim_dead_positions(decoder_input_ids, labels, valid_len):
-    """Decoder positions behind the LAST labelled position of the whole batch are dead: the decoder is causal, so they
-    reach no labelled position; the cross-entropy ignores label -100 and the KL term is masked by `labels >= 0`
+    """Decoder positions behind the LAST labelled position are dead: the decoder is causal, so they reach no labelled
+    position; the cross-entropy ignores label -100 and the KL term is masked by `labels >= 0`
     (run_distillation.py:1453-1462, 1486-1493), so they add nothing to the loss and their rows of every gradient GEMM are
     zero.  The reference still computes them (its collator pads every batch to max_label_length = 448,
-    run_distillation.py:405-478); here the decoders, the LM heads and the loss run over the first `valid_len` positions
-    only -- same loss, same gradients.  `valid_len` is a HOST integer (1 + the index of the last label != -100 over the
-    batch; the collator knows the label lengths before the batch goes to the device,
-    collator.DataCollatorSpeechSeq2SeqWithPadding.report_valid_len); None keeps every position."""
+    run_distillation.py:405-478).  `valid_len` is HOST data, known from the label lengths before the batch goes to the
+    device (collator.DataCollatorSpeechSeq2SeqWithPadding.report_valid_len):
+      * an int (1 + the index of the last label != -100 over the whole batch): the decoders, the LM heads and the loss
+        run over the first `valid_len` positions of every sequence;
+      * a sequence of B ints (the same per sequence): additionally the frozen teacher's decoder, both LM heads and the
+        loss run over the live rows of each sequence only (engine.LiveRows; the student's layers keep the trimmed
+        rectangle -- their backward does);
+      * None keeps every position.
+    Same loss, same gradients in all three.  Returns (decoder_input_ids, labels, per-sequence lengths or None)."""
     if valid_len is None:
-        return decoder_input_ids, labels
+        return decoder_input_ids, labels, None
     T = decoder_input_ids.shape[1]
+    lens = None
+    if not isinstance(valid_len, int):
+        lens = [max(1, min(T, int(x))) for x in valid_len]
+        if len(lens) != decoder_input_ids.shape[0]:
+            raise ValueError("valid_len: one length per sequence of the batch (or one int for the batch)")
+        valid_len = max(lens)
     Te = max(1, min(T, int(valid_len)))
-    if Te == T:
-        return decoder_input_ids, labels
-    return decoder_input_ids[:, :Te], labels[:, :Te]
+    if Te < T:
+        decoder_input_ids, labels = decoder_input_ids[:, :Te], labels[:, :Te]
+    return decoder_input_ids, labels, lens
 
 
 class DistillationTrainer:
@@ -160,17 +171,28 @@ class DistillationTrainer:
         """fp32 waveforms [B, 480000] on the device -> log-mel input_features [B, n_mels, 3000]."""
         return self.ops.logmel(audio, self.mel_filters)
 
-    def forward_backward(self, input_features, decoder_input_ids, labels, zero_grad=True, sync_grads=True, valid_len=None):
+    pack_live_rows_below = 0.9      # per-sequence lengths are used when the live rows are less than this share of B x T
+
+    def _live_rows(self, lens, B, Te, device):
+        if lens is None or sum(lens) >= self.pack_live_rows_below * B * Te:
+            return None
+        return LiveRows.build(lens, Te, device)
+
+    def forward_backward(self, input_features, decoder_input_ids, labels, zero_grad=True, sync_grads=True, valid_len=None,
+                         _live=None):
         """One micro-batch: returns losses fp32[4] = (ce, kl, loss, n_valid) on the device (no host sync).
         zero_grad=False accumulates onto the gradients already in the flat buffer and sync_grads=False skips the
         all-reduce (gradient accumulation, `accelerator.accumulate` / DDP no_sync of run_distillation.py:1607).
         `valid_len`: see trim_dead_positions."""
         ops, S, T = self.ops, self.student, self.teacher
-        decoder_input_ids, labels = trim_dead_positions(decoder_input_ids, labels, valid_len)
+        decoder_input_ids, labels, lens = trim_dead_positions(decoder_input_ids, labels, valid_len)
         B, Td = decoder_input_ids.shape
+        live = _live if _live is not None else self._live_rows(lens, B, Td, decoder_input_ids.device)
         input_features = input_features.to(torch.float32).contiguous()
         decoder_input_ids = decoder_input_ids.contiguous()
         labels_flat = labels.reshape(-1).contiguous()
+        if live is not None:
+            labels_flat = labels_flat.index_select(0, live.idx)      # labels of the packed rows
         if self.overlap_teacher and self._tstream is None:
             self._tstream = torch.cuda.Stream(device=self.student_store.P.device)
         side = self._tstream if (self.overlap_teacher and not self.share_encoder) else None
@@ -179,23 +201,23 @@ class DistillationTrainer:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 enc_t, _ = T.encode(input_features, save=False)
-                logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False)
+                logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False, live=live)
                 del enc_t
             # (no record_stream: the inputs are the caller's and stay alive over the call, the side stream is joined
             # below, and logits_t -- a block of the side stream's pool -- is next written by the teacher forward of the
             # following step, which starts with side.wait_stream(main), i.e. after the loss kernel that reads it)
         enc_s, ectx = S.encode(input_features, save=not self.freeze_encoder)
-        logits_s, dctx = S.decode(decoder_input_ids, enc_s, save=True)
+        logits_s, dctx = S.decode(decoder_input_ids, enc_s, save=True, live=live)
         if side is not None:
             main.wait_stream(side)
         elif self.share_encoder:
             t_ids = shift_tokens_right(labels, self.tdims.pad_token_id, self.tdims.decoder_start_token_id)
-            logits_t, _ = T.decode(t_ids, enc_s, save=False)
+            logits_t, _ = T.decode(t_ids, enc_s, save=False, live=live)
         else:
             enc_t, _ = T.encode(input_features, save=False)
-            logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False)
+            logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False, live=live)
             del enc_t
-        R = B * Td
+        R = B * Td if live is None else live.n
         losses = ops.distill_loss(logits_s[:R], logits_t[:R], labels_flat, self.sdims.vocab, self.temperature, 0.8,
                                   self.kl_weight, 1.0, True)
         del logits_t
@@ -219,20 +241,24 @@ class DistillationTrainer:
         written to the gradient buffer, the student logits are left intact.  Returns losses fp32[4] = (ce, kl, loss,
         n_valid) on the device."""
         ops, S, T = self.ops, self.student, self.teacher
-        decoder_input_ids, labels = trim_dead_positions(decoder_input_ids, labels, valid_len)
+        decoder_input_ids, labels, lens = trim_dead_positions(decoder_input_ids, labels, valid_len)
         B, Td = decoder_input_ids.shape
+        live = self._live_rows(lens, B, Td, decoder_input_ids.device)
         input_features = input_features.to(torch.float32).contiguous()
         decoder_input_ids = decoder_input_ids.contiguous()
         enc_s, _ = S.encode(input_features, save=False)
-        logits_s, _ = S.decode(decoder_input_ids, enc_s, save=False)
+        logits_s, _ = S.decode(decoder_input_ids, enc_s, save=False, live=live)
         if self.share_encoder:
             t_ids = shift_tokens_right(labels, self.tdims.pad_token_id, self.tdims.decoder_start_token_id)
-            logits_t, _ = T.decode(t_ids, enc_s, save=False)
+            logits_t, _ = T.decode(t_ids, enc_s, save=False, live=live)
         else:
             enc_t, _ = T.encode(input_features, save=False)
-            logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False)
-        R = B * Td
-        return ops.distill_loss(logits_s[:R], logits_t[:R], labels.reshape(-1).contiguous(), self.sdims.vocab,
+            logits_t, _ = T.decode(decoder_input_ids, enc_t, save=False, live=live)
+        R = B * Td if live is None else live.n
+        labels_flat = labels.reshape(-1).contiguous()
+        if live is not None:
+            labels_flat = labels_flat.index_select(0, live.idx)
+        return ops.distill_loss(logits_s[:R], logits_t[:R], labels_flat, self.sdims.vocab,
                                 1.0, 0.8, self.kl_weight, 1.0, False)
 
     def set_lr(self, lr):
@@ -290,25 +316,33 @@ class DistillationTrainer:
         lifetimes of one step, no allocator call and no host-side stream bookkeeping remain afterwards -- and every
         later call is three small device copies into the static input buffers plus one graph launch.  Every call
         performs exactly one optimizer step; the returned losses tensor is static (overwritten by the next call).
-        `valid_len` (trim_dead_positions) is part of the plan: one graph per number of live decoder positions, at most
+        `valid_len` (trim_dead_positions) is part of the plan: one graph per (live decoder positions, packed rows), at most
         `max_graphs` of them, all replaying out of the SAME pool (they never run concurrently) and the same static input
         buffers.  Data-parallel runs keep the eager path (`train_step`): the bucketed RCCL all-reduce is issued between
         the backward's layers from the host."""
         if self.reducer is not None and self.reducer.active:
             raise RuntimeError("train_step_graphed: data-parallel steps run eagerly (RCCL buckets are issued from the host)")
         dev = self.student_store.P.device
-        T = decoder_input_ids.shape[1]
+        B, T = decoder_input_ids.shape
+        lens = None
+        if valid_len is not None and not isinstance(valid_len, int):
+            lens = [max(1, min(T, int(x))) for x in valid_len]
+            valid_len = max(lens)
         Te = T if valid_len is None else max(1, min(T, int(valid_len)))
+        if lens is not None and sum(lens) >= self.pack_live_rows_below * B * Te:
+            lens = None
+        Rc = sum(lens) if lens is not None else 0           # packed rows (0: the trimmed rectangle)
         in_key = (tuple(inputs.shape), inputs.dtype, tuple(decoder_input_ids.shape), self.overlap_teacher,
                   self.student.wgrad_stream is not None)
-        key = in_key + (Te,)
+        key = in_key + (Te, Rc)
         ins = self._graph_inputs
         if ins is None or ins["key"] != in_key:
             self._graphs.clear()
             self._graph = None
             ins = self._graph_inputs = {"key": in_key, "stream": torch.cuda.Stream(device=dev), "pool": None,
                                         "x": torch.empty_like(inputs), "ids": torch.empty_like(decoder_input_ids),
-                                        "labels": torch.empty_like(labels)}
+                                        "labels": torch.empty_like(labels),
+                                        "live_idx": torch.zeros(B * T, dtype=torch.int32, device=dev)}
         g = self._graph
         if g is None or g["key"] != key:
             g = self._graphs.get(key)
@@ -321,10 +355,14 @@ class DistillationTrainer:
         ins["x"].copy_(inputs)
         ins["ids"].copy_(decoder_input_ids)
         ins["labels"].copy_(labels)
+        live = None
+        if lens is not None:             # the row list of this batch goes into the plan's static index buffer
+            ins["live_idx"][:Rc].copy_(LiveRows.host_index(lens, Te))
+            live = LiveRows(ins["live_idx"][:Rc], Rc, B, Te)
 
         def body():
             feats = self.features(ins["x"]) if ins["x"].dim() == 2 else ins["x"]
-            losses = self.forward_backward(feats, ins["ids"], ins["labels"], valid_len=Te)
+            losses = self.forward_backward(feats, ins["ids"], ins["labels"], valid_len=Te, _live=live)
             self.optimizer_step(_write_lr=False)
             return losses
 

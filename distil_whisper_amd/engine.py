@@ -211,6 +211,27 @@ class ParamStore:
         return segs
 
 
+class LiveRows:
+    """The live rows of a [B, T] decoder batch: position t of sequence b is live when t < lens[b] (lens[b] = 1 + the
+    last labelled position of the sequence; everything behind it reaches no label through the causal decoder).  `idx`
+    (int32 on the device) lists their row numbers b*T + t, sequence by sequence.  Row-local work (projections,
+    LayerNorm, MLP, LM head, loss) runs over the n packed rows; attention gets the (batch, position) layout back through
+    one scatter / gather pair (ops.scatter_rows / gather_rows)."""
+
+    def __init__(self, idx, n, B, T):
+        self.idx, self.n, self.B, self.T = idx, int(n), int(B), int(T)
+
+    @staticmethod
+    def host_index(lens, T):
+        lens = [max(1, min(int(T), int(x))) for x in lens]
+        return torch.cat([b * T + torch.arange(n, dtype=torch.int32) for b, n in enumerate(lens)])
+
+    @classmethod
+    def build(cls, lens, T, device):
+        h = cls.host_index(lens, T)
+        return cls(h.to(device), h.numel(), len(lens), T)
+
+
 class WhisperEngine:
     """Forward/backward of one Whisper model over a ParamStore.  `stream` is the residual-stream dtype: fp32 for the
     student (autocast keeps residual adds and LayerNorm in fp32), the low-precision dtype for the bf16 teacher."""
@@ -268,6 +289,16 @@ class WhisperEngine:
                                       dres, dg, db, out_lowp=nxt[:R] if emit else None,
                                       colsum=colsum_to if emit else None)
         return dres, nxt
+
+    def _scatter_buf(self, rows, cols):
+        key = (rows, cols)
+        if not hasattr(self, "_sb"):
+            self._sb = {}
+        if key not in self._sb:
+            if len(self._sb) >= 8:
+                self._sb.pop(next(iter(self._sb)))
+            self._sb[key] = self.ops.zeros((_rup(rows, 64), cols), self.lowp)
+        return self._sb[key]
 
     def _scratch_vec(self, n, slot=0):
         key = (n, slot)
@@ -367,21 +398,45 @@ class WhisperEngine:
             ctx.update(x_final=x, mu=mu, rs=rs, enc_out=y)
         return y, ctx
 
-    def _layer_fwd(self, p, x, B, L, enc_out, Lk, causal, save, Rg=None):
-        """One pre-LN transformer layer (TF:modeling_whisper.py:379-413 encoder, 448-505 decoder).  Rg >= B*L: rows
-        the projections run over (`pad_gemm_rows`; x then has Rg rows); attention and LayerNorm see the B*L valid rows."""
+    def _layer_fwd(self, p, x, B, L, enc_out, Lk, causal, save, Rg=None, live=None):
+        """One pre-LN transformer layer (TF:modeling_whisper.py:379-413 encoder, 448-505 decoder).  Rg >= the valid
+        rows: rows the projections run over (`pad_gemm_rows`; x then has Rg rows); attention and LayerNorm see the valid
+        rows.  live (forward-only passes): x holds the packed live rows (LiveRows); attention runs in the (batch,
+        position) layout between a scatter and a gather -- its dead rows hold stale memory, which only ever reaches
+        dead rows (queries are independent, the causal mask hides later keys, encoder keys are all live)."""
         ops, st, d = self.ops, self.st, self.dims
-        D, H, R = d.d_model, d.heads, B * L
+        D, H, Rp = d.d_model, d.heads, B * L
+        R = Rp if live is None else live.n          # valid rows of x
         Rg = R if Rg is None else Rg
         assert Rg == R or not save
+        assert live is None or not save
         lc = {} if save else None
+
+        def attend(q_src, k, v, Lkv, is_causal, cols):
+            """q_src [>= R, cols] with the queries in its first D columns -> o [Rg, D]"""
+            o = self.act(Rg, D)
+            if live is None:
+                _, lse = ops.attn_fwd(q_src[:R, :D], k, v, B, H, L, Lkv, is_causal, 0.125, out=o[:R])
+                return o, lse
+            # Dead rows must hold FINITE values: a live query's masked keys (later positions inside its 64-key tile) enter
+            # the P.V product with probability exactly 0, and 0 x NaN from stale memory would poison the live row.  The
+            # scatter target is a buffer of this engine that starts zeroed and only ever receives projected rows.
+            qp = self._scatter_buf(Rp, cols)
+            ops.scatter_rows(q_src[:R], live.idx, qp)
+            op = self.act(Rp, D)
+            kk, vv = (qp[:Rp, D:2 * D], qp[:Rp, 2 * D:]) if k is None else (k, v)
+            ops.attn_fwd(qp[:Rp, :D], kk, vv, B, H, L, Lkv, is_causal, 0.125, out=op[:Rp])
+            ops.gather_rows(op, live.idx, o)
+            return o, None
         # --- self attention
         av = st.attn_views(f"{p}.self_attn")
         h, mu, rs = self._ln(f"{p}.self_attn_layer_norm", x, R, save, Rg)
         qkv = self.act(Rg, 3 * D)
         ops.gemm(h[:Rg], av["wqkv"], bias=av["bqkv"], out=qkv[:Rg])
-        o = self.act(Rg, D)
-        _, lse = ops.attn_fwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], B, H, L, L, causal, 0.125, out=o[:R])
+        if live is None:
+            o, lse = attend(qkv, qkv[:R, D:2 * D], qkv[:R, 2 * D:], L, causal, 3 * D)
+        else:
+            o, lse = attend(qkv, None, None, L, causal, 3 * D)
         x1 = ops.gemm(o[:Rg], av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
         if save:
             lc.update(x0=x, mu0=mu, rs0=rs, h0=h, qkv=qkv, o0=o, lse0=lse)
@@ -395,8 +450,7 @@ class WhisperEngine:
             ops.gemm(h[:Rg], cv["wqkv"][:D], bias=cv["bqkv"][:D], out=q[:Rg])
             kv = self.act(Re, 2 * D)
             ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=kv[:Re])
-            o = self.act(Rg, D)
-            _, lse = ops.attn_fwd(q[:R], kv[:Re, :D], kv[:Re, D:], B, H, L, Lk, False, 0.125, out=o[:R])
+            o, lse = attend(q, kv[:Re, :D], kv[:Re, D:], Lk, False, D)
             x1 = ops.gemm(o[:Rg], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
             if save:
                 lc.update(x1=x, mu1=mu, rs1=rs, h1=h, q1=q, kv1=kv, o1=o, lse1=lse)
@@ -414,43 +468,60 @@ class WhisperEngine:
         return x2, lc
 
     # ---- decoder -------------------------------------------------------------------------------------------------
-    def decode(self, ids, enc_out, save=False):
+    def decode(self, ids, enc_out, save=False, live=None):
         """WhisperDecoder.forward + tied LM head (TF:modeling_whisper.py:690-795, 965, 1080).  ids int64 [B, T];
-        enc_out low-precision [>= B*Lk, D].  Returns (logits low-precision [B*T, ldv] with V valid columns, ctx)."""
+        enc_out low-precision [>= B*Lk, D].  Returns (logits low-precision [rows, ldv] with V valid columns, ctx); rows =
+        B*T in (batch, position) order, or -- with `live` (LiveRows) -- its n live rows in packed order:
+          * forward-only pass (the frozen teacher): the whole decoder runs over the packed rows (_layer_fwd);
+          * training pass: the layers keep the (batch, position) layout (their backward does), the LM head and with it
+            dE = dlogits^T . hf and dhf = dlogits . E run over the live rows only."""
         ops, st, d = self.ops, self.st, self.dims
         B, T = ids.shape
         R, Lk = B * T, d.max_src
+        assert live is None or (live.B == B and live.T == T)
         ctx = {"B": B, "T": T, "R": R, "ids": ids, "layers": [], "enc_out": enc_out} if save else None
-        Rg = self._gemm_rows(R, save)
+        packed = live is not None and not save
+        Rv = live.n if packed else R                 # rows the layers run over
+        Rg = self._gemm_rows(Rv, save)
         if self.stream == torch.float32:
             x = ops.embed_fwd(ids, st.p["model.decoder.embed_tokens.weight"],
-                              st.p["model.decoder.embed_positions.weight"], torch.float32, rows_alloc=Rg)
+                              st.p["model.decoder.embed_positions.weight"], torch.float32, rows_alloc=R if packed else Rg)
         else:
             x = ops.embed_fwd(ids, st.s["model.decoder.embed_tokens.weight"],
-                              st.s["model.decoder.embed_positions.weight"], self.lowp, rows_alloc=Rg)
+                              st.s["model.decoder.embed_positions.weight"], self.lowp, rows_alloc=R if packed else Rg)
+        if packed:
+            xp, x = x, ops.empty((Rg, d.d_model), self.stream)
+            ops.gather_rows(xp, live.idx, x)
+            del xp
         for i in range(d.dec_layers):
-            x, lc = self._layer_fwd(f"model.decoder.layers.{i}", x, B, T, enc_out, Lk, True, save, Rg)
+            x, lc = self._layer_fwd(f"model.decoder.layers.{i}", x, B, T, enc_out, Lk, True, save, Rg,
+                                    live if packed else None)
             if save:
                 ctx["layers"].append(lc)
         # Training pass: the rows of hf / logits are padded with ZERO rows to a multiple of 320 (same rule as
-        # pad_gemm_rows) so that the backward's dhf = dlogits . E (M = B*T, N = D, K = padded vocabulary) is one round
+        # pad_gemm_rows) so that the backward's dhf = dlogits . E (M = rows, N = D, K = padded vocabulary) is one round
         # of 320-row tiles instead of two rounds of 256-tiles; zero rows add nothing to dE = dlogits^T . hf.
-        Rl = R
-        if save and self.pad_lm_rows and R >= self.pad_gemm_rows_min:
-            Rl = _rup(R, 320)
-            Rl = Rl if Rl - R <= R * self.pad_gemm_rows_slack else R
-        hf, mu, rs = self._ln("model.decoder.layer_norm", x, R, save, Rl)
+        Rh = live.n if live is not None else R       # rows of the LM head
+        Rl = Rh
+        if save and self.pad_lm_rows and Rh >= self.pad_gemm_rows_min:
+            Rl = _rup(Rh, 320)
+            Rl = Rl if Rl - Rh <= Rh * self.pad_gemm_rows_slack else Rh
+        hf, mu, rs = self._ln("model.decoder.layer_norm", x, Rv, save, max(Rl, Rv))
+        if live is not None and save:                # (batch, position) rows of the final LayerNorm -> live rows
+            hfp, hf = hf, self.act(Rl, d.d_model)
+            ops.gather_rows(hfp, live.idx, hf)
+            del hfp
         logits = self.act(Rl, self.ldv)
-        if Rl > R:
-            hf[R:Rl].zero_()
-            logits[R:Rl].zero_()
+        if Rl > Rh:
+            hf[Rh:Rl].zero_()
+            logits[Rh:Rl].zero_()
         # N = padded vocabulary (multiple of 64): the rows of the shadow buffer behind E are finite parameters / zero
         # slack, the resulting pad columns are never read as logits (the loss kernel stops at V and zeroes them)
         eo = st.entries["model.decoder.embed_tokens.weight"][0]
         e_pad = st.S[eo:eo + self.ldv * d.d_model].view(self.ldv, d.d_model)
-        ops.gemm(hf[:R], e_pad, out=logits[:R])
+        ops.gemm(hf[:Rh], e_pad, out=logits[:Rh])
         if save:
-            ctx.update(x_final=x, mu=mu, rs=rs, hf=hf, lm_rows=Rl)
+            ctx.update(x_final=x, mu=mu, rs=rs, hf=hf, lm_rows=Rl, live=live)
         return logits, ctx
 
     # ---- incremental decoding with a KV cache (TF:modeling_whisper.py:312-335, EncoderDecoderCache) -----------------
@@ -710,6 +781,12 @@ class WhisperEngine:
         Rl = ctx.get("lm_rows", R)
         assert dlogits.shape[0] >= Rl
         dh = ops.gemm(dlogits[:Rl], e_pad, trans_b=True)      # rows R..Rl of dlogits are zero (decode, pad_lm_rows)
+        live = ctx.get("live")
+        if live is not None:                                  # packed LM-head rows -> (batch, position); dead rows: zero
+            dhp = self.act(R, D)
+            dhp[:R].zero_()
+            ops.scatter_rows(dh, live.idx, dhp)
+            dh = dhp
         nl = d.dec_layers
         dres, dy = self._ln_bwd("model.decoder.layer_norm", dh, ctx["x_final"], ctx["mu"], ctx["rs"], None, R,
                                 emit=True, colsum_to=self._bias_grad(f"model.decoder.layers.{nl - 1}.fc2.bias"))

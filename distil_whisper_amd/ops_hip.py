@@ -78,6 +78,7 @@ _SIGS = {
     "dw_cast_bf16_f32": ([C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p], C.c_int),
     "dw_colsum_bf16": ([C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p], C.c_int),
     "dw_add": ([C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_void_p], C.c_int),
+    "dw_move_rows": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_sumsq_f32": ([C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "dw_adamw": ([C.c_void_p] * 5 + [C.c_int64, C.c_void_p] + [C.c_float] * 2 + [C.c_double] * 5 + [C.c_int, C.c_void_p], C.c_int),
     "dw_adam_tick": ([C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
@@ -509,6 +510,24 @@ class HipOps:
         assert x.dtype == torch.bfloat16 and x.stride(1) == 1 and out.dtype == torch.float32
         self._chk(self.lib.dw_colsum_bf16(_p(x), x.stride(0), rows, cols, _p(out), int(accumulate), self._stream()),
                   "colsum")
+        return out
+
+    def gather_rows(self, src, idx, out):
+        """out[i] = src[idx[i]] for i < len(idx) (rows of 2-D tensors with unit column stride; idx int32 on the device)."""
+        n, rb = idx.numel(), src.shape[1] * src.element_size()
+        assert src.stride(1) == 1 and out.stride(1) == 1 and out.shape[1] == src.shape[1] and out.dtype == src.dtype
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and out.shape[0] >= n
+        self._chk(self.lib.dw_move_rows(_p(src), src.stride(0) * src.element_size(), _p(out),
+                                        out.stride(0) * out.element_size(), _p(idx), n, rb, 0, self._stream()), "move_rows")
+        return out
+
+    def scatter_rows(self, src, idx, out):
+        """out[idx[i]] = src[i] for i < len(idx); the other rows of `out` are left as they are."""
+        n, rb = idx.numel(), src.shape[1] * src.element_size()
+        assert src.stride(1) == 1 and out.stride(1) == 1 and out.shape[1] == src.shape[1] and out.dtype == src.dtype
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and src.shape[0] >= n
+        self._chk(self.lib.dw_move_rows(_p(src), src.stride(0) * src.element_size(), _p(out),
+                                        out.stride(0) * out.element_size(), _p(idx), n, rb, 1, self._stream()), "move_rows")
         return out
 
     def add(self, a, b, out_dtype):

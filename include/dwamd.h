@@ -180,6 +180,12 @@ int dw_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 int dw_cast_bf16_f32(const void* x, float* y, int64_t n, void* stream);
 /* out[n] (+)= sum_r x[r][n], x bf16 [rows][ld] (bias gradients). */
 int dw_colsum_bf16(const void* x, int64_t ld, int rows, int cols, float* out, int accumulate, void* stream);
+/* Rows through an index list (int32, device): gather (scatter = 0) dst[i][:] = src[idx[i]][:], scatter dst[idx[i]][:] =
+ * src[i][:], i < n; row_bytes and both pitches multiples of 16.  The padding-free decoder pass keeps [live rows][D]
+ * activations between the attention calls -- the reference computes all 448 padded positions of every row of the batch
+ * (collator, run_distillation.py:405-478; decoder, TF:modeling_whisper.py:690-795). */
+int dw_move_rows(const void* src, int64_t src_pitch_bytes, void* dst, int64_t dst_pitch_bytes, const int32_t* idx, int n,
+                 int row_bytes, int scatter, void* stream);
 /* y = a (bf16/f32) + b (bf16/f32) elementwise into f32 or bf16 */
 int dw_add(const void* a, int a_dtype, const void* b, int b_dtype, void* y, int y_dtype, int64_t n, void* stream);
 

@@ -341,6 +341,14 @@ class RefOps:
             out.copy_(s)
         return out
 
+    def gather_rows(self, src, idx, out):
+        out[:idx.numel()] = src[idx.long()]
+        return out
+
+    def scatter_rows(self, src, idx, out):
+        out[idx.long()] = src[:idx.numel()]
+        return out
+
     def add(self, a, b, out_dtype):
         return (a.float() + b.float()).to(out_dtype)
 

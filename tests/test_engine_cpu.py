@@ -312,6 +312,20 @@ def test_dead_decoder_positions_can_be_left_out(shared):
     tr2.train_step(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=valid_len)
     assert torch.equal(tr0.student_store.P, tr1.student_store.P)
     assert relerr(tr2.student_store.P, tr0.student_store.P) < 1e-7
+    # per-sequence lengths: the teacher's decoder, both LM heads and the loss over the packed live rows (30 of 2 x 19)
+    seen = []
+    gemm = ops.gemm
+    ops.gemm = lambda a, *r, **k: (seen.append(a.shape[0]), gemm(a, *r, **k))[1]
+    try:
+        tr3, l3, g3 = run([19, 11])
+    finally:
+        ops.gemm = gemm
+    assert 30 in seen                                           # the packed GEMMs ran
+    assert torch.allclose(l0, l3, rtol=1e-6, atol=0) and relerr(g3, g0) < 1e-6
+    e3 = tr3.eval_step(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=[19, 11])
+    assert torch.allclose(e0[:3], e3[:3], rtol=1e-6, atol=0)
+    with pytest.raises(ValueError):
+        tr3.forward_backward(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=[19])
 
 
 def test_collator_reports_the_last_labelled_position():

@@ -669,3 +669,26 @@ def test_greedy_select_matches_restatement(ops, ref):
             out[name] = (t.cpu(), cur.cpu(), done.cpu())
         for a, b in zip(out["hip"], out["ref"]):
             assert torch.equal(a, b), (trial, kw, out["hip"][1].view(-1).tolist(), out["ref"][1].view(-1).tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,cols", [(torch.bfloat16, 1280), (torch.float32, 1280), (torch.bfloat16, 3840), (torch.int32, 4)])
+def test_move_rows_gather_scatter(dtype, cols):
+    """dw_move_rows: rows through an index list, both directions, strided source / destination (bit-exact)."""
+    from distil_whisper_amd.ops_hip import HipOps
+    ops = HipOps("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    n_src, n = 7136, 4103
+    src = (torch.randn(n_src, cols, generator=g) * 100).to(dtype).cuda()
+    idx = torch.randperm(n_src, generator=g)[:n].sort().values.to(torch.int32).cuda()
+    out = torch.zeros(n + 5, cols, dtype=dtype, device="cuda")
+    ops.gather_rows(src, idx, out)
+    assert torch.equal(out[:n], src[idx.long()]) and float(out[n:].float().abs().max()) == 0.0
+    wide = (torch.randn(n_src, 3 * cols, generator=g) * 100).to(dtype).cuda()       # a column block of a wider matrix
+    ops.gather_rows(wide[:, cols:2 * cols], idx, out)
+    assert torch.equal(out[:n], wide[idx.long(), cols:2 * cols])
+    back = torch.full((n_src, cols), 7, dtype=dtype, device="cuda")
+    ops.scatter_rows(out, idx, back)
+    ref = torch.full((n_src, cols), 7, dtype=dtype, device="cuda")
+    ref[idx.long()] = out[:n]
+    assert torch.equal(back, ref)

@@ -358,10 +358,24 @@ def test_dead_decoder_positions_left_out_on_the_device(ops):
     assert relerr(t.student_store.G, d.student_store.G) < 2e-5
     gp = t.student_store.g["model.decoder.embed_positions.weight"]
     assert float(gp[33:].abs().max()) == 0.0
-    # graphs: alternate two batches with different live lengths; the eager twin gets the same valid_len
+    # per-sequence lengths: teacher decoder, LM heads and loss over the 75 packed live rows instead of 3 x 33
+    p = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    for _ in range(2):                  # the allocator's free blocks hold NaN: stale dead rows must not reach a live row
+        junk = torch.full((96 << 20,), float("nan"), device="cuda", dtype=torch.bfloat16)
+        del junk
+    lp = p.forward_backward(feats, ids, lab, valid_len=[33, 17, 25]).clone()
+    torch.cuda.synchronize()
+    assert lp[3].item() == ld[3].item()
+    assert relerr(lp[:3], ld[:3]) < 1e-6, (ld, lp)
+    assert relerr(p.student_store.G, d.student_store.G) < 2e-5
+    ev0 = d.eval_step(feats, ids, lab).clone()
+    ev1 = p.eval_step(feats, ids, lab, valid_len=[33, 17, 25]).clone()
+    assert relerr(ev1[:3], ev0[:3]) < 1e-6
+    # graphs: alternate batches with different live lengths (rectangle-trimmed and packed plans); the eager twin gets the
+    # same valid_len
     e = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
     g = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
-    batches = [(labels_with([33, 17, 25]), 33), (labels_with([9, 48, 20]), 48)]
+    batches = [(labels_with([33, 17, 25]), [33, 17, 25]), (labels_with([9, 48, 20]), 48)]
     for i in range(10):
         lab_i, vl = batches[i % 2]
         le = e.train_step(feats, ids, lab_i, valid_len=vl).clone()
