@@ -177,6 +177,35 @@ def main():
     log(f"engine ready: {args.model} {args.mode} B={B} world={world} graph={use_graph} decoder positions {Te}/{T}, "
         f"{rows_avg:.1f} packed rows per sample; "
         f"warm-up x{args.warmup}")
+    selection = None
+    if args.graph == "auto" and world == 1 and not (args.overlap or args.no_overlap):
+        # Two ways to issue the same step, a few untimed steps of each, the faster one runs the timed region: the whole step
+        # replayed from one HIP graph on one stream (no host work at all), or issued eagerly with the frozen teacher and
+        # the weight-gradient GEMMs on their own streams (fills the tails of the small decoder GEMMs; needs a host that
+        # keeps up with ~7 launches per millisecond).  Which one wins depends on the box's host as well as its GPU.
+        def probe(step_fn, pre):
+            for _ in range(pre):
+                step_fn()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+            ev[0].record()
+            for i in range(6):
+                step_fn()
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(6))[2]
+        selection = {"hip_graph_single_stream": probe(graph_step, 4)}
+        tr.drop_graph()
+        torch.cuda.empty_cache()
+        tr.overlap_teacher = True
+        tr.set_overlap_wgrad(True)
+        selection["eager_side_streams"] = probe(eager_step, 2)
+        use_graph = selection["hip_graph_single_stream"] <= selection["eager_side_streams"]
+        if use_graph:
+            tr.overlap_teacher = False
+            tr.set_overlap_wgrad(False)
+        one_step = graph_step if use_graph else eager_step
+        log("mode selection (median ms of 6 untimed steps): " + json.dumps(selection) +
+            f" -> {'hip_graph_single_stream' if use_graph else 'eager_side_streams'}")
     if use_graph:
         for _ in range(3):            # two eager steps on the capture stream, then the capture (untimed, before the warm-up)
             one_step()
@@ -296,7 +325,9 @@ def main():
                           "parallelism": f"dp{world}" + (f" ({args.backend}, ranks share cuda:0: plumbing test)" if args.share_device else ""), "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
                           "bwd+allreduce+clip+adamw", "loss": loss_val},
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
-               "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": "hip_graph" if use_graph else "eager", "step_stats": step_stats,
+               "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": ("hip_graph" if use_graph else "eager") +
+               ("_side_streams" if (tr.overlap_teacher or tr.student.wgrad_stream is not None) else "_single_stream"),
+               "mode_selection": selection, "step_stats": step_stats,
                "ab": ab, "roofline": roofline, "cpu_baseline": cpu_baseline}
         print(json.dumps(out), flush=True)
     if world > 1:
