@@ -26,8 +26,9 @@ class DataCollatorSpeechSeq2SeqWithPadding:
     device: str = "cuda:0"
     # True: the batch also carries "valid_len" = 1 + the last labelled decoder position of the batch, a host integer read
     # off the label lengths before anything goes to the device (DistillationTrainer.train_step(..., valid_len=...) then
-    # leaves out the dead positions behind it).  Off by default: the reference feeds the batch as `model(**batch)`.
-    report_valid_len: bool = False
+    # leaves out the dead positions behind it); "per_sequence": the same per row of the batch (a list of ints: the
+    # trainer then also packs the live rows).  Off by default: the reference feeds the batch as `model(**batch)`.
+    report_valid_len: Union[bool, str] = False
 
     def __call__(self, features):
         B = len(features)
@@ -49,7 +50,8 @@ class DataCollatorSpeechSeq2SeqWithPadding:
         labels = torch.where(prompt_mask, torch.full_like(labels, -100), labels).contiguous()
         batch = {"labels": labels, "decoder_input_ids": decoder_input_ids}
         if self.report_valid_len:
-            batch["valid_len"] = max(1, max((int(np.asarray(f["labels"]).size) for f in features), default=1) - 1)
+            per_row = [max(1, int(np.asarray(f["labels"]).size) - 1) for f in features]
+            batch["valid_len"] = per_row if self.report_valid_len == "per_sequence" else max(per_row, default=1)
         if "input_features" in features[0]:
             feats = np.stack([np.asarray(f["input_features"], dtype=np.float32) for f in features])
             batch["input_features"] = torch.from_numpy(feats).to(self.device)

@@ -336,3 +336,5 @@ def test_collator_reports_the_last_labelled_position():
     last = int((b["labels"] != -100).any(0).nonzero().max())
     assert b["valid_len"] == last + 1 == 5
     assert "valid_len" not in DataCollatorSpeechSeq2SeqWithPadding(max_target_length=16, device="cpu")(feats)
+    per = DataCollatorSpeechSeq2SeqWithPadding(max_target_length=16, device="cpu", report_valid_len="per_sequence")(feats)
+    assert per["valid_len"] == [1 + int((row != -100).nonzero().max()) for row in per["labels"]] == [5, 3]
