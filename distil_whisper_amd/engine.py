@@ -254,13 +254,15 @@ class WhisperEngine:
         self.pad_lm_rows = True             # training passes: zero pad rows behind hf / logits for the LM-head backward
 
     # ---- helpers -------------------------------------------------------------------------------------------------
-    def act(self, rows, cols, dtype=None):
+    def act(self, rows, cols, dtype=None, zero_pad=True):
         """Activation buffer with rows padded to a multiple of 64 and the pad rows zeroed: the weight-gradient GEMMs
-        contract over the token dimension in K-steps of 64 and must see zeros there."""
+        contract over the token dimension in K-steps of 64 and must see zeros there.  zero_pad=False (forward-only
+        passes: nothing contracts over the rows) leaves the pad rows as they are -- a decoder pass of the frozen
+        teacher was ~350 five-microsecond fill launches otherwise."""
         dtype = self.lowp if dtype is None else dtype
         rp = _rup(rows, 64)
         t = self.ops.empty((rp, cols), dtype)
-        if rp > rows:
+        if rp > rows and zero_pad:
             t[rows:].zero_()
         return t
 
@@ -271,7 +273,7 @@ class WhisperEngine:
         return Rg if Rg - R <= R * self.pad_gemm_rows_slack else R
 
     def _ln(self, name, x, R, save, rows_alloc=None):
-        y = self.act(R if rows_alloc is None else rows_alloc, x.shape[1])
+        y = self.act(R if rows_alloc is None else rows_alloc, x.shape[1], zero_pad=save)
         _, mu, rs = self.ops.layernorm_fwd(x[:R] if x.shape[0] != R else x, self.st.p[f"{name}.weight"],
                                            self.st.p[f"{name}.bias"], 1e-5, save_stats=save, out=y[:R])
         return y, mu, rs
@@ -375,12 +377,12 @@ class WhisperEngine:
         R1, R = B * T, B * T // 2
         L = T // 2
         ctx = {"B": B, "T": T, "R": R, "layers": []} if save else None
-        xcol1 = self.act(R1, st.kpad1)
+        xcol1 = self.act(R1, st.kpad1, zero_pad=save)
         ops.im2col_mel(mel, st.kpad1, out=xcol1[:R1])
-        a1 = self.act(R1, D)
+        a1 = self.act(R1, D, zero_pad=save)
         _, z1 = ops.gemm(xcol1[:R1], st.conv1_packed, bias=st.p["model.encoder.conv1.bias"], act=1, want_z=True,
                          out=a1[:R1])
-        xcol2 = self.act(R, 3 * D)
+        xcol2 = self.act(R, 3 * D, zero_pad=save)
         ops.im2col_s2(a1[:R1], B, T, out=xcol2[:R])
         x = ops.empty((R, D), self.stream)
         _, z2 = ops.gemm(xcol2[:R], st.conv2_packed, bias=st.p["model.encoder.conv2.bias"], act=1, want_z=True,
@@ -414,7 +416,7 @@ class WhisperEngine:
 
         def attend(q_src, k, v, Lkv, is_causal, cols):
             """q_src [>= R, cols] with the queries in its first D columns -> o [Rg, D]"""
-            o = self.act(Rg, D)
+            o = self.act(Rg, D, zero_pad=save)
             if live is None:
                 _, lse = ops.attn_fwd(q_src[:R, :D], k, v, B, H, L, Lkv, is_causal, 0.125, out=o[:R])
                 return o, lse
@@ -423,7 +425,7 @@ class WhisperEngine:
             # scatter target is a buffer of this engine that starts zeroed and only ever receives projected rows.
             qp = self._scatter_buf(Rp, cols)
             ops.scatter_rows(q_src[:R], live.idx, qp)
-            op = self.act(Rp, D)
+            op = self.act(Rp, D, zero_pad=False)
             kk, vv = (qp[:Rp, D:2 * D], qp[:Rp, 2 * D:]) if k is None else (k, v)
             ops.attn_fwd(qp[:Rp, :D], kk, vv, B, H, L, Lkv, is_causal, 0.125, out=op[:Rp])
             ops.gather_rows(op, live.idx, o)
@@ -431,7 +433,7 @@ class WhisperEngine:
         # --- self attention
         av = st.attn_views(f"{p}.self_attn")
         h, mu, rs = self._ln(f"{p}.self_attn_layer_norm", x, R, save, Rg)
-        qkv = self.act(Rg, 3 * D)
+        qkv = self.act(Rg, 3 * D, zero_pad=save)
         ops.gemm(h[:Rg], av["wqkv"], bias=av["bqkv"], out=qkv[:Rg])
         if live is None:
             o, lse = attend(qkv, qkv[:R, D:2 * D], qkv[:R, 2 * D:], L, causal, 3 * D)
@@ -446,9 +448,9 @@ class WhisperEngine:
             cv = st.attn_views(f"{p}.encoder_attn")
             Re = B * Lk
             h, mu, rs = self._ln(f"{p}.encoder_attn_layer_norm", x, R, save, Rg)
-            q = self.act(Rg, D)
+            q = self.act(Rg, D, zero_pad=save)
             ops.gemm(h[:Rg], cv["wqkv"][:D], bias=cv["bqkv"][:D], out=q[:Rg])
-            kv = self.act(Re, 2 * D)
+            kv = self.act(Re, 2 * D, zero_pad=save)
             ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=kv[:Re])
             o, lse = attend(q, kv[:Re, :D], kv[:Re, D:], Lk, False, D)
             x1 = ops.gemm(o[:Rg], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
@@ -457,7 +459,7 @@ class WhisperEngine:
             x = x1
         # --- feed forward
         h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save, Rg)
-        a = self.act(Rg, d.ffn)
+        a = self.act(Rg, d.ffn, zero_pad=save)
         res = ops.gemm(h[:Rg], st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1,
                        want_z=("grad" if self.ffn_keeps_gelu_grad else True) if save else False, out=a[:Rg])
         z = res[1] if save else None
@@ -511,7 +513,7 @@ class WhisperEngine:
             hfp, hf = hf, self.act(Rl, d.d_model)
             ops.gather_rows(hfp, live.idx, hf)
             del hfp
-        logits = self.act(Rl, self.ldv)
+        logits = self.act(Rl, self.ldv, zero_pad=save)
         if Rl > Rh:
             hf[Rh:Rl].zero_()
             logits[Rh:Rl].zero_()
