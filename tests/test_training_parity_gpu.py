@@ -438,11 +438,23 @@ def test_large_v3_batch_7_with_the_bench_configuration_matches_the_reference_los
         losses.append(tr.train_step_graphed(feats, ids, labels, lr=0.0).clone())
     torch.cuda.synchronize()
     assert tr._graph["graph"] is not None
+    # the same with the dead decoder positions left out (one length for the batch, then one per sequence: the teacher's
+    # decoder, the LM heads and the loss over the packed live rows), eager and replayed from their own plans
+    lens = [int((row != -100).nonzero().max()) + 1 for row in labels.cpu()]
+    assert max(lens) < 447 and sum(lens) < 0.9 * B * max(lens)
+    for vl in (max(lens), lens):
+        for _ in range(3):
+            losses.append(tr.train_step_graphed(feats, ids, labels, lr=0.0, valid_len=vl).clone())
+        torch.cuda.synchronize()
+        assert tr._graph["graph"] is not None
+    assert len(tr._graphs) == 3
     for i, l in enumerate(losses):
         l = l.cpu()
         for name, idx, tol in (("ce", 0, 1e-3), ("kl", 1, 1e-2), ("loss", 2, 1e-3)):
             for ref in (float(g[f"{name}_fp32"]), float(g[f"{name}_bf16"])):
                 assert abs(l[idx].item() - ref) < tol * abs(ref), (i, name, l[idx].item(), ref)
+        assert l[3].item() == losses[0][3].item()
+        assert relerr(l[:3], losses[0][:3].cpu()) < 1e-4, (i, l, losses[0])
         assert l[3].item() == float((labels != -100).sum())
     assert torch.equal(losses[0], losses[1])               # lr = 0: the same step three times (weights unchanged)
     assert relerr(losses[2][:3], losses[0][:3]) < 1e-6
