@@ -15,9 +15,16 @@ del t_sd, s_sd
 B, T = 32, 447
 audio = 0.1 * torch.randn(B, 480000, device=dev)
 ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
-dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
+dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone()
+# DW_LENS=1: the bench's label lengths (U{32..224}) and the step over the live decoder rows only (bench.py's default)
+if os.environ.get("DW_LENS"):
+    lens = torch.randint(32, 225, (B,), generator=torch.Generator().manual_seed(1234)).tolist()
+    labels[torch.arange(T, device=dev)[None, :] >= torch.tensor(lens, device=dev)[:, None]] = -100
+else:
+    lens = None
+    labels[:, 200:] = -100
 def step():
-    return tr.train_step(tr.features(audio), dec_in, labels)
+    return tr.train_step(tr.features(audio), dec_in, labels, valid_len=lens)
 # (GEMM variant, strip[, attention-backward mode]); variant 3 = default, 4 = phase-pipelined kernel; strip 0 = auto rule;
 # attention mode = dw_debug_set key 3 (default 1)
 configs = eval(os.environ.get("DW_AB", "[(115,0,5),(2163,0,5)]"))
