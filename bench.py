@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="teacher forward and weight-gradient GEMMs on their own HIP streams (round 2's default; since the "
                          "round-3 epilogue work the single-stream step is ~1 %% faster in the same-process A/B, `ab` below)")
-    ap.add_argument("--no-overlap", action="store_true", help="(default now) everything on the main stream")
+    ap.add_argument("--no-overlap", action="store_true", help="everything on the main stream (one rank without either flag: "
+                                                               "decided by a short measurement, see mode_selection)")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="with --overlap: weight-gradient GEMMs of the backward stay on the main stream")
     ap.add_argument("--no-pad-teacher-rows", action="store_true",
@@ -132,10 +133,15 @@ def main():
     s_sd, sdims = si.student_from_teacher(t_sd, tdims, le, ld)
     filt = torch.tensor(si.mel_filter_bank(tdims.n_mels), dtype=torch.float32, device=dev).contiguous()
     recipe = args.mode == "recipe"
+    # side streams: on request; one rank decides by measurement unless told (mode_selection below).  Data-parallel ranks keep
+    # the main stream + the reducer's stream unless --overlap is given: that combination is the one exercised with two
+    # ranks here (over gloo on a shared GPU the three-stream variant ran 12x slower -- gloo's host round trips serialise
+    # the streams; over RCCL it is untested on this pool's one-GPU boxes)
+    side = args.overlap and not args.no_overlap
     tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
-                             mel_filters=filt, overlap_teacher=args.overlap and not (args.no_overlap or args.no_teacher_overlap),
-                             overlap_wgrad=args.overlap and not (args.no_wgrad_overlap or args.no_overlap),
+                             mel_filters=filt, overlap_teacher=side and not args.no_teacher_overlap,
+                             overlap_wgrad=side and not args.no_wgrad_overlap,
                              pad_teacher_rows=not args.no_pad_teacher_rows)
     del t_sd, s_sd
     torch.cuda.empty_cache()
