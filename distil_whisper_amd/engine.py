@@ -272,8 +272,8 @@ class WhisperEngine:
         Rg = _rup(R, 320)
         return Rg if Rg - R <= R * self.pad_gemm_rows_slack else R
 
-    def _ln(self, name, x, R, save, rows_alloc=None):
-        y = self.act(R if rows_alloc is None else rows_alloc, x.shape[1], zero_pad=save)
+    def _ln(self, name, x, R, save, rows_alloc=None, zero_pad=None):
+        y = self.act(R if rows_alloc is None else rows_alloc, x.shape[1], zero_pad=save if zero_pad is None else zero_pad)
         _, mu, rs = self.ops.layernorm_fwd(x[:R] if x.shape[0] != R else x, self.st.p[f"{name}.weight"],
                                            self.st.p[f"{name}.bias"], 1e-5, save_stats=save, out=y[:R])
         return y, mu, rs
@@ -395,7 +395,9 @@ class WhisperEngine:
             x, lc = self._layer_fwd(f"model.encoder.layers.{i}", x, B, L, None, 0, False, save)
             if save:
                 ctx["layers"].append(lc)
-        y, mu, rs = self._ln("model.encoder.layer_norm", x, R, save)
+        # (pad rows zeroed also in a forward-only pass: with a frozen encoder its output is still an operand of the
+        # decoder's k_proj / v_proj weight-gradient GEMMs, which contract over the padded rows -- 0 x NaN from stale memory)
+        y, mu, rs = self._ln("model.encoder.layer_norm", x, R, save, zero_pad=True)
         if save:
             ctx.update(x_final=x, mu=mu, rs=rs, enc_out=y)
         return y, ctx

@@ -28,7 +28,12 @@ class RefOps:
         return x.to(self.lowp)
 
     def empty(self, shape, dtype):
-        return torch.empty(shape, dtype=dtype, device=self.device)
+        # Uninitialised memory is NaN here (floating types), so that the host-logic tests catch any path on which stale
+        # rows of a buffer can reach a result (the HIP allocator hands back whatever the block held before)
+        t = torch.empty(shape, dtype=dtype, device=self.device)
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
 
     def zeros(self, shape, dtype):
         return torch.zeros(shape, dtype=dtype, device=self.device)
