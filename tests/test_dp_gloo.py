@@ -29,7 +29,13 @@ def _make(seed=7):
     g = torch.Generator().manual_seed(seed)
     feats = torch.randn(4, cfg_t.n_mels, 3000, generator=g) * 0.5
     b = wo.synthetic_batch(cfg_t, 4, seed=seed + 1, T=33, with_audio=False)
-    return cfg_t, cfg_s, t_sd, s_sd, feats, b["decoder_input_ids"], b["labels"]
+    labels = b["labels"].clone()
+    for i, n in enumerate(LENS):                 # dead tails of different lengths (rank 0: 20, 9; rank 1: 27, 14)
+        labels[i, n:] = -100
+    return cfg_t, cfg_s, t_sd, s_sd, feats, b["decoder_input_ids"], labels
+
+
+LENS = [20, 9, 27, 14]
 
 
 def _worker(rank, world, port, out_dir):
@@ -42,7 +48,9 @@ def _worker(rank, world, port, out_dir):
     tr.reducer.bucket_elems = 20000  # several buckets
     sl = slice(rank * 2, rank * 2 + 2)
     for _ in range(2):
-        tr.train_step(feats[sl], ids[sl], labels[sl])
+        # every rank leaves out ITS dead decoder positions (different trimmed lengths and packed row counts per rank);
+        # the single-process reference below computes all 33 positions
+        tr.train_step(feats[sl], ids[sl], labels[sl], valid_len=LENS[sl])
     torch.save({"P": tr.student_store.P.clone(), "world": tr.world}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
