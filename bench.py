@@ -199,17 +199,23 @@ def main():
                 ev[i + 1].record()
             torch.cuda.synchronize()
             return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(6))[2]
-        selection = {"hip_graph_single_stream": probe(graph_step, 4)}
+        try:
+            selection = {"hip_graph_single_stream": probe(graph_step, 4)}
+        except Exception as e:      # a box on which the capture fails still gets its measurement from the eager step
+            log(f"HIP-graph capture of the step failed ({type(e).__name__}: {e}); eager steps only")
+            selection = {"hip_graph_single_stream": float("inf")}
+            torch.cuda.synchronize()
         tr.drop_graph()
         torch.cuda.empty_cache()
         tr.overlap_teacher = True
         tr.set_overlap_wgrad(True)
         selection["eager_side_streams"] = probe(eager_step, 2)
-        use_graph = selection["hip_graph_single_stream"] <= selection["eager_side_streams"]
+        use_graph = selection["hip_graph_single_stream"] <= selection["eager_side_streams"]       # (inf: capture failed)
         if use_graph:
             tr.overlap_teacher = False
             tr.set_overlap_wgrad(False)
         one_step = graph_step if use_graph else eager_step
+        selection = {k: (v if v != float("inf") else None) for k, v in selection.items()}
         log("mode selection (median ms of 6 untimed steps): " + json.dumps(selection) +
             f" -> {'hip_graph_single_stream' if use_graph else 'eager_side_streams'}")
     if use_graph:
@@ -277,8 +283,12 @@ def main():
 
     ab = None
     if world == 1 and not args.no_ab:
-        ab = ab_legs(tr, eager_step, graph_step, B, dense=None if args.dense else (lambda: graph_step(None)),
-                     trimmed=(lambda: graph_step(Te)) if isinstance(valid_len, list) else None)
+        try:
+            ab = ab_legs(tr, eager_step, graph_step, B, dense=None if args.dense else (lambda: graph_step(None)),
+                         trimmed=(lambda: graph_step(Te)) if isinstance(valid_len, list) else None)
+        except Exception as e:       # (the legs are extra information: the timed result above is reported regardless)
+            ab = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
         log("A/B (median ms/step over 10 steps, same process): " + json.dumps(ab))
     tr.drop_graph()
     torch.cuda.empty_cache()
@@ -335,7 +345,7 @@ def main():
                ("_side_streams" if (tr.overlap_teacher or tr.student.wgrad_stream is not None) else "_single_stream"),
                "mode_selection": selection, "step_stats": step_stats,
                "ab": ab, "roofline": roofline, "cpu_baseline": cpu_baseline}
-        if ab and "hip_graph_all_447_decoder_positions" in ab:
+        if ab and "hip_graph_all_447_decoder_positions" in ab and "error" not in ab:
             # the step exactly as the reference shapes it (every padded decoder position computed), same process
             d447 = ab["hip_graph_all_447_decoder_positions"]
             out["all_447_decoder_positions"] = {"ms_per_step": d447["median_ms"], "value": d447["audio_s_per_s"],
