@@ -293,8 +293,7 @@ def main():
     tr.drop_graph()
     torch.cuda.empty_cache()
 
-    roofline = None
-    if not args.no_roofline:
+    def roofline_leg():
         ops.profile = {}
         overlap, tr.overlap_teacher = tr.overlap_teacher, False   # one kernel at a time for the per-launch events
         wgrad_overlap = tr.student.wgrad_stream is not None
@@ -311,7 +310,7 @@ def main():
         if prof:
             key = max(prof, key=lambda k: prof[k]["ms"])
             p = prof[key]
-            roofline = {"bound": "mfma", "kernel": key, "launches": p["n"],
+            return {"bound": "mfma", "kernel": key, "launches": p["n"],
                         "avg_launch_ms": p["ms"] / p["n"], "flops_per_launch": p["flops"] / p["n"],
                         "achieved": p["flops"] / (p["ms"] * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
@@ -322,6 +321,16 @@ def main():
                         max(sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9,
                         "attn_ms": sum(v["ms"] for k, v in prof.items() if k.startswith("attn")),
                         "step_ms_instrumented": sum(v["ms"] for v in prof.values())}
+        return None
+
+    roofline = None
+    if not args.no_roofline:
+        try:
+            roofline = roofline_leg()
+        except Exception as e:         # (extra information: the timed result is reported regardless)
+            ops.profile = None
+            roofline = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
