@@ -596,8 +596,8 @@ class WhisperForConditionalGeneration(nn.Module):
                           ("prefix_allowed_tokens_fn", prefix_allowed_tokens_fn), ("monitor_progress", monitor_progress)):
             if val is not None and (not hasattr(val, "__len__") or len(val) > 0):
                 raise NotImplementedError(f"generate({name}=...) is not implemented on the MI355X engine path")
-        if return_token_timestamps or return_segments:
-            raise NotImplementedError("return_token_timestamps / return_segments are not implemented on the MI355X path")
+        if return_token_timestamps:
+            raise NotImplementedError("return_token_timestamps is not implemented on the MI355X path")
         temps = list(temperature) if isinstance(temperature, (list, tuple)) else [temperature]
         fallback_args = dict(temperatures=temps, compression_ratio_threshold=compression_ratio_threshold,
                              logprob_threshold=logprob_threshold, no_speech_threshold=no_speech_threshold,
@@ -654,12 +654,19 @@ class WhisperForConditionalGeneration(nn.Module):
                     "You have passed more than 3000 mel input features (> 30 seconds) which automatically enables "
                     "long-form generation which requires the model to predict timestamp tokens. Please either pass "
                     "`return_timestamps=True` or make sure to pass no more than 3000 mel input features.")
+            if prompt_condition_type is not None:
+                if prompt_condition_type not in ("first-segment", "all-segments"):
+                    raise ValueError("`prompt_condition_type` must be either 'first-segment' or 'all-segments'")
+                gc.prompt_condition_type = prompt_condition_type
             if frames > 2 * d.max_src or (rt and not force_unique_generate_call):
                 # the reference's seek loop (TF:784-903): with timestamps every window is decoded until its audio is
                 # consumed, also when the input is a single 30 s window (run_pseudo_labelling.py:861-996 calls it so)
                 return self._generate_seek_loop(input_features, attention_mask, gc, language, task, is_multilingual,
                                                 prompt_ids, kwargs, use_graphs, return_dict_in_generate, num_beams,
-                                                fallback_args)
+                                                fallback_args, return_segments)
+            if return_segments:
+                raise NotImplementedError("return_segments comes with the timestamp seek loop (return_timestamps=True) "
+                                          "on the MI355X path")
             if uses_fallback:
                 raise NotImplementedError("temperature fallback / condition_on_prev_tokens are implemented for the "
                                           "timestamp seek loop (return_timestamps=True) only on the MI355X path")
@@ -778,7 +785,7 @@ class WhisperForConditionalGeneration(nn.Module):
     def seek_decode(self, input_features, max_frames, init_tokens, lengths, eos, pad, no_timestamps_token_id,
                     max_initial_timestamp_index=None, suppress_tokens=None, begin_suppress_tokens=None,
                     detect_language=None, temperatures=(0.0,), compression_ratio_threshold=None, logprob_threshold=None,
-                    no_speech_threshold=None, condition_on_prev_tokens=False, prev_sot_token_id=None):
+                    no_speech_threshold=None, condition_on_prev_tokens=False, prev_sot_token_id=None, prompt_ids=None):
         """The seek loop itself (TF:generation_whisper.py:784-903): input_features [B, n_mels, frames], max_frames[b] =
         valid mel frames of utterance b.  init_tokens: the decoder prompt rows (list of B lists) or a callable(detect)
         building them (detect() = language ids from the first window); lengths(P) -> (max_new_tokens, min_new_tokens)
@@ -792,6 +799,10 @@ class WhisperForConditionalGeneration(nn.Module):
             again at the next temperature (sampling; the random stream is this process's, not the reference's);
             `no_speech_threshold`: P(<|nospeech|>) after <|startoftranscript|> above it together with a low average
             log-probability skips the window.  The scores are recomputed by one teacher-forced decoder pass.
+          * prompt_ids (`processor.get_prompt_ids`, run_eval.py:709-710; prompt_condition_type "first-segment"): without
+            conditioning on previous tokens the prompt precedes the decoder prompt of EVERY window (TF:1909-1911); with
+            it the prompt is the utterance's segment zero (TF:1119-1123), so it conditions the following windows like
+            any earlier text until the 223-token cut-off pushes it out, and is dropped from the result (TF:906-910).
         -> per utterance the list of segments {"start", "end", "tokens"}."""
         import math
         import zlib
@@ -901,6 +912,10 @@ class WhisperForConditionalGeneration(nn.Module):
             return len(raw) / len(zlib.compress(raw))
 
         segments = [[] for _ in range(B)]
+        prompt = [int(x) for x in prompt_ids] if prompt_ids is not None else None
+        if prompt:
+            body = prompt[1:] if (prev_sot is not None and prompt[0] == prev_sot) else prompt
+            segments = [[{"tokens": list(body)}] for _ in range(B)]
         do_cond = [bool(condition_on_prev_tokens)] * B
         if not hasattr(self, "_seek_decoders"):
             self._seek_decoders = {}           # reused by later calls (pseudo-labelling decodes batch after batch)
@@ -924,6 +939,8 @@ class WhisperForConditionalGeneration(nn.Module):
                             pre += tk[:-1] if (len(tk) > 2 and tk[-2] >= tb) else tk
                         pre = pre[-cut_off:]
                     pre = [prev_sot] + pre
+                elif prompt:
+                    pre = list(prompt)
                 prompts[b] = pre + list(init[b])
             accepted = {}
             # (the reference left-pads the batch to its longest prompt and derives the lengths from that, TF:835-840)
@@ -987,25 +1004,30 @@ class WhisperForConditionalGeneration(nn.Module):
                 segs, offset = G.retrieve_segment(seq, tb, snf[b], time_offset=seek[b] * 0.01)
                 seek[b] += offset
                 segments[b] += segs
-        return segments
+        return [sg[1:] for sg in segments] if prompt else segments
 
     def _generate_seek_loop(self, input_features, attention_mask, gc, language, task, is_multilingual, prompt_ids, kwargs,
-                            use_graphs, return_dict_in_generate, num_beams, fallback_args=None):
+                            use_graphs, return_dict_in_generate, num_beams, fallback_args=None, return_segments=False):
         """Timestamp-driven multi-pass transcription: `WhisperGenerationMixin.generate` steps 5-7 (TF:745-968) with
         temperature 0 and no fallback thresholds -- every utterance keeps a `seek` position in mel frames; each pass
         decodes the next <= 30 s window of every unfinished utterance with the timestamp rules, `retrieve_segment`
         splits the tokens at consecutive timestamp pairs and advances `seek` to the last predicted end of segment (or
         past the window).  Inputs of any length ([B, n_mels, frames]; batches of long inputs need `attention_mask`).
         Returns the concatenated segment tokens per utterance, right-padded with pad_token_id (the reference's plain
-        return value), or a GenerateOutput with `.sequences` and `.segments`."""
+        return value), a GenerateOutput with `.sequences` and `.segments` (return_dict_in_generate), or -- with
+        `return_segments=True`, like the reference (TF:generate, "8. If we return all segments") -- a plain dict
+        {"sequences", "segments"}: per utterance the list of {"start", "end", "tokens"} in seconds / token ids (the
+        reference's entries also carry the raw GenerationMixin output of their window under "result" and "idxs")."""
         from . import generation as G
         eng, d = self.engine, self.dims
         B, _, frames = input_features.shape
         dev = input_features.device
         W = 2 * d.max_src
-        if prompt_ids is not None or kwargs.get("decoder_input_ids") is not None:
-            raise NotImplementedError("prompt_ids / decoder_input_ids with the timestamp seek loop are not implemented on "
-                                      "the MI355X path (pass force_unique_generate_call=True for a single window)")
+        if kwargs.get("decoder_input_ids") is not None:
+            raise NotImplementedError("decoder_input_ids with the timestamp seek loop are not implemented on the MI355X "
+                                      "path (pass prompt_ids, or force_unique_generate_call=True for a single window)")
+        if prompt_ids is not None and getattr(gc, "prompt_condition_type", "first-segment") == "all-segments":
+            raise NotImplementedError("prompt_condition_type='all-segments' is not implemented on the MI355X path")
         if kwargs.get("assistant_model") is not None or num_beams != 1 or kwargs.get("use_cache", True) is False:
             raise NotImplementedError("the timestamp seek loop runs greedy search on the KV-cache decoder only")
         if not hasattr(gc, "no_timestamps_token_id"):
@@ -1044,6 +1066,7 @@ class WhisperForConditionalGeneration(nn.Module):
                                     list(gc.suppress_tokens) if gc.suppress_tokens else None,
                                     list(gc.begin_suppress_tokens) if gc.begin_suppress_tokens else None,
                                     detect_language=detect_on, prev_sot_token_id=getattr(gc, "prev_sot_token_id", None),
+                                    prompt_ids=(prompt_ids.tolist() if torch.is_tensor(prompt_ids) else prompt_ids),
                                     **(fallback_args or {}))
         rows_out = [[tok for sg in segments[b] for tok in sg["tokens"]] for b in range(B)]
         width = max((len(r) for r in rows_out), default=0)
@@ -1051,6 +1074,8 @@ class WhisperForConditionalGeneration(nn.Module):
         for b, r in enumerate(rows_out):
             if r:
                 seqs[b, :len(r)] = torch.as_tensor(r, dtype=torch.long, device=dev)
+        if return_segments:
+            return {"sequences": seqs, "segments": segments}
         if return_dict_in_generate or getattr(gc, "return_dict_in_generate", False):
             out = G.GenerateOutput(seqs)
             out.segments = segments

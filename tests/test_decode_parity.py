@@ -260,6 +260,28 @@ def test_timestamp_seek_loop_matches_transformers_live():
             out = model.generate(feats, return_dict_in_generate=True, **kw)
             assert out.sequences.tolist() == ref.tolist(), (seed, kw)
             multi += max(len(s) for s in out.segments) > 1
+            # return_segments=True: the reference's {"sequences", "segments"} with the same start / end / tokens per segment
+            with torch.no_grad():
+                rs = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, return_segments=True, **kw)
+            mine = model.generate(feats, return_segments=True, **kw)
+            assert isinstance(mine, dict) and mine["sequences"].tolist() == rs["sequences"].tolist()
+            assert len(mine["segments"]) == len(rs["segments"])
+            for got_row, ref_row in zip(mine["segments"], rs["segments"]):
+                assert len(got_row) == len(ref_row)
+                for gs, hs in zip(got_row, ref_row):
+                    assert list(gs["tokens"]) == hs["tokens"].tolist()
+                    assert abs(float(gs["start"]) - float(hs["start"])) < 1e-6 and abs(float(gs["end"]) - float(hs["end"])) < 1e-6
+            # prompt_ids (run_eval.py:709-710 passes them to long-form generate too): in front of every window's decoder
+            # prompt without conditioning; segment zero of the utterance with condition_on_prev_tokens
+            pid = torch.tensor([fields["prev_sot_token_id"], 31, 32, 33])
+            for extra in ({}, {"condition_on_prev_tokens": True}):
+                with torch.no_grad():
+                    rp = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, prompt_ids=pid, return_segments=True,
+                                                                         **kw, **extra)
+                mp = model.generate(feats, prompt_ids=pid, return_segments=True, **kw, **extra)
+                assert mp["sequences"].tolist() == rp["sequences"].tolist(), (seed, kw, extra)
+                assert [[list(sg["tokens"]) for sg in row] for row in mp["segments"]] == \
+                       [[sg["tokens"].tolist() for sg in row] for row in rp["segments"]]
     assert multi >= 4                                  # the loop really ran several passes
     # the segment rule on its own (TF `_retrieve_segment`): pairs, single ending, no timestamps, empty
     tb = 100
