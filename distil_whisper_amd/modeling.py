@@ -785,7 +785,8 @@ class WhisperForConditionalGeneration(nn.Module):
     def seek_decode(self, input_features, max_frames, init_tokens, lengths, eos, pad, no_timestamps_token_id,
                     max_initial_timestamp_index=None, suppress_tokens=None, begin_suppress_tokens=None,
                     detect_language=None, temperatures=(0.0,), compression_ratio_threshold=None, logprob_threshold=None,
-                    no_speech_threshold=None, condition_on_prev_tokens=False, prev_sot_token_id=None, prompt_ids=None):
+                    no_speech_threshold=None, condition_on_prev_tokens=False, prev_sot_token_id=None, prompt_ids=None,
+                    prompt_all_segments=False):
         """The seek loop itself (TF:generation_whisper.py:784-903): input_features [B, n_mels, frames], max_frames[b] =
         valid mel frames of utterance b.  init_tokens: the decoder prompt rows (list of B lists) or a callable(detect)
         building them (detect() = language ids from the first window); lengths(P) -> (max_new_tokens, min_new_tokens)
@@ -802,7 +803,9 @@ class WhisperForConditionalGeneration(nn.Module):
           * prompt_ids (`processor.get_prompt_ids`, run_eval.py:709-710; prompt_condition_type "first-segment"): without
             conditioning on previous tokens the prompt precedes the decoder prompt of EVERY window (TF:1909-1911); with
             it the prompt is the utterance's segment zero (TF:1119-1123), so it conditions the following windows like
-            any earlier text until the 223-token cut-off pushes it out, and is dropped from the result (TF:906-910).
+            any earlier text until the 223-token cut-off pushes it out, and is dropped from the result (TF:906-910);
+            prompt_all_segments (prompt_condition_type "all-segments", needs condition_on_prev_tokens): the prompt takes
+            the place of <|startofprev|> in front of the previous tokens of every window (TF:1887-1888).
         -> per utterance the list of segments {"start", "end", "tokens"}."""
         import math
         import zlib
@@ -913,7 +916,8 @@ class WhisperForConditionalGeneration(nn.Module):
 
         segments = [[] for _ in range(B)]
         prompt = [int(x) for x in prompt_ids] if prompt_ids is not None else None
-        if prompt:
+        first_segment_prompt = bool(prompt) and not prompt_all_segments
+        if first_segment_prompt:
             body = prompt[1:] if (prev_sot is not None and prompt[0] == prev_sot) else prompt
             segments = [[{"tokens": list(body)}] for _ in range(B)]
         do_cond = [bool(condition_on_prev_tokens)] * B
@@ -938,7 +942,7 @@ class WhisperForConditionalGeneration(nn.Module):
                             tk = sg["tokens"]
                             pre += tk[:-1] if (len(tk) > 2 and tk[-2] >= tb) else tk
                         pre = pre[-cut_off:]
-                    pre = [prev_sot] + pre
+                    pre = (list(prompt) if (prompt and prompt_all_segments) else [prev_sot]) + pre
                 elif prompt:
                     pre = list(prompt)
                 prompts[b] = pre + list(init[b])
@@ -1004,7 +1008,7 @@ class WhisperForConditionalGeneration(nn.Module):
                 segs, offset = G.retrieve_segment(seq, tb, snf[b], time_offset=seek[b] * 0.01)
                 seek[b] += offset
                 segments[b] += segs
-        return [sg[1:] for sg in segments] if prompt else segments
+        return [sg[1:] for sg in segments] if first_segment_prompt else segments
 
     def _generate_seek_loop(self, input_features, attention_mask, gc, language, task, is_multilingual, prompt_ids, kwargs,
                             use_graphs, return_dict_in_generate, num_beams, fallback_args=None, return_segments=False):
@@ -1026,8 +1030,10 @@ class WhisperForConditionalGeneration(nn.Module):
         if kwargs.get("decoder_input_ids") is not None:
             raise NotImplementedError("decoder_input_ids with the timestamp seek loop are not implemented on the MI355X "
                                       "path (pass prompt_ids, or force_unique_generate_call=True for a single window)")
-        if prompt_ids is not None and getattr(gc, "prompt_condition_type", "first-segment") == "all-segments":
-            raise NotImplementedError("prompt_condition_type='all-segments' is not implemented on the MI355X path")
+        all_segments = getattr(gc, "prompt_condition_type", "first-segment") == "all-segments"
+        if all_segments and not (fallback_args or {}).get("condition_on_prev_tokens"):
+            raise ValueError("Make sure to set `condition_on_prev_tokens=True` when setting "
+                             "`prompt_condition_type='all-segments'`.")
         if kwargs.get("assistant_model") is not None or num_beams != 1 or kwargs.get("use_cache", True) is False:
             raise NotImplementedError("the timestamp seek loop runs greedy search on the KV-cache decoder only")
         if not hasattr(gc, "no_timestamps_token_id"):
@@ -1067,6 +1073,7 @@ class WhisperForConditionalGeneration(nn.Module):
                                     list(gc.begin_suppress_tokens) if gc.begin_suppress_tokens else None,
                                     detect_language=detect_on, prev_sot_token_id=getattr(gc, "prev_sot_token_id", None),
                                     prompt_ids=(prompt_ids.tolist() if torch.is_tensor(prompt_ids) else prompt_ids),
+                                    prompt_all_segments=all_segments and prompt_ids is not None,
                                     **(fallback_args or {}))
         rows_out = [[tok for sg in segments[b] for tok in sg["tokens"]] for b in range(B)]
         width = max((len(r) for r in rows_out), default=0)

@@ -274,7 +274,8 @@ def test_timestamp_seek_loop_matches_transformers_live():
             # prompt_ids (run_eval.py:709-710 passes them to long-form generate too): in front of every window's decoder
             # prompt without conditioning; segment zero of the utterance with condition_on_prev_tokens
             pid = torch.tensor([fields["prev_sot_token_id"], 31, 32, 33])
-            for extra in ({}, {"condition_on_prev_tokens": True}):
+            for extra in ({}, {"condition_on_prev_tokens": True},
+                          {"condition_on_prev_tokens": True, "prompt_condition_type": "all-segments"}):
                 with torch.no_grad():
                     rp = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, prompt_ids=pid, return_segments=True,
                                                                          **kw, **extra)
@@ -282,6 +283,8 @@ def test_timestamp_seek_loop_matches_transformers_live():
                 assert mp["sequences"].tolist() == rp["sequences"].tolist(), (seed, kw, extra)
                 assert [[list(sg["tokens"]) for sg in row] for row in mp["segments"]] == \
                        [[sg["tokens"].tolist() for sg in row] for row in rp["segments"]]
+    with pytest.raises(ValueError, match="condition_on_prev_tokens=True"):
+        model.generate(feats, prompt_ids=pid, prompt_condition_type="all-segments", **kw)
     assert multi >= 4                                  # the loop really ran several passes
     # the segment rule on its own (TF `_retrieve_segment`): pairs, single ending, no timestamps, empty
     tb = 100
