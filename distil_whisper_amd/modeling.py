@@ -786,7 +786,7 @@ class WhisperForConditionalGeneration(nn.Module):
                     max_initial_timestamp_index=None, suppress_tokens=None, begin_suppress_tokens=None,
                     detect_language=None, temperatures=(0.0,), compression_ratio_threshold=None, logprob_threshold=None,
                     no_speech_threshold=None, condition_on_prev_tokens=False, prev_sot_token_id=None, prompt_ids=None,
-                    prompt_all_segments=False):
+                    prompt_all_segments=False, num_beams=1, length_penalty=1.0, early_stopping=False):
         """The seek loop itself (TF:generation_whisper.py:784-903): input_features [B, n_mels, frames], max_frames[b] =
         valid mel frames of utterance b.  init_tokens: the decoder prompt rows (list of B lists) or a callable(detect)
         building them (detect() = language ids from the first window); lengths(P) -> (max_new_tokens, min_new_tokens)
@@ -805,7 +805,10 @@ class WhisperForConditionalGeneration(nn.Module):
             it the prompt is the utterance's segment zero (TF:1119-1123), so it conditions the following windows like
             any earlier text until the 223-token cut-off pushes it out, and is dropped from the result (TF:906-910);
             prompt_all_segments (prompt_condition_type "all-segments", needs condition_on_prev_tokens): the prompt takes
-            the place of <|startofprev|> in front of the previous tokens of every window (TF:1887-1888).
+            the place of <|startofprev|> in front of the previous tokens of every window (TF:1887-1888);
+          * num_beams > 1 (run_eval.py:693 / run_pseudo_labelling.py `--generation_num_beams`): the temperature-0 pass of a
+            window is a beam search (decoding.beam_search_decode with the timestamp rules); sampled fallback passes use
+            one beam like the reference (TF:1010-1012).  The score-based thresholds (logprob / no-speech) are greedy-only.
         -> per utterance the list of segments {"start", "end", "tokens"}."""
         import math
         import zlib
@@ -838,6 +841,9 @@ class WhisperForConditionalGeneration(nn.Module):
         if prev_sot is None and suppress_tokens is not None and len(suppress_tokens) >= 2:
             prev_sot = suppress_tokens[-2]
         need_scores = logprob_threshold is not None or no_speech_threshold is not None
+        if int(num_beams) > 1 and need_scores:
+            raise NotImplementedError("logprob_threshold / no_speech_threshold with beam search are not implemented on the "
+                                      "MI355X path (the reference scores beams by `sequences_scores`)")
         if no_speech_threshold is not None and logprob_threshold is None:
             raise ValueError("no_speech_threshold needs logprob_threshold (the reference compares both)")
 
@@ -958,6 +964,14 @@ class WhisperForConditionalGeneration(nn.Module):
                     ids = torch.as_tensor([prompts[b] for b in pending], dtype=torch.long, device=dev)
                     if temp > 0.0:
                         out = sample(enc, ids, max_new, min_new, temp)[:, P:].tolist()
+                    elif int(num_beams) > 1:
+                        from .decoding import beam_search_decode
+                        out = beam_search_decode(
+                            eng, enc, ids, max_new, int(num_beams), eos, pad_token_id=pad, suppress_tokens=suppress_tokens,
+                            begin_suppress_tokens=begin_suppress_tokens, min_new_tokens=min_new,
+                            length_penalty=float(length_penalty), early_stopping=early_stopping,
+                            timestamp_rules=dict(begin_index=P, no_timestamps_token_id=nts,
+                                                 max_initial_timestamp_index=max_initial_timestamp_index))[:, P:].tolist()
                     else:
                         key = (len(pending), P, max_new, eos, pad, nts, max_initial_timestamp_index,
                                tuple(suppress_tokens or ()), tuple(begin_suppress_tokens or ()))
@@ -1034,8 +1048,8 @@ class WhisperForConditionalGeneration(nn.Module):
         if all_segments and not (fallback_args or {}).get("condition_on_prev_tokens"):
             raise ValueError("Make sure to set `condition_on_prev_tokens=True` when setting "
                              "`prompt_condition_type='all-segments'`.")
-        if kwargs.get("assistant_model") is not None or num_beams != 1 or kwargs.get("use_cache", True) is False:
-            raise NotImplementedError("the timestamp seek loop runs greedy search on the KV-cache decoder only")
+        if kwargs.get("assistant_model") is not None or kwargs.get("use_cache", True) is False:
+            raise NotImplementedError("the timestamp seek loop runs greedy / beam search on the KV-cache decoder only")
         if not hasattr(gc, "no_timestamps_token_id"):
             raise ValueError("You are trying to return timestamps, but the generation config is not properly set. Make "
                              "sure to initialize the generation config with the correct attributes that are needed "
@@ -1074,6 +1088,9 @@ class WhisperForConditionalGeneration(nn.Module):
                                     detect_language=detect_on, prev_sot_token_id=getattr(gc, "prev_sot_token_id", None),
                                     prompt_ids=(prompt_ids.tolist() if torch.is_tensor(prompt_ids) else prompt_ids),
                                     prompt_all_segments=all_segments and prompt_ids is not None,
+                                    num_beams=num_beams,
+                                    length_penalty=1.0 if getattr(gc, "length_penalty", None) is None else gc.length_penalty,
+                                    early_stopping=getattr(gc, "early_stopping", False) or False,
                                     **(fallback_args or {}))
         rows_out = [[tok for sg in segments[b] for tok in sg["tokens"]] for b in range(B)]
         width = max((len(r) for r in rows_out), default=0)

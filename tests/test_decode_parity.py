@@ -283,6 +283,10 @@ def test_timestamp_seek_loop_matches_transformers_live():
                 assert mp["sequences"].tolist() == rp["sequences"].tolist(), (seed, kw, extra)
                 assert [[list(sg["tokens"]) for sg in row] for row in mp["segments"]] == \
                        [[sg["tokens"].tolist() for sg in row] for row in rp["segments"]]
+            # beam search inside the loop (run_eval.py:693 `--generation_num_beams`)
+            with torch.no_grad():
+                rb = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, num_beams=2, **kw)
+            assert model.generate(feats, num_beams=2, **kw).tolist() == rb.tolist(), (seed, kw, "beams")
     with pytest.raises(ValueError, match="condition_on_prev_tokens=True"):
         model.generate(feats, prompt_ids=pid, prompt_condition_type="all-segments", **kw)
     assert multi >= 4                                  # the loop really ran several passes
