@@ -154,7 +154,7 @@ class GreedyDecoder:
 
 def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_ids, max_new_tokens,
                            num_assistant_tokens=5, eos_token_id=None, suppress_tokens=None, min_new_tokens=0,
-                           pad_token_id=None, use_cache=True):
+                           pad_token_id=None, use_cache=True, timestamp_rules=None):
     """Speculative (assisted) greedy decoding: the small `assistant` engine drafts `num_assistant_tokens` tokens, the
     `target` engine scores all of them in ONE decoder pass and keeps the longest draft prefix that equals its own
     greedy choices plus its next token -- the output is token-for-token what target-only greedy decoding produces.
@@ -165,7 +165,9 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
     prompt_ids int64 [B, P].  With a batch the accepted length is the minimum over the rows that are still running
     (every emitted token is still each row's own greedy token).  suppress_tokens / min_new_tokens are the target's
     logits rules (SuppressTokensLogitsProcessor, MinNewTokensLengthLogitsProcessor); finished rows are filled with
-    pad_token_id.
+    pad_token_id.  timestamp_rules (dict(begin_index, no_timestamps_token_id, max_initial_timestamp_index)): the
+    WhisperTimeStampLogitsProcessor rules on every scored position, for the drafts and for the verification alike (the
+    reference hands the same processors to the candidate generator): `return_timestamps=True` with an assistant.
 
     use_cache: both models keep KV caches.  The target verifies with `decode_multi` -- only the tokens it has not
     consumed yet (last accepted + drafts) go through the decoder, against the cached keys/values with the
@@ -193,8 +195,9 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
             sup[V] = m
         return sup[V]
 
-    def pick(logits, d, first_pos):
-        """greedy tokens from scores [B, n, V] whose row j predicts the token at sequence index first_pos + j"""
+    def pick(logits, d, first_pos, hist=None):
+        """greedy tokens from scores [B, n, V] whose row j predicts the token at sequence index first_pos + j (hist: the
+        sequence those positions continue, at least first_pos + n - 1 tokens: history of the timestamp rules)"""
         sc = logits.float()
         m = sup_mask(d.vocab)
         if m is not None:
@@ -204,6 +207,12 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
             sc = sc.clone()
             sc[:, :, eos_token_id] = torch.where((gen_idx < min_new_tokens)[None, :], float("-inf"),
                                                  sc[:, :, eos_token_id])
+        if timestamp_rules is not None:
+            tr = timestamp_rules
+            sc = torch.stack([apply_timestamp_rules(sc[:, j], hist, first_pos + j, int(tr["begin_index"]),
+                                                    int(tr["no_timestamps_token_id"]), eos_token_id,
+                                                    tr.get("max_initial_timestamp_index"))
+                              for j in range(sc.shape[1])], 1)
         return sc.argmax(-1)
 
     def scores_nocache(eng, d, seq, enc, first):
@@ -232,13 +241,13 @@ def assisted_greedy_decode(target, assistant, enc_target, enc_assistant, prompt_
                 sc = scores_cached(assistant, da, ca, draft)[:, -1:]
             else:
                 sc = scores_nocache(assistant, da, draft, enc_assistant, draft.shape[1] - 1)
-            nxt = pick(sc, da, draft.shape[1])[:, -1]
+            nxt = pick(sc, da, draft.shape[1], draft)[:, -1]
             draft = torch.cat([draft, nxt[:, None]], 1)
         if use_cache:
             sc = scores_cached(target, dt, ct, draft)[:, -(k + 1):]
         else:
             sc = scores_nocache(target, dt, draft, enc_target, L - 1)
-        own = pick(sc, dt, L)                                # [B, k + 1]: target's choice after each prefix
+        own = pick(sc, dt, L, draft)                         # [B, k + 1]: target's choice after each prefix
         if k > 0:
             agree = (own[:, :k] == draft[:, L:]) | done[:, None]
             n_ok = int(agree.long().cumprod(1).sum(1).min().item())

@@ -736,8 +736,12 @@ class WhisperForConditionalGeneration(nn.Module):
             # assistant with this model's encoder dimensions re-uses the encoder output (the distilled student keeps
             # a frozen copy of the teacher's encoder); otherwise it encodes the features itself.
             from .decoding import assisted_greedy_decode
-            if gc.return_timestamps:
-                raise NotImplementedError("assistant_model with return_timestamps is not implemented on the MI355X path")
+            a_ts_rules = None
+            if gc.return_timestamps:       # (single window, force_unique_generate_call: the seek loop has its own branch)
+                if eos is None:
+                    raise ValueError("return_timestamps=True needs eos_token_id in the generation config")
+                a_ts_rules = dict(begin_index=P, no_timestamps_token_id=int(gc.no_timestamps_token_id),
+                                  max_initial_timestamp_index=getattr(gc, "max_initial_timestamp_index", None))
             begin_suppress = None          # TF:719-721: the model must be able to return EOS right away
             assistant_model._sync_shadow()
             ad = assistant_model.dims
@@ -752,7 +756,7 @@ class WhisperForConditionalGeneration(nn.Module):
                 getattr(getattr(assistant_model, "generation_config", None), "num_assistant_tokens", None) or 5
             seqs, self.last_drafted, self.last_accepted = assisted_greedy_decode(
                 eng, assistant_model.engine, enc, enc_a, ids, max_new, int(k), eos, suppress_tokens=suppress,
-                min_new_tokens=min_new, pad_token_id=pad)
+                min_new_tokens=min_new, pad_token_id=pad, timestamp_rules=a_ts_rules)
         elif use_cache:
             from .decoding import GreedyDecoder
             ts_rules = None
@@ -786,7 +790,8 @@ class WhisperForConditionalGeneration(nn.Module):
                     max_initial_timestamp_index=None, suppress_tokens=None, begin_suppress_tokens=None,
                     detect_language=None, temperatures=(0.0,), compression_ratio_threshold=None, logprob_threshold=None,
                     no_speech_threshold=None, condition_on_prev_tokens=False, prev_sot_token_id=None, prompt_ids=None,
-                    prompt_all_segments=False, num_beams=1, length_penalty=1.0, early_stopping=False):
+                    prompt_all_segments=False, num_beams=1, length_penalty=1.0, early_stopping=False, assistant=None,
+                    num_assistant_tokens=5):
         """The seek loop itself (TF:generation_whisper.py:784-903): input_features [B, n_mels, frames], max_frames[b] =
         valid mel frames of utterance b.  init_tokens: the decoder prompt rows (list of B lists) or a callable(detect)
         building them (detect() = language ids from the first window); lengths(P) -> (max_new_tokens, min_new_tokens)
@@ -808,7 +813,10 @@ class WhisperForConditionalGeneration(nn.Module):
             the place of <|startofprev|> in front of the previous tokens of every window (TF:1887-1888);
           * num_beams > 1 (run_eval.py:693 / run_pseudo_labelling.py `--generation_num_beams`): the temperature-0 pass of a
             window is a beam search (decoding.beam_search_decode with the timestamp rules); sampled fallback passes use
-            one beam like the reference (TF:1010-1012).  The score-based thresholds (logprob / no-speech) are greedy-only.
+            one beam like the reference (TF:1010-1012).  The score-based thresholds (logprob / no-speech) are greedy-only;
+          * assistant = (engine, encode) of a draft model (run_eval.py:578-599, 706-707 with long-form inputs): the
+            temperature-0 pass of a window is decoding.assisted_greedy_decode with the timestamp rules; encode(features)
+            gives the assistant's encoder output of a window batch, or None when it shares this model's.
         -> per utterance the list of segments {"start", "end", "tokens"}."""
         import math
         import zlib
@@ -964,6 +972,19 @@ class WhisperForConditionalGeneration(nn.Module):
                     ids = torch.as_tensor([prompts[b] for b in pending], dtype=torch.long, device=dev)
                     if temp > 0.0:
                         out = sample(enc, ids, max_new, min_new, temp)[:, P:].tolist()
+                    elif assistant is not None:
+                        from .decoding import assisted_greedy_decode
+                        a_eng, a_encode = assistant
+                        enc_a = enc.to(a_eng.lowp) if a_encode is None else a_encode(window(pending))
+                        out, nd, na = assisted_greedy_decode(
+                            eng, a_eng, enc, enc_a, ids, max_new, int(num_assistant_tokens), eos,
+                            suppress_tokens=suppress_tokens, min_new_tokens=min_new, pad_token_id=pad,
+                            timestamp_rules=dict(begin_index=P, no_timestamps_token_id=nts,
+                                                 max_initial_timestamp_index=max_initial_timestamp_index))
+                        self.last_drafted = getattr(self, "last_drafted", 0) + nd
+                        self.last_accepted = getattr(self, "last_accepted", 0) + na
+                        out = torch.cat([out, torch.full((out.shape[0], P + max_new - out.shape[1]), pad,
+                                                         dtype=out.dtype, device=dev)], 1)[:, P:].tolist()
                     elif int(num_beams) > 1:
                         from .decoding import beam_search_decode
                         out = beam_search_decode(
@@ -1048,8 +1069,20 @@ class WhisperForConditionalGeneration(nn.Module):
         if all_segments and not (fallback_args or {}).get("condition_on_prev_tokens"):
             raise ValueError("Make sure to set `condition_on_prev_tokens=True` when setting "
                              "`prompt_condition_type='all-segments'`.")
-        if kwargs.get("assistant_model") is not None or kwargs.get("use_cache", True) is False:
-            raise NotImplementedError("the timestamp seek loop runs greedy / beam search on the KV-cache decoder only")
+        if kwargs.get("use_cache", True) is False:
+            raise NotImplementedError("the timestamp seek loop runs on the KV-cache decoder only")
+        assistant, begin_suppress_loop = None, (list(gc.begin_suppress_tokens) if gc.begin_suppress_tokens else None)
+        am = kwargs.get("assistant_model")
+        if am is not None:
+            if num_beams != 1:
+                raise ValueError("assistant_model cannot be combined with beam search (TF raises the same)")
+            am._sync_shadow()
+            shared = bool(getattr(am, "share_encoder_output", None))     # (a distilled student keeps the teacher's encoder)
+            a_encode = None if shared else \
+                (lambda f: am.engine.encode(f.to(torch.float32).contiguous(), save=False)[0])
+            assistant = (am.engine, a_encode)
+            begin_suppress_loop = None     # TF:719-721: with an assistant the model must be able to return EOS right away
+            self.last_drafted = self.last_accepted = 0
         if not hasattr(gc, "no_timestamps_token_id"):
             raise ValueError("You are trying to return timestamps, but the generation config is not properly set. Make "
                              "sure to initialize the generation config with the correct attributes that are needed "
@@ -1084,11 +1117,13 @@ class WhisperForConditionalGeneration(nn.Module):
                                     eos, pad, int(gc.no_timestamps_token_id),
                                     getattr(gc, "max_initial_timestamp_index", None),
                                     list(gc.suppress_tokens) if gc.suppress_tokens else None,
-                                    list(gc.begin_suppress_tokens) if gc.begin_suppress_tokens else None,
+                                    begin_suppress_loop,
                                     detect_language=detect_on, prev_sot_token_id=getattr(gc, "prev_sot_token_id", None),
                                     prompt_ids=(prompt_ids.tolist() if torch.is_tensor(prompt_ids) else prompt_ids),
                                     prompt_all_segments=all_segments and prompt_ids is not None,
-                                    num_beams=num_beams,
+                                    num_beams=num_beams, assistant=assistant,
+                                    num_assistant_tokens=(getattr(gc, "num_assistant_tokens", None) or getattr(
+                                        getattr(am, "generation_config", None), "num_assistant_tokens", None) or 5),
                                     length_penalty=1.0 if getattr(gc, "length_penalty", None) is None else gc.length_penalty,
                                     early_stopping=getattr(gc, "early_stopping", False) or False,
                                     **(fallback_args or {}))

@@ -232,6 +232,40 @@ def test_generate_matches_transformers_live_and_rejects_unsupported_arguments():
         en.generate(feats, language="en")
 
 
+def test_assistant_model_in_the_timestamp_seek_loop():
+    """run_eval.py:578-599, 706-707 with long-form inputs: `assistant_model` inside the seek loop.  Speculative greedy
+    decoding emits the target's own greedy tokens -- that is its contract -- so the result must equal the plain seek loop
+    with the begin-suppress rule off (TF:719-721 drops it when an assistant is given), whether the assistant shares the
+    encoder or not, for one long utterance and for a batch.  (Not compared with the imported class here: transformers
+    5.15's assisted path with `return_timestamps=True` does not reproduce its own greedy output on these inputs -- it
+    emits decreasing timestamp pairs, the timestamp rules being applied to candidate positions with the wrong history --
+    so there is no reference behaviour to match beyond the contract.)"""
+    ops = _ops("ref")
+    fields = gd.generation_fields(multilingual=True, suppress=True, timestamps=True)
+    plain_fields = dict(fields, begin_suppress_tokens=None)
+    for seed in (310, 311):
+        teacher, student = _models(ops, seed, fields)
+        plain, _ = _models(ops, seed, plain_fields)
+        long1 = torch.cat([gd.features(seed + 1, 1), gd.features(seed + 2, 1)[..., :2200]], -1)
+        batch = torch.cat([gd.features(seed + 3, 1), gd.features(seed + 4, 1)], 0)
+        for shared in (False, True):
+            student.share_encoder_output = shared
+            if shared:                      # a student that kept the teacher's encoder
+                student = _model(ops, student.dims, {**student.state_dict(), **{k: v for k, v in teacher.state_dict().items()
+                                                                                   if k.startswith("model.encoder.")}}, fields)
+                student.share_encoder_output = True
+            for feats, kw in ((long1, dict(max_new_tokens=6, return_timestamps=True, language="en")),
+                              (batch, dict(max_new_tokens=5, return_timestamps=True, language="de"))):
+                want = plain.generate(feats, **kw)
+                got = teacher.generate(feats, assistant_model=student, **kw)
+                assert got.tolist() == want.tolist(), (seed, shared, kw)
+                assert teacher.last_drafted > 0 and 0 <= teacher.last_accepted <= teacher.last_drafted
+        # one window, one call (force_unique_generate_call): the same contract
+        one = gd.features(seed + 5, 2)
+        kw1 = dict(max_new_tokens=7, return_timestamps=True, language="en", force_unique_generate_call=True)
+        assert teacher.generate(one, assistant_model=student, **kw1).tolist() == plain.generate(one, **kw1).tolist()
+
+
 def test_timestamp_seek_loop_matches_transformers_live():
     """generate(..., return_timestamps=True) is a seek loop in the reference (TF:generation_whisper.py:784-903): every
     window is decoded with the timestamp rules, `_retrieve_segment` splits it at consecutive timestamp pairs and moves
