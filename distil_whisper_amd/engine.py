@@ -293,14 +293,18 @@ class WhisperEngine:
         return dres, nxt
 
     def _scatter_buf(self, rows, cols):
-        key = (rows, cols)
+        """(batch, position)-layout target of the packed pass's scatter: zero-initialised once, afterwards it only ever
+        receives projected rows, so its dead rows stay finite.  Buffers are never freed or replaced while the engine lives
+        -- a captured step (train_step_graphed) has their addresses baked in -- a request is served by the smallest
+        existing buffer of that width with enough rows, a larger one is added when none has."""
         if not hasattr(self, "_sb"):
             self._sb = {}
-        if key not in self._sb:
-            if len(self._sb) >= 8:
-                self._sb.pop(next(iter(self._sb)))
-            self._sb[key] = self.ops.zeros((_rup(rows, 64), cols), self.lowp)
-        return self._sb[key]
+        fits = [b for b in self._sb.get(cols, []) if b.shape[0] >= rows]
+        if fits:
+            return min(fits, key=lambda b: b.shape[0])
+        buf = self.ops.zeros((_rup(rows, 64), cols), self.lowp)
+        self._sb.setdefault(cols, []).append(buf)
+        return buf
 
     def _scratch_vec(self, n, slot=0):
         key = (n, slot)
