@@ -338,3 +338,23 @@ def test_collator_reports_the_last_labelled_position():
     assert "valid_len" not in DataCollatorSpeechSeq2SeqWithPadding(max_target_length=16, device="cpu")(feats)
     per = DataCollatorSpeechSeq2SeqWithPadding(max_target_length=16, device="cpu", report_valid_len="per_sequence")(feats)
     assert per["valid_len"] == [1 + int((row != -100).nonzero().max()) for row in per["labels"]] == [5, 3]
+
+
+def test_live_rows_index_and_scatter_buffers():
+    """engine.LiveRows lists row b*T + t for t < lens[b], sequence by sequence (lengths clamped to [1, T]); the scatter
+    targets of the packed pass are zero-initialised, shared by every request they can hold, and never replaced (a
+    captured step has their addresses baked in)."""
+    from distil_whisper_amd.engine import LiveRows
+    idx = LiveRows.host_index([3, 0, 9, 2], 5)
+    assert idx.dtype == torch.int32 and idx.tolist() == [0, 1, 2, 5, 10, 11, 12, 13, 14, 15, 16]
+    live = LiveRows.build([3, 0, 9, 2], 5, "cpu")
+    assert (live.n, live.B, live.T) == (11, 4, 5) and torch.equal(live.idx, idx)
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup()
+    ops = RefOps("cpu", lowp=torch.float32)
+    eng = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t).teacher
+    a = eng._scatter_buf(100, 384)
+    assert a.shape == (128, 384) and float(a.abs().max()) == 0.0
+    assert eng._scatter_buf(70, 384) is a and eng._scatter_buf(128, 384) is a
+    b = eng._scatter_buf(200, 384)
+    assert b is not a and b.shape[0] == 256 and eng._scatter_buf(100, 384) is a and eng._scatter_buf(130, 384) is b
+    assert eng._scatter_buf(100, 128) is not a
