@@ -60,6 +60,7 @@ int g_gemm_cus = 256;
 static int g_gemm_stage_next = 1;   // dw_debug_set key 11: profiling switches of the software-pipelined kernels (bit 4: skip the epilogue)
 static int g_gemm_stagger = 0;   // dw_debug_set key 12: start offsets of the persistent workgroups (S | unit << 8), 0 = none
 static unsigned g_gemm_trace_lo = 0, g_gemm_trace_hi = 0;   // dw_debug_set keys 13 / 14: device pointer of the phase-trace buffer
+static int g_gemm_dbg = 0;       // dw_debug_set key 19: row-major 256-row GEMMs run the ablation / experiment kernel `value` of gemm_wp8_dbg.hip
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
 
 // Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never
@@ -98,6 +99,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 13) { g_gemm_trace_lo = (unsigned)value; return DW_OK; }
     if (key == 14) { g_gemm_trace_hi = (unsigned)value; return DW_OK; }
     if (key == 17) { g_attn_bwd_waves = value; return DW_OK; }
+    if (key == 19) { g_gemm_dbg = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
     if (key == 16) { g_attn_fwd_waves = value; return DW_OK; }
     if (key == 15) { g_attn_ablate = value; return DW_OK; }
@@ -247,6 +249,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
                 // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
                 // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
                 const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
+                if ((v & 16) && wp_ok && !epi_bound && g_gemm_dbg) return dw_gemm_wp8_nn_dbg_launch(q, g_gemm_dbg, s);
                 if ((v & 16) && wp_ok && !epi_bound && (v & 1536)) return dw_gemm_wp8_nn_dbg_launch(q, (v >> 9) & 3, s);
                 if ((v & 16) && wp_ok && !epi_bound) return (v & 256) ? dw_gemm_wp8_nn_ref_launch(q, s) : dw_gemm_wp8_nn_launch(q, s);
             } else if (!g->trans_a && g->trans_b) {

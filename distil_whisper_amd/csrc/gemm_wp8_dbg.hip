@@ -5,5 +5,6 @@
 int dw_gemm_wp8_nn_dbg_launch(const GemmP& p, int dbg, hipStream_t s) {
     if (dbg == 1) return launch_wp<false, false, 2, 4, true, 1>(p, s);
     if (dbg == 2) return launch_wp<false, false, 2, 4, true, 2>(p, s);
+    if (dbg == 4) return launch_wp<false, false, 2, 4, true, 4>(p, s);     // operand DMA always L2-warm (K advance dropped)
     return launch_wp<false, false, 2, 4, true, 3>(p, s);
 }

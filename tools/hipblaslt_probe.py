@@ -30,10 +30,17 @@ for name, M, N, K, ta, tb in shapes:
     out2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     A = a.t() if ta else a                  # [M, K] view
     Bm = b if tb else b.t()                 # [K, N] view
-    mine = lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out, tile=256)
+    if ta and tb:
+        # weight-gradient form as the step runs it: fp32 accumulation into the flat gradient buffer, K cut into slices that
+        # fill the 256 CUs + dw_reduce_slices (round-3 probe called the bf16-output form without slices: 100 tiles on 256 CUs,
+        # which is where its 439-550 TFLOP/s against the step's 1 029 came from)
+        out32 = torch.zeros(M, N, device="cuda", dtype=torch.float32)
+        mine = lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out32, atomic_acc=True)
+    else:
+        mine = lambda: ops.gemm(a, b, trans_a=ta, trans_b=tb, out=out, tile=256)
     vend = lambda: torch.matmul(A, Bm, out=out2)
     mine(); vend()
-    d = (out.float() - out2.float()).abs().max().item()
+    d = ((out32 if ta and tb else out.float()) - out2.float()).abs().max().item()
     r = {"mine": [], "vendor": []}
     for _ in range(5):
         r["mine"].append(2.0 * M * N * K / (timed(mine) * 1e-3) / 1e12)
