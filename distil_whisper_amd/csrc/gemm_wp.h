@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             // sub-step 0: second half of tile t+1
             PIN_SET(0);
             frags(I1{}, I1{}, buf);
-            if constexpr (MORE1) { substep(I0{}, I1{}, I2{}, buf ^ 1); if constexpr ((DBG & 4) == 0) { kA += stepA; kB += stepB; }   // (DBG & 4: every DMA of the loop re-fetches the first K tiles -- always L2-warm; tools/gemm_dma_diag.py) }
+            if constexpr (MORE1) { substep(I0{}, I1{}, I2{}, buf ^ 1); if constexpr ((DBG & 4) == 0) { kA += stepA; kB += stepB; } }   // (DBG & 4: every DMA of the loop re-fetches the first K tiles -- always L2-warm; tools/gemm_dma_diag.py)
             else substep(I0{}, I1{}, I0{}, 0);
             // sub-step 1
             PIN_SET(1);
