@@ -11,6 +11,8 @@ Semantics kept from the reference (PyTorch path):
 Data parallelism: the flat fp32 gradient buffer is all-reduced with RCCL (torch.distributed "nccl" backend on ROCm)
 in layer-ordered buckets on a side stream while the backward of earlier layers is still running.
 """
+import numbers
+
 import torch
 
 from .engine import LiveRows, ParamStore, WhisperDims, WhisperEngine
@@ -66,6 +68,17 @@ class GradReducer:
         if self.pending_hi - self.pending_lo >= self.bucket_elems:
             self.flush()
 
+    def reduce_small(self, t):
+        """Sum a small device tensor over the ranks on the communication stream (joined by wait())."""
+        if not self.active:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.stream):
+                self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.handles.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def flush(self):
         if self.pending_lo is not None:
             self._launch(self.pending_lo, self.pending_hi)
@@ -78,6 +91,15 @@ class GradReducer:
         self.handles = []
         if self.stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+
+
+def _as_int(v):
+    """A host integer in any of its spellings (int, numpy integer, 0-d array / tensor) -> int; everything else unchanged."""
+    if isinstance(v, numbers.Integral):
+        return int(v)
+    if v is not None and hasattr(v, "ndim") and v.ndim == 0:
+        return int(v.item())
+    return v
 
 
 def trim_dead_positions(decoder_input_ids, labels, valid_len):
@@ -98,6 +120,7 @@ def trim_dead_positions(decoder_input_ids, labels, valid_len):
         return decoder_input_ids, labels, None
     T = decoder_input_ids.shape[1]
     lens = None
+    valid_len = _as_int(valid_len)
     if not isinstance(valid_len, int):
         lens = [max(1, min(T, int(x))) for x in valid_len]
         if len(lens) != decoder_input_ids.shape[0]:
@@ -284,6 +307,12 @@ class DistillationTrainer:
         gradients AdamW would still move the weights by momentum and weight decay)."""
         ops, st = self.ops, self.student_store
         if self.reducer is not None:
+            if self.reducer.active and self._gate is not None:
+                # The gradients every rank applies are the reduced ones, so the skip decision has to be global too: a rank
+                # whose own shard held no label would otherwise freeze its replica (parameters, moments, step count) while
+                # the others step -- replicas diverge silently.  The label counts are summed with the gradient buckets.
+                self._gate = self._gate.clone()
+                self.reducer.reduce_small(self._gate)
             self.reducer.wait()
         if _write_lr:
             self.set_lr(self.lr if lr is None else lr)
@@ -325,15 +354,26 @@ class DistillationTrainer:
         dev = self.student_store.P.device
         B, T = decoder_input_ids.shape
         lens = None
+        valid_len = _as_int(valid_len)
         if valid_len is not None and not isinstance(valid_len, int):
             lens = [max(1, min(T, int(x))) for x in valid_len]
             valid_len = max(lens)
         Te = T if valid_len is None else max(1, min(T, int(valid_len)))
+        # Plans are keyed by QUANTISED sizes: the live positions rounded up to a multiple of `plan_pos_quantum`, the packed
+        # rows to a multiple of `plan_row_quantum` (the list is filled up with dead rows of the rectangle: label -100, no
+        # contribution).  With the label lengths of real batches nearly every batch has its own (max, sum); exact keys
+        # would mean a capture per batch and constant eviction among the `max_graphs` plans.
+        qp, qr = self.plan_pos_quantum, self.plan_row_quantum
+        Te = min(T, -(-Te // qp) * qp) if (qp > 1 and valid_len is not None) else Te
         if lens is not None and sum(lens) >= self.pack_live_rows_below * B * Te:
             lens = None
         Rc = sum(lens) if lens is not None else 0           # packed rows (0: the trimmed rectangle)
+        if lens is not None and qr > 1:
+            Rc = min(B * Te, -(-Rc // qr) * qr)
         in_key = (tuple(inputs.shape), inputs.dtype, tuple(decoder_input_ids.shape), self.overlap_teacher,
-                  self.student.wgrad_stream is not None)
+                  self.student.wgrad_stream is not None,
+                  # (a captured plan has these baked into its launches)
+                  self.temperature, self.kl_weight, self.max_grad_norm, self.eps, self.weight_decay, self._accum)
         key = in_key + (Te, Rc)
         ins = self._graph_inputs
         if ins is None or ins["key"] != in_key:
@@ -357,7 +397,7 @@ class DistillationTrainer:
         ins["labels"].copy_(labels)
         live = None
         if lens is not None:             # the row list of this batch goes into the plan's static index buffer
-            ins["live_idx"][:Rc].copy_(LiveRows.host_index(lens, Te))
+            ins["live_idx"][:Rc].copy_(LiveRows.host_index(lens, Te, fill_to=Rc))
             live = LiveRows(ins["live_idx"][:Rc], Rc, B, Te)
 
         def body():
@@ -389,6 +429,8 @@ class DistillationTrainer:
         return g["losses"]
 
     max_graphs = 8    # captured steps kept (one per number of live decoder positions; the oldest plan is dropped)
+    plan_pos_quantum = 32     # live decoder positions of a plan: multiples of this
+    plan_row_quantum = 320    # packed rows of a plan: multiples of this (one row tile of the 320-row GEMM kernel)
 
     def drop_graph(self):
         """Forget every captured step (their shared memory pool is released with them)."""

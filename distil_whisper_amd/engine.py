@@ -222,9 +222,19 @@ class LiveRows:
         self.idx, self.n, self.B, self.T = idx, int(n), int(B), int(T)
 
     @staticmethod
-    def host_index(lens, T):
+    def host_index(lens, T, fill_to=None):
+        """Row numbers of the live positions, sequence by sequence.  fill_to: pad the list up to that many rows with
+        DEAD rows of the rectangle (distinct positions behind their sequence's last label: label -100, their own causal
+        context only) -- captured plans are keyed by a quantised row count (DistillationTrainer.plan_row_quantum)."""
         lens = [max(1, min(int(T), int(x))) for x in lens]
-        return torch.cat([b * T + torch.arange(n, dtype=torch.int32) for b, n in enumerate(lens)])
+        idx = torch.cat([b * T + torch.arange(n, dtype=torch.int32) for b, n in enumerate(lens)])
+        if fill_to is not None and fill_to > idx.numel():
+            need = int(fill_to) - idx.numel()
+            dead = torch.cat([b * T + torch.arange(n, T, dtype=torch.int32) for b, n in enumerate(lens)])
+            if dead.numel() < need:
+                raise ValueError("LiveRows.host_index: not enough dead rows to fill the list")
+            idx = torch.cat([idx, dead[:need]])
+        return idx
 
     @classmethod
     def build(cls, lens, T, device):
@@ -489,6 +499,13 @@ class WhisperEngine:
         assert live is None or (live.B == B and live.T == T)
         ctx = {"B": B, "T": T, "R": R, "ids": ids, "layers": [], "enc_out": enc_out} if save else None
         packed = live is not None and not save
+        if packed and getattr(self, "_sb", None):
+            # The dead rows of the scatter targets must be finite (see _layer_fwd.attend).  They only ever receive
+            # projected rows, but one overflowing row of one bad batch would stay in a dead slot for the rest of the run
+            # and reach later batches through 0 x NaN: one fill per buffer and pass (two fills of a 32-layer pass).
+            for bufs in self._sb.values():
+                for b_ in bufs:
+                    b_.zero_()
         Rv = live.n if packed else R                 # rows the layers run over
         Rg = self._gemm_rows(Rv, save)
         if self.stream == torch.float32:

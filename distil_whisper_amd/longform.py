@@ -198,7 +198,12 @@ class LongFormTranscriber:
             self.time_precision = feature_extractor.chunk_length / d.max_src          # 30 s / 1500 positions = 0.02 s
             # every id the tokenizer lists as special and that is not a timestamp: by default the ids from EOS up to
             # <|notimestamps|> (Whisper's vocabulary keeps them contiguous)
+            # (the default covers the special-token block [eos, timestamp_begin); a pad id below eos -- the collator-style
+            # 50256 with the multilingual eos 50257 -- is NOT in it and would end up in the segments as text, so the pad,
+            # start and prompt ids this decoder knows are always added; a tokenizer's all_special_ids can be passed)
             self.special_ids = set(range(int(eos_token_id), self.timestamp_begin)) if special_ids is None else set(special_ids)
+            self.special_ids |= {int(eos_token_id), int(d.pad_token_id), int(d.decoder_start_token_id)}
+            self.special_ids |= {int(t) for t in self.prompt.tolist()}
             rules = dict(begin_index=len(self.prompt), no_timestamps_token_id=int(no_timestamps_token_id),
                          max_initial_timestamp_index=max_initial_timestamp_index)
         self.decoder = GreedyDecoder(model.engine, self.B, len(self.prompt) + self.max_new, eos_token_id=eos_token_id,

@@ -82,6 +82,41 @@ def test_two_ranks_match_averaged_single_process(tmp_path):
     assert rel < 2e-6, rel
 
 
+def _empty_shard_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg_t, cfg_s, t_sd, s_sd, feats, ids, labels = _make()
+    tr = DistillationTrainer(RefOps("cpu", lowp=torch.float32), s_sd, cfg_s, t_sd, cfg_t, weight_decay=0.05)
+    sl = slice(rank * 2, rank * 2 + 2)
+    lab = labels[sl].clone()
+    if rank == 1:
+        lab[:] = -100                    # this rank's shard holds no label at all
+    tr.train_step(feats[sl], ids[sl], lab)
+    torch.save({"P": tr.student_store.P.clone(), "step": tr.step_count}, os.path.join(out_dir, f"e{rank}.pt"))
+    # second case: NO rank has a label -> every rank skips the step (on the device), together
+    before = tr.student_store.P.clone()
+    tr.train_step(feats[sl], ids[sl], torch.full_like(lab, -100))
+    torch.save({"same": torch.equal(before, tr.student_store.P), "step": tr.step_count}, os.path.join(out_dir, f"f{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rank_without_labels_steps_with_the_others(tmp_path):
+    """The optimizer-skip gate is the label count of the whole data-parallel step, not of the rank: a rank whose shard has
+    no label applies the reduced gradient like everybody else (replicas stay identical); only a step without any label
+    on any rank is skipped."""
+    port = _free_port()
+    mp.spawn(_empty_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    e0, e1 = torch.load(os.path.join(tmp_path, "e0.pt")), torch.load(os.path.join(tmp_path, "e1.pt"))
+    assert e0["step"] == 1 and e1["step"] == 1
+    assert torch.equal(e0["P"], e1["P"])
+    f0, f1 = torch.load(os.path.join(tmp_path, "f0.pt")), torch.load(os.path.join(tmp_path, "f1.pt"))
+    assert f0["same"] and f1["same"] and f0["step"] == 1 and f1["step"] == 1
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # eval-side exchange (SURVEY.md 8e C4): generated ids padded to a common width and concatenated in rank order
 def _gather_worker(rank, world, port, out_dir):

@@ -358,3 +358,34 @@ def test_live_rows_index_and_scatter_buffers():
     b = eng._scatter_buf(200, 384)
     assert b is not a and b.shape[0] == 256 and eng._scatter_buf(100, 384) is a and eng._scatter_buf(130, 384) is b
     assert eng._scatter_buf(100, 128) is not a
+
+
+def test_live_rows_filled_with_dead_rows_and_integer_spellings():
+    """A row list filled up with dead rows of the rectangle (quantised plan keys of train_step_graphed) gives the same loss
+    and gradients; valid_len may arrive as a numpy integer or a 0-d tensor."""
+    import numpy as np
+    from distil_whisper_amd.engine import LiveRows
+    idx = LiveRows.host_index([3, 1], 5, fill_to=7)
+    assert idx.tolist() == [0, 1, 2, 5, 3, 4, 6] and len(set(idx.tolist())) == 7
+    with pytest.raises(ValueError):
+        LiveRows.host_index([5, 5], 5, fill_to=11)
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(T=37)
+    labels = batch["labels"].clone()
+    labels[0, 19:] = -100
+    labels[1, 11:] = -100
+    ops = RefOps("cpu", lowp=torch.float32)
+
+    def run(vl, live=None):
+        tr = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+        losses = tr.forward_backward(batch["input_features"], batch["decoder_input_ids"], labels, valid_len=vl, _live=live)
+        return losses.clone(), tr.student_store.G.clone()
+    l0, g0 = run(None)
+    for vl in (np.int64(19), torch.tensor(19), 19):
+        l1, g1 = run(vl)
+        assert torch.allclose(l0, l1, rtol=1e-6, atol=0) and relerr(g1, g0) < 1e-6
+    # rectangle of 24 positions, 30 live rows filled up to 40 with dead ones
+    Te = 24
+    h = LiveRows.host_index([19, 11], Te, fill_to=40)
+    l2, g2 = run(Te, LiveRows(h, 40, 2, Te))
+    assert l2[3].item() == l0[3].item()
+    assert torch.allclose(l0, l2, rtol=1e-6, atol=0) and relerr(g2, g0) < 1e-6
