@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device); a test of the "
                          "launcher, the rank plumbing and the data-parallel step, not a measurement")
+    ap.add_argument("--no-reference-loop", action="store_true",
+                    help="skip the `via_reference_loop` leg (the reference's loop body -- model(**batch), its own fp32 softmax / "
+                         "KL lines, loss.backward(), clip_grad_norm_, torch.optim.AdamW -- over the drop-in modules)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -114,6 +117,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL runs one workgroup (one CU) per channel for as long as a bucket is in flight.  The step needs 5.3 GB per GPU
+        # moved (ring all-reduce of 3.0 GB) inside ~250 ms of backward: 21 GB/s -- a handful of channels -- while every CU
+        # RCCL holds is one the persistent GEMM grids (256 workgroups, tiles drawn from per-XCD counters) do without:
+        # 8 CUs held for the WHOLE step cost +6 % (tools/comm_contention.py), so 8 channels active for ~1/5 of it cost ~1 %.
+        # A caller's own setting wins.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", "4")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
@@ -133,11 +143,13 @@ def main():
     s_sd, sdims = si.student_from_teacher(t_sd, tdims, le, ld)
     filt = torch.tensor(si.mel_filter_bank(tdims.n_mels), dtype=torch.float32, device=dev).contiguous()
     recipe = args.mode == "recipe"
-    # side streams: on request; one rank decides by measurement unless told (mode_selection below).  Data-parallel ranks keep
-    # the main stream + the reducer's stream unless --overlap is given: that combination is the one exercised with two
-    # ranks here (over gloo on a shared GPU the three-stream variant ran 12x slower -- gloo's host round trips serialise
-    # the streams; over RCCL it is untested on this pool's one-GPU boxes)
-    side = args.overlap and not args.no_overlap
+    # Side streams (frozen teacher forward, weight-gradient GEMMs): one rank decides by measurement unless told
+    # (mode_selection below: HIP graph on one stream against eager with side streams).  Data-parallel ranks run the eager
+    # step -- the RCCL buckets are issued from the host between the backward's layers -- and run it WITH the side streams:
+    # the same step one rank selects on this pool's boxes, plus the reducer's communication stream (--no-overlap keeps
+    # everything on the main stream).  Over gloo on a shared GPU (--share-device, a plumbing test) the side streams stay
+    # off unless --overlap is given: gloo's host round trips serialise them (12x slower, measured in round 3).
+    side = (args.overlap or (world > 1 and args.backend == "nccl")) and not args.no_overlap
     tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
                              mel_filters=filt, overlap_teacher=side and not args.no_teacher_overlap,
@@ -174,6 +186,21 @@ def main():
         return tr.train_step_graphed(audio, dec_in, labels, valid_len=vl)
 
     one_step = graph_step if use_graph else eager_step
+
+    # label lengths that CHANGE from step to step (an A/B leg): real batches have their own (max, sum) of label lengths, so
+    # the captured plans are keyed by quantised sizes (DistillationTrainer.plan_pos_quantum / plan_row_quantum)
+    fresh = []
+    for i in range(8):
+        li = torch.randint(32, 225, (B,), generator=g, device=dev)
+        lab_i = ids[:, 1:].clone()
+        lab_i[torch.arange(T, device=dev)[None, :] >= li[:, None]] = -100
+        fresh.append((lab_i, [min(T, int(x)) for x in li.tolist()]))
+    fresh_i = [0]
+
+    def fresh_step():
+        lab_i, lens_i = fresh[fresh_i[0] % len(fresh)]
+        fresh_i[0] += 1
+        return tr.train_step_graphed(audio, dec_in, lab_i, valid_len=lens_i)
 
     def sync():
         if world > 1:
@@ -285,7 +312,8 @@ def main():
     if world == 1 and not args.no_ab:
         try:
             ab = ab_legs(tr, eager_step, graph_step, B, dense=None if args.dense else (lambda: graph_step(None)),
-                         trimmed=(lambda: graph_step(Te)) if isinstance(valid_len, list) else None)
+                         trimmed=(lambda: graph_step(Te)) if isinstance(valid_len, list) else None,
+                         fresh=fresh_step if isinstance(valid_len, list) else None)
         except Exception as e:       # (the legs are extra information: the timed result above is reported regardless)
             ab = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.synchronize()
@@ -316,6 +344,7 @@ def main():
                         "frac": p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                         "traffic": pmc_traffic(key, args),
                         "vendor_library_tflops": vendor_ceiling(),
+                        "attention_vendor_tflops": attn_vendor_ceiling(),
                         "all_gemm_ms": sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")),
                         "all_gemm_tflops": sum(v["flops"] for k, v in prof.items() if k.startswith("gemm")) /
                         max(sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")), 1e-9) / 1e9,
@@ -331,6 +360,19 @@ def main():
             ops.profile = None
             roofline = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.synchronize()
+
+    via_loop = None
+    if world == 1 and not args.no_reference_loop:
+        # what a maintainer gets from the two-line import change alone: the drop-in modules under the
+        # reference's own loop body, optimizer and loss lines -- timed here so that the cost of staying on them is a number
+        del tr
+        torch.cuda.empty_cache()
+        try:
+            via_loop = reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_host, filt, B, dev)
+        except Exception as e:         # (extra information: the timed result is reported regardless)
+            via_loop = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
+        log("reference loop over the drop-in modules: " + json.dumps(via_loop))
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -353,7 +395,8 @@ def main():
                "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": ("hip_graph" if use_graph else "eager") +
                ("_side_streams" if (tr.overlap_teacher or tr.student.wgrad_stream is not None) else "_single_stream"),
                "mode_selection": selection, "step_stats": step_stats,
-               "ab": ab, "roofline": roofline, "cpu_baseline": cpu_baseline}
+               "kernels_sha16": _kernels_sha16(),
+               "ab": ab, "via_reference_loop": via_loop, "roofline": roofline, "cpu_baseline": cpu_baseline}
         if ab and "hip_graph_all_447_decoder_positions" in ab and "error" not in ab:
             # the step exactly as the reference shapes it (every padded decoder position computed), same process
             d447 = ab["hip_graph_all_447_decoder_positions"]
@@ -364,6 +407,54 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_host, filt, B, dev, warm=2, steps=4):
+    """The reference's hot loop over the DROP-IN surface (distil_whisper_amd.modeling), exactly as run_distillation.py drives
+    it: `student_model(**batch)`, `teacher_model(**batch)`, the fp32 softmax / log_softmax / kl_divergence lines,
+    `loss.backward()`, `clip_grad_norm_`, `torch.optim.AdamW.step()`, `zero_grad()` (1465-1495, 1606-1614).  The loop body is
+    the verbatim restatement the parity tests use (oracle/reference_loop.py) -- here it is the CALLER of the product, not
+    part of it.  Three legs, median ms per step: the batch as the reference's collator emits it; the same with the label
+    lengths in the batch (`valid_len`, what the drop-in collator adds: dead decoder positions left out); and that plus the
+    one-call fused KD loss (modeling.fused_distillation_loss) instead of the reference's softmax lines."""
+    from distil_whisper_amd import modeling as M
+    from distil_whisper_amd import student_init as si
+    from oracle.reference_loop import ReferenceLoop
+    recipe = args.mode == "recipe"
+    t_sd = si.random_state_dict(tdims, seed=0, device=dev)
+    s_sd, sdims = si.student_from_teacher(t_sd, tdims, le, ld)
+    student = M.WhisperForConditionalGeneration(sdims, ops=ops, state_dict=s_sd)
+    teacher = M.WhisperForConditionalGeneration(tdims, ops=ops, state_dict=t_sd, dtype=torch.bfloat16)
+    del t_sd, s_sd
+    if recipe:
+        student.freeze_encoder()
+    out = {"steps": steps, "warmup": warm, "optimizer": "torch.optim.AdamW (two groups) + clip_grad_norm_", "unit": "ms/step"}
+
+    def leg(with_len, fused):
+        loop = ReferenceLoop(student, teacher, M.BaseModelOutput, share_hidden_states=recipe, teacher_dtype=torch.bfloat16,
+                             fused_loss=M.fused_distillation_loss if fused else None)
+
+        def one():
+            feats = ops.logmel(audio, filt)                      # (the front end is part of the step, as in the main run)
+            batch = {"input_features": feats, "decoder_input_ids": dec_in, "labels": labels}
+            if with_len:
+                batch["valid_len"] = lens_host
+            return loop.training_iteration(batch, temperature=2.0)
+        for _ in range(warm):
+            m, _ = one()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        marks[0].record()
+        for i in range(steps):
+            m, _ = one()
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        t = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        return {"median_ms": t[len(t) // 2], "audio_s_per_s": B * 30e3 / t[len(t) // 2], "loss": float(m["loss"].item())}
+    out["verbatim"] = leg(False, False)
+    if not recipe:       # (the shared-encoder teacher call of the reference passes labels only: no lengths reach it)
+        out["with_valid_len"] = leg(True, False)
+        out["with_valid_len_and_fused_kd_loss"] = leg(True, True)
+    return out
 
 
 def spawn_ranks(n):
@@ -383,7 +474,7 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None, trimmed=None):
+def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None, trimmed=None, fresh=None):
     """The same process, the same weights and inputs, seconds apart: median GPU ms per step (HIP events around each
     step on the main stream) of the ways to issue the step; `dense`: the graphed step over all 447 decoder positions
     (what the reference computes) when the main run leaves the dead ones out."""
@@ -412,6 +503,12 @@ def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None, trimmed
         tr.drop_graph()
         torch.cuda.empty_cache()
         out["hip_graph_common_dead_tail_only"] = leg(trimmed, pre=3)
+    if fresh is not None:
+        # eight batches with their own label lengths in turn: every plan of the cycle is captured in the untimed steps
+        # (8 batches x (2 eager + 1 capture)), the timed ones replay whichever plan the batch's quantised sizes select
+        tr.drop_graph()
+        torch.cuda.empty_cache()
+        out["hip_graph_label_lengths_change_every_step"] = dict(leg(fresh, pre=21), plans=len(tr._graphs))
     tr.drop_graph()
     torch.cuda.empty_cache()
     out["eager_side_streams" if (ov_t or ov_w) else "eager_single_stream"] = leg(eager_step)
@@ -428,9 +525,16 @@ def ab_legs(tr, eager_step, graph_step, B, steps=10, warm=3, dense=None, trimmed
     return out
 
 
+def _kernels_sha16():
+    from distil_whisper_amd.build import kernels_sha16
+    return kernels_sha16()
+
+
 def vendor_ceiling():
     """Second ceiling next to the 2.5 PFLOP/s peak: what the vendor GEMM library reaches on the step's
-    row-major shapes on an MI355X of this pool (committed measurement, tools/hipblaslt_probe.py); None if not committed."""
+    row-major shapes on an MI355X of this pool (committed measurement, tools/hipblaslt_probe.py); None if not committed.
+    (The vendor's side of the calibration does not depend on this library's kernels; the file says which kernel sources
+    its `this_library_tflops` column was measured with.)"""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "vendor_gemm_ceiling.json")
     if not os.path.exists(path):
         return None
@@ -438,15 +542,39 @@ def vendor_ceiling():
         return json.load(f).get("row_major_forward_median_tflops")
 
 
+def attn_vendor_ceiling():
+    """What torch's scaled_dot_product_attention reaches on the encoder self-attention shape on a box of this pool
+    (tools/attn_vendor_probe.py, committed): {"fwd_tflops", "bwd_tflops"} of its best backend, or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "attn_vendor_ceiling.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        cls = json.load(f).get("classes", [])
+    for c in cls:
+        if c.get("Lq") == 1500 and c.get("Lk") == 1500:
+            ok = [v for v in c.get("vendor", {}).values() if "error" not in v]
+            if ok:
+                return {"fwd_tflops": max(v["fwd_tflops"] for v in ok), "bwd_tflops": max(v["bwd_tflops"] for v in ok),
+                        "this_library_fwd_tflops": c["mine"]["fwd_tflops"], "this_library_bwd_tflops": c["mine"]["bwd_tflops"]}
+    return None
+
+
 def pmc_traffic(key, args):
     """L2-fabric-side bytes per launch of the reported kernel class, from the committed PMC passes of this same
-    workload (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE cannot be collected inside a timed run).  None when the
-    committed summary is for another workload or does not hold the class."""
+    workload (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE cannot be collected inside a timed run).  None -- with the
+    reason logged -- when the committed summary is for another workload, does not hold the class, or was measured with
+    other kernel sources than the ones this run built (kernels_sha16)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     if not os.path.exists(path) or args.model != "large-v3" or args.mode != "full" or args.batch != 32:
         return None
     with open(path) as f:
-        c = json.load(f).get("classes", {}).get(key)
+        j = json.load(f)
+    sha = _kernels_sha16()
+    if j.get("kernels_sha16") != sha:
+        log(f"roofline.traffic: profiles/pmc_traffic.json was measured with kernel sources {j.get('kernels_sha16')}, "
+            f"this run has {sha}: not quoted (re-take it with tools/profile_round.sh)")
+        return None
+    c = j.get("classes", {}).get(key)
     return None if c is None else c["traffic_bytes_per_launch"]
 
 

@@ -14,6 +14,21 @@ SOURCES = ["gemm.hip", "gemm_tile256.hip", "gemm_tile128.hip", "gemm_phased.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
 
 
+def kernels_sha16() -> str:
+    """Identity of the kernel sources (every file under csrc/ + the C header): measurements that depend on the kernels
+    (profiles/pmc_traffic.json, this library's side of the vendor calibration) carry it, and bench.py only quotes a
+    committed measurement whose hash is the current one."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "dwamd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(obj, deps):
     if not os.path.exists(obj):
         return True

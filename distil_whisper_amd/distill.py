@@ -370,6 +370,8 @@ class DistillationTrainer:
         Rc = sum(lens) if lens is not None else 0           # packed rows (0: the trimmed rectangle)
         if lens is not None and qr > 1:
             Rc = min(B * Te, -(-Rc // qr) * qr)
+            if Rc >= self.pack_live_rows_below * B * Te:        # (filled up, the list is nearly the rectangle: keep the rectangle)
+                lens, Rc = None, 0
         in_key = (tuple(inputs.shape), inputs.dtype, tuple(decoder_input_ids.shape), self.overlap_teacher,
                   self.student.wgrad_stream is not None,
                   # (a captured plan has these baked into its launches)

@@ -38,6 +38,7 @@ class Seq2SeqLMOutput:
     # [rows >= B*T, padded vocabulary] behind `.logits`, and the model that produced them
     _logits_lowp: Optional[torch.Tensor] = None
     _model: Optional[object] = None
+    _rows: Optional[object] = None      # _RowSel of a forward called with valid_len (rows of _logits_lowp), else None
 
 
 @dataclass
@@ -300,14 +301,72 @@ class WhisperConfig:
             json.dump(self.to_dict(), f, indent=2, sort_keys=True)
 
 
+class _RowSel:
+    """Which decoder positions a forward computed when it was told the label lengths (`valid_len`, see
+    distill.trim_dead_positions): the first `Te` positions of every sequence, or -- per-sequence lengths -- the packed live
+    rows (engine.LiveRows over the [B, Te] rectangle).  The engine's low-precision logits hold exactly these rows; the
+    reference-shaped fp32 `.logits` [B, T, V] keeps its shape with ZERO rows at the dead positions (labels -100 there:
+    the reference's CE ignores them and its KL term masks them, run_distillation.py:1453-1462)."""
+
+    def __init__(self, B, T, Te, live):
+        self.B, self.T, self.Te, self.live = B, T, Te, live
+        self.n = B * Te if live is None else live.n
+        self.idx_full = None
+        if live is not None:
+            i = live.idx.long()
+            self.idx_full = (i // Te) * T + i % Te          # row numbers in the full [B * T] layout
+
+    @classmethod
+    def make(cls, valid_len, B, T, device, pack_below=0.9):
+        from .distill import _as_int
+        from .engine import LiveRows
+        valid_len = _as_int(valid_len)
+        if valid_len is None:
+            return None
+        lens = None
+        if not isinstance(valid_len, int):
+            lens = [max(1, min(T, int(x))) for x in valid_len]
+            if len(lens) != B:
+                raise ValueError("valid_len: one length per sequence of the batch (or one int for the batch)")
+            valid_len = max(lens)
+        Te = max(1, min(T, int(valid_len)))
+        live = None
+        if lens is not None and sum(lens) < pack_below * B * Te:
+            live = LiveRows.build(lens, Te, device)
+        if Te == T and live is None:
+            return None
+        return cls(B, T, Te, live)
+
+    def same_as(self, other):
+        if other is None or (self.B, self.T, self.Te, self.n) != (other.B, other.T, other.Te, other.n):
+            return False
+        return (self.live is None) == (other.live is None) and (self.live is None or torch.equal(self.live.idx, other.live.idx))
+
+    def select(self, flat):
+        """[B * T, C] in (batch, position) order -> the computed rows [n, C]"""
+        if self.live is None:
+            return flat.reshape(self.B, self.T, -1)[:, :self.Te].reshape(self.B * self.Te, -1)
+        return flat.index_select(0, self.idx_full)
+
+    def expand(self, rows, V):
+        """computed rows [n, >= V] -> fp32 [B, T, V], zeros at the positions that were not computed"""
+        B, T, Te = self.B, self.T, self.Te
+        out = torch.zeros(B, T, V, dtype=torch.float32, device=rows.device)
+        if self.live is None:
+            out[:, :Te] = rows[: B * Te, :V].reshape(B, Te, V)
+        else:
+            out.view(B * T, V).index_copy_(0, self.idx_full, rows[: self.n, :V].float())
+        return out
+
+
 class _EngineFn(torch.autograd.Function):
     """forward: engine encode+decode with activations kept; backward: engine backward from d(loss)/d(logits) (and
     optionally d/d(encoder_last_hidden_state)); parameter gradients are returned as views of the flat buffer."""
 
     @staticmethod
-    def forward(ctx, model, input_features, enc_in, decoder_input_ids, *params):
+    def forward(ctx, model, input_features, enc_in, decoder_input_ids, sel, *params):
         eng = model.engine
-        train = any(ctx.needs_input_grad[4:])  # (grad mode is off inside Function.forward; this is the real signal)
+        train = any(ctx.needs_input_grad[5:])  # (grad mode is off inside Function.forward; this is the real signal)
         enc_train = train and model._encoder_requires_grad()
         ectx = None
         if enc_in is None:
@@ -316,14 +375,19 @@ class _EngineFn(torch.autograd.Function):
             rows = enc_in.shape[0] * enc_in.shape[1]
             enc = eng.act(rows, eng.dims.d_model)
             enc[:rows].copy_(enc_in.reshape(rows, -1))
-        logits, dctx = eng.decode(decoder_input_ids.contiguous(), enc, save=train)
         B, T = decoder_input_ids.shape
         V = eng.dims.vocab
-        ctx.model, ctx.ectx, ctx.dctx, ctx.shape = model, ectx, dctx, (B, T, V)
+        if sel is None:
+            logits, dctx = eng.decode(decoder_input_ids.contiguous(), enc, save=train)
+            out_logits = logits[: B * T, :V].float().view(B, T, V)       # accelerate upcasts model outputs to fp32
+        else:
+            # the dead decoder positions are left out (same loss, same gradients: distill.trim_dead_positions)
+            logits, dctx = eng.decode(decoder_input_ids[:, :sel.Te].contiguous(), enc, save=train, live=sel.live)
+            out_logits = sel.expand(logits, V)
+        ctx.model, ctx.ectx, ctx.dctx, ctx.shape, ctx.sel = model, ectx, dctx, (B, T, V), sel
         ctx.logits_buf = logits if train else None
         model._last_logits_lowp = logits
         Re = B * eng.dims.max_src
-        out_logits = logits[: B * T, :V].float().view(B, T, V)       # accelerate upcasts model outputs to fp32
         enc_out = enc[:Re].float().view(B, eng.dims.max_src, -1)
         ctx.mark_non_differentiable(enc_out)
         return out_logits, enc_out
@@ -335,7 +399,10 @@ class _EngineFn(torch.autograd.Function):
         st = eng.st
         buf = ctx.logits_buf
         buf.zero_()
-        buf[: B * T, :V].copy_(g_logits.reshape(B * T, V))
+        if ctx.sel is None:
+            buf[: B * T, :V].copy_(g_logits.reshape(B * T, V))
+        else:
+            buf[: ctx.sel.n, :V].copy_(ctx.sel.select(g_logits.reshape(B * T, V)))
         eng.zero_small_grads()
         denc = eng.backward_decoder(ctx.dctx, buf, want_denc=ctx.ectx is not None)
         if ctx.ectx is not None:
@@ -347,7 +414,7 @@ class _EngineFn(torch.autograd.Function):
         grads = []
         for name, p in zip(model._param_names, model._param_list):
             grads.append(st.g[name].clone() if (p.requires_grad and name in st.g) else None)
-        return (None, None, None, None, *grads)
+        return (None, None, None, None, None, *grads)
 
 
 class _FusedLossFn(torch.autograd.Function):
@@ -359,16 +426,16 @@ class _FusedLossFn(torch.autograd.Function):
     autograd would hand to the model's backward anyway."""
 
     @staticmethod
-    def forward(ctx, logits, ops, s_buf, t_buf, labels, V, temperature, ce_weight, kl_weight):
+    def forward(ctx, logits, ops, s_buf, t_buf, labels, V, temperature, ce_weight, kl_weight, sel=None):
         B, T = labels.shape
-        R = B * T
-        lab = labels.reshape(-1).contiguous()
+        R = B * T if sel is None else sel.n
+        lab = (labels.reshape(-1) if sel is None else sel.select(labels.reshape(-1, 1)).reshape(-1)).contiguous()
         need = ctx.needs_input_grad[0]      # (grad mode is off inside Function.forward; this is the real signal)
         grad = ops.empty(tuple(s_buf[:R].shape), s_buf.dtype) if need else None
         t_rows = s_buf[:R] if t_buf is None else t_buf[:R]
         losses = ops.distill_loss(s_buf[:R], t_rows, lab, V, temperature, ce_weight, kl_weight if t_buf is not None else 0.0,
                                   1.0, need, grad_out=grad)
-        ctx.grad, ctx.shape = grad, (B, T, V)
+        ctx.grad, ctx.shape, ctx.sel = grad, (B, T, V), sel
         ctx.mark_non_differentiable(losses)
         total = losses[2] if t_buf is not None else losses[0]
         return total.clone(), losses
@@ -376,8 +443,8 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_losses):
         B, T, V = ctx.shape
-        g = ctx.grad[:, :V].float().view(B, T, V)
-        return (g * g_total, None, None, None, None, None, None, None, None)
+        g = ctx.grad[:, :V].float().view(B, T, V) if ctx.sel is None else ctx.sel.expand(ctx.grad, V)
+        return (g * g_total, None, None, None, None, None, None, None, None, None)
 
 
 def fused_distillation_loss(student_outputs, teacher_outputs, labels, temperature=2.0, kl_weight=1.0, ce_weight=0.8):
@@ -389,8 +456,12 @@ def fused_distillation_loss(student_outputs, teacher_outputs, labels, temperatur
     if s_buf is None or t_buf is None:
         raise ValueError("fused_distillation_loss needs outputs of distil_whisper_amd.WhisperForConditionalGeneration")
     model = student_outputs._model
+    sel = student_outputs._rows
+    if (sel is None) != (teacher_outputs._rows is None) or (sel is not None and not sel.same_as(teacher_outputs._rows)):
+        raise ValueError("fused_distillation_loss: student and teacher outputs were computed over different decoder "
+                         "positions (pass the same valid_len to both forwards)")
     loss, losses = _FusedLossFn.apply(student_outputs.logits, model.ops, s_buf, t_buf, labels, model.dims.vocab,
-                                      float(temperature), float(ce_weight), float(kl_weight))
+                                      float(temperature), float(ce_weight), float(kl_weight), sel)
     return loss, {"loss": losses[2], "ce_loss": losses[0], "kl_loss": losses[1]}
 
 
@@ -537,7 +608,12 @@ class WhisperForConditionalGeneration(nn.Module):
             self._versions = v
 
     def forward(self, input_features=None, attention_mask=None, decoder_input_ids=None, labels=None,
-                encoder_outputs=None, **kwargs):
+                encoder_outputs=None, valid_len=None, **kwargs):
+        """`valid_len` (optional, HOST integers from the collator -- DataCollatorSpeechSeq2SeqWithPadding(report_valid_len=...)
+        puts them into the batch, so the reference's `student_model(**batch)` / `teacher_model(**batch)` pass them on): one
+        int = 1 + the last labelled position of the batch, or one per sequence.  The decoder positions behind them are dead
+        (distill.trim_dead_positions) and are not computed; `.logits` keeps the reference shape [B, T, V] with zero rows there,
+        `.loss` and the gradients are those of the full-length forward.  Absent: every position is computed."""
         d = self.dims
         if labels is not None:
             if labels.shape[1] > d.max_tgt:
@@ -557,13 +633,15 @@ class WhisperForConditionalGeneration(nn.Module):
             raise ValueError(f"Whisper expects the mel input features to be of length {2 * d.max_src}, but found "
                              f"{input_features.shape[-1]}. Make sure to pad the input mel features to {2 * d.max_src}.")
         self._sync_shadow()
-        logits, enc = _EngineFn.apply(self, input_features, enc_in, decoder_input_ids, *self._param_list)
+        sel = _RowSel.make(valid_len, decoder_input_ids.shape[0], decoder_input_ids.shape[1], decoder_input_ids.device)
+        logits, enc = _EngineFn.apply(self, input_features, enc_in, decoder_input_ids, sel, *self._param_list)
         lowp, self._last_logits_lowp = self._last_logits_lowp, None
         loss = None
         if labels is not None:
             # token-mean CE over labels != -100 (TF:modeling_whisper.py:1083-1087) by the fused loss kernel
-            loss, _ = _FusedLossFn.apply(logits, self.ops, lowp, None, labels, d.vocab, 1.0, 1.0, 0.0)
-        return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc, _logits_lowp=lowp, _model=self)
+            loss, _ = _FusedLossFn.apply(logits, self.ops, lowp, None, labels, d.vocab, 1.0, 1.0, 0.0, sel)
+        return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc, _logits_lowp=lowp, _model=self,
+                               _rows=sel)
 
     @torch.no_grad()
     def generate(self, input_features=None, generation_config=None, logits_processor=None, stopping_criteria=None,

@@ -112,8 +112,73 @@ def test_reference_loop_over_drop_in_classes_equals_transformers_cpu(shared):
             assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in s.parameters())   # zero_grad reached them
 
 
+@pytest.mark.parametrize("per_sequence", [False, True])
+def test_valid_len_travels_through_the_boundary(per_sequence):
+    """The drop-in collator puts the label lengths into the batch (`valid_len`, host integers); the reference's loop body
+    hands the batch to both models unchanged (`student_model(**batch)`, `teacher_model(**batch)`,
+    run_distillation.py:1472-1481) and the drop-in forward leaves the dead decoder positions out: same metrics, same
+    gradient norm, same parameters as the same loop over the same batch without `valid_len`; `.logits` keeps its
+    [B, T, V] shape with zero rows at the dead positions."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from distil_whisper_amd import modeling as M
+    from distil_whisper_amd.collator import DataCollatorSpeechSeq2SeqWithPadding
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 71)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    T = 33
+    rng = np.random.default_rng(5)
+    col = DataCollatorSpeechSeq2SeqWithPadding(max_target_length=T + 1, device="cpu", decoder_start_token_id=cfg_t.decoder_start_token_id,
+                                               pad_token_id=cfg_t.pad_token_id,
+                                               report_valid_len="per_sequence" if per_sequence else True)
+    batches = []
+    for i, lens in enumerate(([13, 7, 20], [5, 22, 9])):
+        feats = [{"labels": [cfg_t.decoder_start_token_id] + rng.integers(0, cfg_t.vocab - 10, n).tolist(),
+                  "input_features": (0.5 * rng.standard_normal((cfg_t.n_mels, 3000))).astype(np.float32)} for n in lens]
+        batches.append(col(feats))
+    assert batches[0]["valid_len"] == ([13, 7, 20] if per_sequence else 20)
+    kw = dict(kl_weight=0.7, max_grad_norm=0.5, learning_rate=1e-3, weight_decay=0.1)
+
+    def run(with_len, fused):
+        ops = RefOps("cpu", lowp=torch.float32)
+        s = M.WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)
+        t = M.WhisperForConditionalGeneration(cfg_t, ops=ops, state_dict=t_sd)
+        loop = ReferenceLoop(s, t, M.BaseModelOutput, wrap=lambda m: DDP(m),
+                             fused_loss=M.fused_distillation_loss if fused else None, **kw)
+        bs = batches if with_len else [{k: v for k, v in b.items() if k != "valid_len"} for b in batches]
+        out = [loop.training_iteration(b, temperature=2.0) for b in bs]
+        return s, out
+
+    with _Group("gloo"):
+        for fused in (False, True):
+            s0, out0 = run(False, fused)
+            s1, out1 = run(True, fused)
+            for (m0, g0), (m1, g1) in zip(out0, out1):
+                for k in ("loss", "ce_loss", "kl_loss"):
+                    assert abs(m1[k].item() - m0[k].item()) < 1e-5 * abs(m0[k].item()) + 1e-7, (fused, k)
+                assert abs(g1.item() - g0.item()) < 1e-5 * g0.item(), fused
+            p0 = dict(s0.named_parameters())
+            for n, p in s1.named_parameters():
+                assert relerr(p, p0[n]) < 1e-5, (fused, n)
+        # the output keeps the reference shape; dead positions are zero rows, live ones equal the full forward's
+        ops = RefOps("cpu", lowp=torch.float32)
+        s = M.WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd).eval()
+        b = batches[0]
+        with torch.no_grad():
+            full = s(**{k: v for k, v in b.items() if k != "valid_len"})
+            part = s(**b)
+        assert part.logits.shape == full.logits.shape == (3, T, cfg_s.vocab)
+        live = torch.arange(T)[None, :] < torch.tensor([13, 7, 20] if per_sequence else [20, 20, 20])[:, None]
+        assert float(part.logits[~live].abs().max()) == 0.0
+        assert relerr(part.logits[live], full.logits[live]) < 1e-6
+        assert abs(part.loss.item() - full.loss.item()) < 1e-6 * full.loss.item()
+
+
 @pytest.mark.gpu
-def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fixtures():
+@pytest.mark.parametrize("with_len", [False, True])
+def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fixtures(with_len):
+    """with_len: the batch also carries the per-sequence label lengths (`valid_len`, what the drop-in collator reports) and
+    travels through `student_model(**batch)` / `teacher_model(**batch)` unchanged: the dead decoder positions are left out
+    and the fixture losses, gradient norm and parameters must come out all the same."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     from distil_whisper_amd import modeling as M
     from distil_whisper_amd.ops_hip import HipOps
@@ -129,6 +194,10 @@ def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fix
     feats = fe([a for a in b["audio"]], sampling_rate=16000, return_tensors="pt").input_features
     assert feats.is_cuda and np.abs(feats[:, ::9, ::97].cpu().numpy() - g32["mel_slice"]).max() < 1e-4
     batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"].cuda(), "labels": b["labels"].cuda()}
+    if with_len:
+        lab = b["labels"]
+        batch["valid_len"] = [1 + int((row != -100).nonzero().max()) for row in lab]
+        assert max(batch["valid_len"]) < lab.shape[1]          # (the fixture batch does have a dead tail)
     probe = [str(x) for x in g32["probe_names"]]
 
     def sample(t):

@@ -68,5 +68,8 @@ for name, Lq, Lk, causal in shapes:
     print(json.dumps(rec), flush=True)
     out.append(rec)
     del q4, k4, v4, do4
-if len(sys.argv) > 1:
-    json.dump({"note": "ceiling only; torch " + torch.__version__, "classes": out}, open(sys.argv[1], "w"), indent=1)
+if len(sys.argv) > 1:        # -> profiles/attn_vendor_ceiling.json (bench.py quotes it in `roofline`)
+    from distil_whisper_amd.build import kernels_sha16
+    json.dump({"note": "ceiling only: torch.nn.functional.scaled_dot_product_attention, torch " + torch.__version__ +
+               ", same box, same random data, interleaved with this library's kernels", "kernels_sha16": kernels_sha16(),
+               "classes": out}, open(sys.argv[1], "w"), indent=1)

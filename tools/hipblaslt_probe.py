@@ -24,6 +24,7 @@ def timed(fn, n=10):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
+records = {}
 for name, M, N, K, ta, tb in shapes:
     a = rnd((K, M) if ta else (M, K)); b = rnd((K, N) if tb else (N, K), 0.05)
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
@@ -47,3 +48,13 @@ for name, M, N, K, ta, tb in shapes:
         r["vendor"].append(2.0 * M * N * K / (timed(vend) * 1e-3) / 1e12)
     med = {k: sorted(v)[len(v) // 2] for k, v in r.items()}
     print(f"{name:28s} mine {med['mine']:6.0f} TF/s   vendor {med['vendor']:6.0f} TF/s   max|diff| {d:.3g}", flush=True)
+    records[name] = {"this_library_tflops": round(med["mine"]), "vendor_library_tflops": round(med["vendor"])}
+if len(sys.argv) > 1:        # -> profiles/vendor_gemm_ceiling.json (bench.py reads row_major_forward_median_tflops)
+    import json
+    from distil_whisper_amd.build import kernels_sha16
+    fwd = sorted(v["vendor_library_tflops"] for k, v in records.items() if k.startswith("fwd"))
+    json.dump({"source": "tools/hipblaslt_probe.py on one MI355X box of the pool (torch.matmul -> hipBLASLt, bf16, interleaved with "
+                         "this library on the same buffers; weight gradients through the step's split-K path)",
+               "kernels_sha16": kernels_sha16(), "shapes": records,
+               "row_major_forward_median_tflops": (fwd[len(fwd) // 2 - 1] + fwd[len(fwd) // 2]) / 2 if len(fwd) % 2 == 0 else fwd[len(fwd) // 2]},
+              open(sys.argv[1], "w"), indent=1)

@@ -12,6 +12,7 @@ fabric side of L2, so Infinity-Cache (MALL) hits are included: this is traffic l
 DRAM traffic.  bench.py reads the JSON this writes and fills roofline.traffic for the kernel class it reports.
 """
 import json
+import os
 import re
 import sqlite3
 import sys
@@ -55,7 +56,9 @@ def main(fetch_db, write_db, out_path):
             c["fetch_kib_sum"] += f[name][1]; c["launches_f"] += f[name][2]
         if name in w:
             c["write_kib_sum"] += w[name][1]; c["launches_w"] += w[name][2]
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1 "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from distil_whisper_amd.build import kernels_sha16
+    out = {"kernels_sha16": kernels_sha16(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1 "
                      "--no-cpu-baseline --no-roofline; FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes",
            "classes": {}}
     for key, c in classes.items():

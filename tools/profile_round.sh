@@ -3,7 +3,8 @@
 # Every stage is bounded by its own `timeout`: a rocprofv3 --pmc pass that faults does not return by itself (one such
 # pass once held the box for 24 minutes).  The whole script is ~4 minutes of box time.
 O=gpurun_out/prof; mkdir -p $O; export TMPDIR=/tmp
-timeout 120 python tools/hipblaslt_probe.py > $O/hipblaslt.log 2>&1
+timeout 120 python tools/hipblaslt_probe.py $O/vendor_gemm_ceiling.json > $O/hipblaslt.log 2>&1
+timeout 120 python tools/attn_vendor_probe.py $O/attn_vendor_ceiling.json > $O/attn_vendor.log 2>&1
 timeout 150 rocprofv3 --kernel-trace --stats -d $O/probe_prof -o p -- python tools/hipblaslt_probe.py > /dev/null 2>&1
 python tools/rocprof_summary.py $O/probe_prof/p_results.db $O/probe_kernels.md > /dev/null 2>&1
 rm -rf $O/probe_prof
