@@ -361,6 +361,8 @@ def main():
             roofline = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.synchronize()
 
+    step_mode = ("hip_graph" if use_graph else "eager") + \
+        ("_side_streams" if (tr.overlap_teacher or tr.student.wgrad_stream is not None) else "_single_stream")
     via_loop = None
     if world == 1 and not args.no_reference_loop:
         # what a maintainer gets from the two-line import change alone: the drop-in modules under the
@@ -392,8 +394,7 @@ def main():
                           "parallelism": f"dp{world}" + (f" ({args.backend}, ranks share cuda:0: plumbing test)" if args.share_device else ""), "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
                           "bwd+allreduce+clip+adamw", "loss": loss_val},
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
-               "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": ("hip_graph" if use_graph else "eager") +
-               ("_side_streams" if (tr.overlap_teacher or tr.student.wgrad_stream is not None) else "_single_stream"),
+               "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": step_mode,
                "mode_selection": selection, "step_stats": step_stats,
                "kernels_sha16": _kernels_sha16(),
                "ab": ab, "via_reference_loop": via_loop, "roofline": roofline, "cpu_baseline": cpu_baseline}

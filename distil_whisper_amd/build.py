@@ -44,6 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                os.path.join(HERE, "..", "include", "dwamd.h")]
     objs, procs = [], []
     flags = FLAGS + (["-DDW_ABLATE"] if os.environ.get("DW_ABLATE") else [])   # timing-experiment kernels (tools/attn_ablate.py)
+    flags += os.environ.get("DW_EXTRA_FLAGS", "").split()                      # -D switches of A/B builds (tools/build_variant_lib.sh)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))

@@ -465,15 +465,103 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             });
             if (RT ? p.colsum != nullptr : (F & EPI_COLSUM) != 0) gemm_colsum_flush<LPR>(p, cs, lane, n);
         };
+        // ---- flavours WITHOUT side inputs and with bf16 output (plain, bias, bias + GELU [+ stored gelu']): the element-wise
+        // work is done on the accumulators where they are (lane = output row, register = output column: the bias is one
+        // value per register, GELU is per element), and only the 2-byte RESULTS go through the wave's LDS patch to become
+        // row-major -- half the patch bytes of the fp32 walk above, written with ds_write_b64 instead of ds_write_b128 (the
+        // LDS write path, ~79 B/clk per CU, was ~60 % of a slab's 0.74 us), read back 8 columns per lane, stored with half as
+        // many (16-byte) global stores.  Same arithmetic per element as the fp32 walk: results are bit-identical.
+        // Patch: 32 rows x 136 B per wave (8 B of padding per row instead of a swizzle: the transposing b64 writes of 16
+        // consecutive rows land on 16 different bank pairs, and every LDS address is ONE lane register + an immediate);
+        // gelu'(z) (fp16), when it is stored, goes through the same patch after the outputs.
+        auto walk16 = [&](auto fc) __attribute__((always_inline)) {
+            constexpr int F = decltype(fc)::value;
+            static_assert((F & ~(EPI_BIAS | EPI_GELU | EPI_STOREG)) == 0 && TN == 64, "walk16: bf16 output, no side inputs");
+            constexpr bool HAS_G = (F & EPI_STOREG) != 0;
+            constexpr int PRS = 136;                  // patch row stride in bytes
+            char* const bp = (char*)smem + wave * 8192;
+            const float* const bsrc = lds_bias ? lds_bias + wn0 + hi * 4 : p.bias + n0 + wn0 + hi * 4;
+            hook();
+            gemm_lds_barrier();                       // every wave is done reading the operand tiles
+            if (tslot) tslot[5] = (long long)__builtin_amdgcn_s_memrealtime();
+            const int rr = lane >> 3, sc = lane & 7;  // row-major side: 8 rows per instruction, 8 lanes x 16 B per row
+            char* const wr = bp + ln * PRS + hi * 8;          // transposing side: + (j * 8 + g * 2) * 8
+            const char* const rd = bp + rr * PRS + sc * 16;   // row-major side:   + it * 8 * PRS (+ 8)
+            const unsigned l_c16 = (unsigned)((rr * (int)p.ldc + sc * 8) * 2);
+            const unsigned l_z16 = (unsigned)((rr * (int)p.ldz + sc * 8) * 2);
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            auto flush = [&](char* dst_u, long ld, unsigned l16, auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
+                    constexpr int it = decltype(itc)::value;
+                    constexpr long rg = i * 32 + it * 8;
+                    const u32x2 lo = *(const u32x2*)(rd + it * 8 * PRS), hi2 = *(const u32x2*)(rd + it * 8 * PRS + 8);
+                    u32x4 o4; o4[0] = lo[0]; o4[1] = lo[1]; o4[2] = hi2[0]; o4[3] = hi2[1];
+                    *(u32x4*)(dst_u + rg * ld * 2 + l16) = o4;
+                });
+            };
+            static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if (i == 1 && tslot) tslot[6] = (long long)__builtin_amdgcn_s_memrealtime();
+                f16x4 gq[HAS_G ? FN * 4 : 1];
+                static_for<0, FN>([&](auto jc) __attribute__((always_inline)) {
+                    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+                        constexpr int j = decltype(jc)::value, g = decltype(gc)::value;
+                        float v[4] = {acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+                        if constexpr ((F & EPI_BIAS) != 0) {
+                            const f32x4 b4t = *(const f32x4*)(bsrc + j * 32 + g * 8);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += b4t[e];
+                        }
+                        if constexpr ((F & EPI_GELU) != 0) {
+#pragma unroll
+                            for (int e = 0; e < 4; e += 2) {
+                                f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
+                                f32x2 cdf, pdf;
+                                gelu_parts2(x2, cdf, pdf);
+                                v[e] = x2[0] * cdf[0]; v[e + 1] = x2[1] * cdf[1];
+                                if constexpr (HAS_G) {
+                                    const f32x2 g2 = cdf + x2 * pdf;
+                                    gq[j * 4 + g][e] = (_Float16)g2[0]; gq[j * 4 + g][e + 1] = (_Float16)g2[1];
+                                }
+                            }
+                        }
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                        *(bf16x4*)(wr + (j * 8 + g * 2) * 8) = o;
+                    });
+                });
+                // (wave-private patch: the compiler's lgkmcnt waits order its LDS writes and reads)
+                flush(c_u, p.ldc, l_c16, ic);
+                if constexpr (HAS_G) {
+                    static_for<0, FN * 4>([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        *(f16x4*)(wr + ((q / 4) * 8 + (q % 4) * 2) * 8) = gq[q];
+                    });
+                    flush(z_u, p.ldz, l_z16, ic);
+                }
+            });
+        };
+#ifndef DW_EPI16
+#define DW_EPI16 1
+#endif
+        // 16-byte accesses of C (and z_out): pointer and leading dimension multiples of 8 elements
+        const bool ok16 = DW_EPI16 && SWZ && p.c_dtype != DW_F32 && ((uintptr_t)p.c & 15) == 0 && (p.ldc & 7) == 0 &&
+                          (!p.z_out || (((uintptr_t)p.z_out & 15) == 0 && (p.ldz & 7) == 0));
+#define DW_EPI_CASE16(F)                                                                             \
+    case (F):                                                                                        \
+        if constexpr (SWZ) { if (ok16) { walk16(std::integral_constant<int, (F)>{}); return; } }      \
+        walk(std::integral_constant<int, (F)>{}); return
 #define DW_EPI_CASE(F) case (F): walk(std::integral_constant<int, (F)>{}); return
         if constexpr (FM == 4 || FM == 2) {
             // 256-row kernels (8 waves: FM = 4; 16 waves and the 128-tile variant: FM = 2): one compact walk per flavour the step uses; any other flavour (the conv stem's GEMMs: two
             // launches per step) takes the looped general walk below -- there is NO unrolled run-time copy in the image.
             switch (gemm_epi_flavour(p)) {
-                DW_EPI_CASE(0);                                                              // dX GEMMs, LM head
-                DW_EPI_CASE(EPI_BIAS);                                                       // QKV / Q / KV projections
-                DW_EPI_CASE(EPI_BIAS | EPI_GELU);                                            // teacher fc1
-                DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);                               // student fc1 (keeps gelu'(z))
+                DW_EPI_CASE16(0);                                                              // dX GEMMs, LM head
+                DW_EPI_CASE16(EPI_BIAS);                                                       // QKV / Q / KV projections
+                DW_EPI_CASE16(EPI_BIAS | EPI_GELU);                                            // teacher fc1
+                DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);                               // student fc1 (keeps gelu'(z); two outputs: the fp32 walk is 1 % faster)
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);      // student out-proj / fc2
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROUND);                                  // teacher out-proj / fc2
                 DW_EPI_CASE(EPI_ZG16);                                                        // dX of fc2 (x gelu'(z))
@@ -488,9 +576,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             // apart, 763 spills against 12)
             if constexpr (FM == 5) {
                 switch (gemm_epi_flavour(p)) {
-                    DW_EPI_CASE(0);
-                    DW_EPI_CASE(EPI_BIAS);
-                    DW_EPI_CASE(EPI_BIAS | EPI_GELU);
+                    DW_EPI_CASE16(0);
+                    DW_EPI_CASE16(EPI_BIAS);
+                    DW_EPI_CASE16(EPI_BIAS | EPI_GELU);
                     DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);
                     DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);
                     DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROUND);
@@ -502,6 +590,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             return;
         }
 #undef DW_EPI_CASE
+#undef DW_EPI_CASE16
     }
 
     // ---- general walk (ragged tile edges, unaligned pointers, atomic accumulation): looped, loads at use ----

@@ -391,6 +391,7 @@ def test_dead_decoder_positions_left_out_on_the_device(ops):
     # same valid_len
     e = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
     g = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd)
+    g.plan_pos_quantum, g.plan_row_quantum = 8, 16      # (micro shapes: the production quanta would merge all three plans)
     # three signatures in turn (packed rows, a common tail, per-sequence lengths too dense to pack): three plans out of one
     # pool, each captured on its third visit and replayed afterwards
     batches = [(labels_with([33, 17, 25]), [33, 17, 25]), (labels_with([9, 48, 20]), 48), (labels_with([40, 70, 62]), [40, 70, 62])]
