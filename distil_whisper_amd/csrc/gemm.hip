@@ -214,7 +214,17 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
             if (t320 <= g_gemm_cus && 2 * t320 >= g_gemm_cus) { tile = 256; one_round_320 = true; }
         }
     }
+    if (tile == 256 && g->tile != 256 && !g->trans_a && !g->trans_b && g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 &&
+        g->k <= 1024 && p.split_k == 1 && !p.atomic) {
+        // Short K with the fp32 residual read + fp32 store (small.en's out-proj: N = K = 768): 655 KB of epilogue traffic per
+        // 320 x 256 tile against 12 K tiles of main loop -- the epilogue is the kernel.  Two 128-tile workgroups per CU run
+        // one's epilogue under the other's K loop: 504 vs 464 TFLOP/s at M = 48 000 (tools/gemm_small_en_probe.py).
+        tile = 128;
+    }
     if (tile == 256) {
+        // K <= 1024 (D = 768 models): the next tile's first operand tile is requested before the epilogue (gemm_wp.h; neutral
+        // at K = 1280, +1..2 % over 12 K tiles: qkv 915 -> 933, fc1 738 -> 750 TFLOP/s)
+        if (g->k <= 1024) p.stage_next |= 128;
         // the software-pipelined kernels address their operand DMA with 31-bit buffer offsets
         const long spanA = g->trans_a ? (long)g->k * g->lda * 2 : 256L * g->lda * 2 + (long)g->k * 2;
         const long spanB = g->trans_b ? (long)g->k * g->ldb * 2 : 256L * g->ldb * 2 + (long)g->k * 2;
