@@ -32,6 +32,12 @@ int dw_gemm_wp8_nn_dbg_launch(const GemmP& p, int dbg, hipStream_t s);         /
 int dw_gemm_wp8_nn_launch(const GemmP& p, hipStream_t s);                   // gemm_wp8_*.hip: software-pipelined loop, 8 waves
 int dw_gemm_wp8_nt_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp8_tt_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_nn_launch(const GemmP& p, hipStream_t s);                  // gemm_wp16_*.hip: the same loop on v_mfma_f32_16x16x32_bf16
+int dw_gemm_wp16_nn320_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_nt_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_nt320_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_tt_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_nn_dbg_launch(const GemmP& p, int dbg, hipStream_t s);
 
 extern int g_attn_bwd_stage;  // attention.hip
 extern int g_attn_decode;
@@ -60,6 +66,12 @@ int g_gemm_cus = 256;
 static int g_gemm_stage_next = 1;   // dw_debug_set key 11: profiling switches of the software-pipelined kernels (bit 4: skip the epilogue)
 static int g_gemm_stagger = 0;   // dw_debug_set key 12: start offsets of the persistent workgroups (S | unit << 8), 0 = none
 static unsigned g_gemm_trace_lo = 0, g_gemm_trace_hi = 0;   // dw_debug_set keys 13 / 14: device pointer of the phase-trace buffer
+// dw_debug_set key 20, bit mask: the software-pipelined kernels run on v_mfma_f32_16x16x32_bf16 (gemm_wp16.h): 1 row-major, 2 k-major B,
+// 4 both k-major.  Default 4: the weight-gradient GEMMs gain 3 % (two transposing LDS reads per fragment either way, and the
+// 16-cycle instruction leaves twice the issue gaps for them: 1 127 vs 1 093 TFLOP/s, -2.0 ms per step); the row-major and dX loops
+// tie without their epilogue and lose 1-6 % with it (more live registers around the epilogue walks: 152 / 332 B of scratch), so
+// they keep 32x32x16 (tools/gemm_mi16_probe.py, tools/gemm_mi16_sustained.py, tools/ab_step.py field 15).  Bit-identical results.
+static int g_gemm_mi16 = 4;
 static int g_gemm_dbg = 0;       // dw_debug_set key 19: row-major 256-row GEMMs run the ablation / experiment kernel `value` of gemm_wp8_dbg.hip
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
 
@@ -100,6 +112,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 14) { g_gemm_trace_hi = (unsigned)value; return DW_OK; }
     if (key == 17) { g_attn_bwd_waves = value; return DW_OK; }
     if (key == 19) { g_gemm_dbg = value; return DW_OK; }
+    if (key == 20) { g_gemm_mi16 = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
     if (key == 16) { g_attn_fwd_waves = value; return DW_OK; }
     if (key == 15) { g_attn_ablate = value; return DW_OK; }
@@ -254,19 +267,24 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
             else use320 = r320 < r256 && (r2rule ? g->k >= 2560 : !g->zgrad_in);
         }
         auto launch256 = [&](const GemmP& q) -> int {
-            if (use320) return g->trans_b ? dw_gemm_wp8_nt320_launch(q, s) : dw_gemm_wp8_nn320_launch(q, s);
+            if (use320) {
+                if (g->trans_b) return (g_gemm_mi16 & 2) ? dw_gemm_wp16_nt320_launch(q, s) : dw_gemm_wp8_nt320_launch(q, s);
+                return (g_gemm_mi16 & 1) ? dw_gemm_wp16_nn320_launch(q, s) : dw_gemm_wp8_nn320_launch(q, s);
+            }
             if (!g->trans_a && !g->trans_b) {
                 // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
                 // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
                 const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
                 if ((v & 16) && wp_ok && !epi_bound && g_gemm_dbg) return dw_gemm_wp8_nn_dbg_launch(q, g_gemm_dbg, s);
                 if ((v & 16) && wp_ok && !epi_bound && (v & 1536)) return dw_gemm_wp8_nn_dbg_launch(q, (v >> 9) & 3, s);
+                if ((v & 16) && wp_ok && !epi_bound && (g_gemm_mi16 & 1) && g_gemm_dbg) return dw_gemm_wp16_nn_dbg_launch(q, g_gemm_dbg, s);
+                if ((v & 16) && wp_ok && !epi_bound && (g_gemm_mi16 & 1)) return dw_gemm_wp16_nn_launch(q, s);
                 if ((v & 16) && wp_ok && !epi_bound) return (v & 256) ? dw_gemm_wp8_nn_ref_launch(q, s) : dw_gemm_wp8_nn_launch(q, s);
             } else if (!g->trans_a && g->trans_b) {
                 if (((v & 4) && g->k >= 3840 && q.split_k == 1) || (v & 128)) return dw_gemm_phased_launch(q, 0, 1, s);
-                if ((v & 32) && wp_ok) return dw_gemm_wp8_nt_launch(q, s);
+                if ((v & 32) && wp_ok) return (g_gemm_mi16 & 2) ? dw_gemm_wp16_nt_launch(q, s) : dw_gemm_wp8_nt_launch(q, s);
             } else if (g->trans_a && g->trans_b) {
-                if ((v & 64) && wp_ok) return dw_gemm_wp8_tt_launch(q, s);
+                if ((v & 64) && wp_ok) return (g_gemm_mi16 & 4) ? dw_gemm_wp16_tt_launch(q, s) : dw_gemm_wp8_tt_launch(q, s);
             }
             return dw_gemm_tile256_launch(q, g->trans_a, g->trans_b, s);
         };

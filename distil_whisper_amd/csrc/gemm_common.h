@@ -318,8 +318,13 @@ __device__ __forceinline__ void gemm_lds_barrier() {
 // b128 reads -- a row's 16 slots are a permutation): 8 waves x 8 KiB = exactly one 64 KiB operand buffer, so the
 // software-pipelined kernels can keep the patches in buffer 1 while the NEXT tile's first operand tile is already
 // arriving in buffer 0 (gemm_wp.h).
-template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook, bool SWZ = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][FN], char* smem, int wave, int lane,
+// LAY: accumulator layout.  32: f32x16 acc[FM][FN] of v_mfma_f32_32x32x16_bf16 (lane & 31 = row of the 32-row slab, register r =
+// column (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the 32-column block).  16: f32x4 acc[2 FM][2 FN] of v_mfma_f32_16x16x32_bf16
+// (lane & 15 = row of the 16-row block, register r = column 4 (lane >> 4) + r of the 16-column block).  Either way a lane holds
+// FN * 4 "quads" (4 consecutive columns of one row) per 32-row slab; quad q of slab i sits at row qrow(q) + lane part, column
+// qcol(q) + lane part of the slab.
+template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook, bool SWZ = false, int LAY = 32, class Acc = f32x16[FM][FN]>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* smem, int wave, int lane,
                                               int m0_, int wm0_, int n0_, int wn0_, int ks_, Hook hook = Hook(),
                                               const float* lds_bias = nullptr, long long* tslot = nullptr) {
     // tslot (phase trace, tools/gemm_phase_trace.py; thread 0 only, or null): [5] behind the leading barrier, [6] first slab
@@ -354,6 +359,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
     constexpr int NIT = 32 / RPI;                  // row groups of a 32-row slab
     float* patch = (float*)smem + wave * (32 * PLD);
     const int hi = lane >> 5, ln = lane & 31;
+    // quad accessors (see LAY above)
+    const int lrow = LAY == 32 ? ln : (lane & 15);                   // lane part of a quad's row within the slab
+    const int lcol = LAY == 32 ? hi * 4 : (lane >> 4) * 4;           // lane part of a quad's first column within the wave tile
+    auto qrow = [](int q) constexpr -> int { return LAY == 32 ? 0 : (q / (FN * 2)) * 16; };
+    auto qcol = [](int q) constexpr -> int { return LAY == 32 ? (q / 4) * 32 + (q % 4) * 8 : (q % (FN * 2)) * 16; };
+    auto quad = [&](auto ic, auto qc) __attribute__((always_inline)) -> f32x4 {
+        constexpr int i = decltype(ic)::value, q = decltype(qc)::value;
+        f32x4 v4;
+        if constexpr (LAY == 32) {
+            constexpr int j = q / 4, g = q % 4;
+            v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1]; v4[2] = acc[i][j][g * 4 + 2]; v4[3] = acc[i][j][g * 4 + 3];
+        } else {
+            constexpr int h = q / (FN * 2), j = q % (FN * 2);
+            v4 = acc[2 * i + h][j];
+        }
+        return v4;
+    };
     const bool plain = !p.bias && !p.z_out && p.act == 0 && !p.zgrad && !p.r;
     float* const cf = (float*)p.c + (long)ks * p.slice_stride;  // (fp32 outputs only; slice_stride = 0 otherwise)
     const int pr = lane / LPR, pc = (lane % LPR) * 4;
@@ -371,17 +393,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
         }
     }
     auto to_patch = [&](auto ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        static_for<0, FN>([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value;
-            static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
-                constexpr int g = decltype(gc)::value;
-                f32x4 v4;
-                v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1];
-                v4[2] = acc[i][j][g * 4 + 2]; v4[3] = acc[i][j][g * 4 + 3];
-                if constexpr (SWZ) *(f32x4*)(patch + ln * PLD + (((j * 8 + g * 2 + hi) ^ (ln & 15)) << 2)) = v4;
-                else *(f32x4*)(patch + ln * PLD + j * 32 + g * 8 + hi * 4) = v4;
-            });
+        static_for<0, FN * 4>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            const f32x4 v4 = quad(ic, qc);
+            const int row = lrow + qrow(q), col = lcol + qcol(q);
+            if constexpr (SWZ) *(f32x4*)(patch + row * PLD + (((col >> 2) ^ (row & 15)) << 2)) = v4;
+            else *(f32x4*)(patch + row * PLD + col) = v4;
         });
         // (wave-private patch: the compiler's lgkmcnt wait orders these LDS writes before the reads that follow)
     };
@@ -480,12 +497,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
             constexpr bool HAS_G = (F & EPI_STOREG) != 0;
             constexpr int PRS = 136;                  // patch row stride in bytes
             char* const bp = (char*)smem + wave * 8192;
-            const float* const bsrc = lds_bias ? lds_bias + wn0 + hi * 4 : p.bias + n0 + wn0 + hi * 4;
+            const float* const bsrc = lds_bias ? lds_bias + wn0 + lcol : p.bias + n0 + wn0 + lcol;
             hook();
             gemm_lds_barrier();                       // every wave is done reading the operand tiles
             if (tslot) tslot[5] = (long long)__builtin_amdgcn_s_memrealtime();
             const int rr = lane >> 3, sc = lane & 7;  // row-major side: 8 rows per instruction, 8 lanes x 16 B per row
-            char* const wr = bp + ln * PRS + hi * 8;          // transposing side: + (j * 8 + g * 2) * 8
+            char* const wr = bp + lrow * PRS + lcol * 2;      // transposing side: + qrow(q) * PRS + qcol(q) * 2
             const char* const rd = bp + rr * PRS + sc * 16;   // row-major side:   + it * 8 * PRS (+ 8)
             const unsigned l_c16 = (unsigned)((rr * (int)p.ldc + sc * 8) * 2);
             const unsigned l_z16 = (unsigned)((rr * (int)p.ldz + sc * 8) * 2);
@@ -504,40 +521,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[FM][
                 constexpr int i = decltype(ic)::value;
                 if (i == 1 && tslot) tslot[6] = (long long)__builtin_amdgcn_s_memrealtime();
                 f16x4 gq[HAS_G ? FN * 4 : 1];
-                static_for<0, FN>([&](auto jc) __attribute__((always_inline)) {
-                    static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
-                        constexpr int j = decltype(jc)::value, g = decltype(gc)::value;
-                        float v[4] = {acc[i][j][g * 4 + 0], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
-                        if constexpr ((F & EPI_BIAS) != 0) {
-                            const f32x4 b4t = *(const f32x4*)(bsrc + j * 32 + g * 8);
+                static_for<0, FN * 4>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    const f32x4 a4 = quad(ic, qc);
+                    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                    if constexpr ((F & EPI_BIAS) != 0) {
+                        const f32x4 b4t = *(const f32x4*)(bsrc + qcol(q));
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += b4t[e];
-                        }
-                        if constexpr ((F & EPI_GELU) != 0) {
+                        for (int e = 0; e < 4; ++e) v[e] += b4t[e];
+                    }
+                    if constexpr ((F & EPI_GELU) != 0) {
 #pragma unroll
-                            for (int e = 0; e < 4; e += 2) {
-                                f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
-                                f32x2 cdf, pdf;
-                                gelu_parts2(x2, cdf, pdf);
-                                v[e] = x2[0] * cdf[0]; v[e + 1] = x2[1] * cdf[1];
-                                if constexpr (HAS_G) {
-                                    const f32x2 g2 = cdf + x2 * pdf;
-                                    gq[j * 4 + g][e] = (_Float16)g2[0]; gq[j * 4 + g][e + 1] = (_Float16)g2[1];
-                                }
+                        for (int e = 0; e < 4; e += 2) {
+                            f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
+                            f32x2 cdf, pdf;
+                            gelu_parts2(x2, cdf, pdf);
+                            v[e] = x2[0] * cdf[0]; v[e + 1] = x2[1] * cdf[1];
+                            if constexpr (HAS_G) {
+                                const f32x2 g2 = cdf + x2 * pdf;
+                                gq[q][e] = (_Float16)g2[0]; gq[q][e + 1] = (_Float16)g2[1];
                             }
                         }
-                        bf16x4 o;
+                    }
+                    bf16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-                        *(bf16x4*)(wr + (j * 8 + g * 2) * 8) = o;
-                    });
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+                    *(bf16x4*)(wr + qrow(q) * PRS + qcol(q) * 2) = o;
                 });
                 // (wave-private patch: the compiler's lgkmcnt waits order its LDS writes and reads)
                 flush(c_u, p.ldc, l_c16, ic);
                 if constexpr (HAS_G) {
                     static_for<0, FN * 4>([&](auto qc) __attribute__((always_inline)) {
                         constexpr int q = decltype(qc)::value;
-                        *(f16x4*)(wr + ((q / 4) * 8 + (q % 4) * 2) * 8) = gq[q];
+                        *(f16x4*)(wr + qrow(q) * PRS + qcol(q) * 2) = gq[q];
                     });
                     flush(z_u, p.ldz, l_z16, ic);
                 }

@@ -59,6 +59,22 @@ __device__ __forceinline__ void wp_dma16(const i32x4_t& rsrc, const char* lds_ds
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(m0v), "v"(voffset), "s"(rsrc), "s"(soffset));
 }
+// The same with the LDS destination as a 32-bit LDS ADDRESS (integer arithmetic on the address of the operand buffers, taken
+// once per kernel): the generic -> LDS pointer conversion of the form above costs a null check per call (s_cmp_lg_u64 /
+// s_cselect_b32 / 64-bit add: four scalar instructions in front of every operand load of the K loop).
+__device__ __forceinline__ unsigned wp_lds_addr(const void* lds_ptr) {
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const lds_void_t*)lds_ptr);
+}
+__device__ __forceinline__ void wp_dma16u(const i32x4_t& rsrc, unsigned lds_addr, unsigned voffset, int soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset));
+}
+// ... with the piece's compile-time offset added on the way into M0 (one scalar instruction instead of two)
+template <int IMM>
+__device__ __forceinline__ void wp_dma16i(const i32x4_t& rsrc, unsigned lds_base, unsigned voffset, int soffset) {
+    asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset), "i"(IMM) : "scc");
+}
 
 // ASMDMA = false builds the same kernel with the operand DMA issued through the compiler builtin (A/B reference only).
 // BM = 320 (row-major A only): a 320 x 256 block tile, 160 x 64 per wave (5 x 2 accumulators).  M = 48000 is 150 row
@@ -90,6 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * TN;
+    const unsigned smem_w = wp_lds_addr(smem) + (unsigned)(wave * 1024);     // this wave's first DMA piece of buffer 0
 
     __shared__ int job_slot[2];
     GemmJobs jobs;
@@ -207,8 +224,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             const char* tA = smem + ((DBG & 2) ? (buf & 1) : buf) * STAGE + wave * 1024 + i * (NW * 1024);
             if constexpr ((DBG & 2) != 0) { if (buf < 8) return; }                  // ablation: no operand DMA in the loop
             if constexpr (ASMDMA) {
-                if constexpr (isA) wp_dma16(ra, tA, offA[UNI ? 0 : i], UNI ? kA + i * pieceA : kA);
-                else wp_dma16(rb, tA + BM * 128, offB[UNI ? 0 : i], UNI ? kB + i * pieceB : kB);
+                const unsigned lb = smem_w + (unsigned)(((DBG & 2) ? (buf & 1) : buf) * STAGE);
+                if constexpr (isA) wp_dma16i<i * (NW * 1024)>(ra, lb, offA[UNI ? 0 : i], UNI ? kA + i * pieceA : kA);
+                else wp_dma16i<i * (NW * 1024) + BM * 128>(rb, lb, offB[UNI ? 0 : i], UNI ? kB + i * pieceB : kB);
             } else {
                 const auto bA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);
                 const auto bB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, 0x7fffffff, 0x00020000);

@@ -217,6 +217,51 @@ def test_gemm_320_row_tiles_are_bit_identical(ops, ref, tb):
         ops.lib.dw_debug_set(0, 2163)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_16x16x32_main_loop_is_bit_identical(ops, ref, ta, tb):
+    """gemm_wp16.h: the software-pipelined main loop on v_mfma_f32_16x16x32_bf16 (dw_debug_set key 20; the default for the
+    weight-gradient layout) -- 16 x 32 fragments under their own LDS swizzles, the k-major image through ds_read_b64_tr_b16 in
+    the 16 x 16 x 32 operand order, accumulators as 16 x 16 blocks through the LAY = 16 epilogue.  The hardware accumulates a
+    32-deep instruction in the order two 16-deep ones do, so every output bit agrees with the 32x32x16 kernels: each
+    layout, 256-row and 320-row tiles, ragged edges, 1..5 and 20 K tiles, persistent walk, every epilogue flavour of the
+    step (both epilogue walks), split-K slices, repeated launches."""
+    try:
+        shapes = ((520, 392, 64), (776, 1024, 320), (640, 512, 128), (3200, 1280, 192), (320 * 30, 3840, 256), (8 * 1500, 1280, 1280))
+        for M, N, K in shapes:
+            a = rnd((K, M) if ta else (M, K), 0.5, seed=71)
+            b = rnd((K, N) if tb else (N, K), 0.1, seed=72)
+            bias = rnd((N,), 0.5, torch.float32, seed=73)
+            r16 = rnd((M, N), 1.0, seed=74)
+            r32 = rnd((M, N), 1.0, torch.float32, seed=75)
+            zin = rnd((M, N), 1.0, seed=76).to(torch.float16)
+            flavours = (dict(), dict(bias=bias), dict(bias=bias, act=1), dict(out_dtype=torch.float32), dict(bias=bias, residual=r16),
+                        dict(bias=bias, residual=r32, out_dtype=torch.float32), dict(zgrad=zin), dict(bias=bias, act=1, want_z="grad"))
+            want = []
+            ops.lib.dw_debug_set(20, 0)
+            for f in flavours:
+                o = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256, **f)
+                want.append([t.clone() for t in o] if isinstance(o, tuple) else [o.clone()])
+            ops.lib.dw_debug_set(20, 7)
+            for rep in range(2):
+                for f, w in zip(flavours, want):
+                    o = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256, **f)
+                    o = list(o) if isinstance(o, tuple) else [o]
+                    for g_, w_ in zip(o, w):
+                        assert torch.equal(g_, w_), (M, N, K, ta, tb, sorted(f), rep, (g_.float() - w_.float()).abs().max().item())
+            assert relerr(want[3][0], ref.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32)) < 1e-5
+        if ta and tb:       # weight-gradient form with K slices
+            a, b = rnd((6400, 1280), 0.5, seed=77), rnd((6400, 384), 0.5, seed=78)
+            outs = []
+            for v in (0, 7):
+                ops.lib.dw_debug_set(20, v)
+                o = torch.zeros(1280, 384, device="cuda")
+                ops.gemm(a, b, trans_a=True, trans_b=True, out_dtype=torch.float32, out=o, atomic_acc=True, split_k=5)
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1])
+    finally:
+        ops.lib.dw_debug_set(20, 4)
+
+
 def test_gemm_dynamic_job_handout_is_invisible(ops, ref):
     """Persistent 256-tile kernels draw their tiles from per-XCD device counters (dw_debug_set key 10; the last
     workgroup resets them): the tile -> workgroup assignment changes, the results must not -- three launches in a row
