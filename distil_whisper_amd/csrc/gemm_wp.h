@@ -32,11 +32,18 @@
 #define PINF(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]), "+v"((f)[2]), "+v"((f)[3]))
 #define PINF2(f) asm volatile("" : "+v"((f)[0]), "+v"((f)[1]))
 #define PIN_SET(set)                                                                                              \
-    do {                                                                                                          \
-        if constexpr (FM == 4) PINF(af[set]);                                                                     \
-        else if constexpr (FM == 5) { PINF(af[set]); asm volatile("" : "+v"(af[set][4])); }                      \
-        else PINF2(af[set]);                                                                                      \
-        if constexpr (FN == 4) PINF(bfr[set]); else PINF2(bfr[set]);                                              \
+    do {        /* ONE statement per set: one lgkmcnt wait in front of the sub-step instead of one per fragment group */  \
+        if constexpr (FM == 4 && FN == 2)                                                                                 \
+            asm volatile("" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(af[set][2]), "+v"(af[set][3]), "+v"(bfr[set][0]), "+v"(bfr[set][1]));   \
+        else if constexpr (FM == 5 && FN == 2)                                                                            \
+            asm volatile("" : "+v"(af[set][0]), "+v"(af[set][1]), "+v"(af[set][2]), "+v"(af[set][3]), "+v"(af[set][4]), "+v"(bfr[set][0]),     \
+                         "+v"(bfr[set][1]));                                                                              \
+        else {                                                                                                            \
+            if constexpr (FM == 4) PINF(af[set]);                                                                         \
+            else if constexpr (FM == 5) { PINF(af[set]); asm volatile("" : "+v"(af[set][4])); }                          \
+            else PINF2(af[set]);                                                                                          \
+            if constexpr (FN == 4) PINF(bfr[set]); else PINF2(bfr[set]);                                                  \
+        }                                                                                                                 \
     } while (0)
 
 // One 16-byte-per-lane operand DMA (buffer_load_dwordx4 ... lds: LDS destination = M0 + lane * 16), written as inline
@@ -70,6 +77,14 @@ __device__ __forceinline__ void wp_dma16u(const i32x4_t& rsrc, unsigned lds_addr
                  :: "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset));
 }
 // ... with the piece's compile-time offset added on the way into M0 (one scalar instruction instead of two)
+// ... and, for the kernels whose pieces differ by a scalar stride (UNI), the piece's scalar offset computed in the wait state the
+// M0 write needs anyway (instead of an s_nop and a separate s_add)
+template <int IMM>
+__device__ __forceinline__ void wp_dma16p(const i32x4_t& rsrc, unsigned lds_base, unsigned voffset, int kbase, int piece_off) {
+    int so;
+    asm volatile("s_add_u32 m0, %1, %5\n\ts_add_u32 %0, %4, %6\n\tbuffer_load_dwordx4 %2, %3, %0 offen lds"
+                 : "=&s"(so) : "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(kbase), "i"(IMM), "s"(piece_off) : "scc");
+}
 template <int IMM>
 __device__ __forceinline__ void wp_dma16i(const i32x4_t& rsrc, unsigned lds_base, unsigned voffset, int soffset) {
     asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -225,8 +240,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             if constexpr ((DBG & 2) != 0) { if (buf < 8) return; }                  // ablation: no operand DMA in the loop
             if constexpr (ASMDMA) {
                 const unsigned lb = smem_w + (unsigned)(((DBG & 2) ? (buf & 1) : buf) * STAGE);
-                if constexpr (isA) wp_dma16i<i * (NW * 1024)>(ra, lb, offA[UNI ? 0 : i], UNI ? kA + i * pieceA : kA);
-                else wp_dma16i<i * (NW * 1024) + BM * 128>(rb, lb, offB[UNI ? 0 : i], UNI ? kB + i * pieceB : kB);
+                if constexpr (UNI) {
+                    if constexpr (isA) wp_dma16p<i * (NW * 1024)>(ra, lb, offA[0], kA, i * pieceA);
+                    else wp_dma16p<i * (NW * 1024) + BM * 128>(rb, lb, offB[0], kB, i * pieceB);
+                } else {
+                    if constexpr (isA) wp_dma16i<i * (NW * 1024)>(ra, lb, offA[i], kA);
+                    else wp_dma16i<i * (NW * 1024) + BM * 128>(rb, lb, offB[i], kB);
+                }
             } else {
                 const auto bA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);
                 const auto bB = __builtin_amdgcn_make_buffer_rsrc((void*)gB, 0, 0x7fffffff, 0x00020000);

@@ -157,8 +157,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
             constexpr int i = (isA ? (h ? NA0 : 0) : (h ? NB0 : 0)) + idx;
             static_assert(j < na + nb, "load index");
             const unsigned lb = smem_w + (unsigned)(buf * STAGE);
-            if constexpr (isA) wp_dma16i<i * (NW * 1024)>(rsA, lb, offA[UNI ? 0 : i], UNI ? kA + i * pieceA : kA);
-            else wp_dma16i<i * (NW * 1024) + BM * 128>(rsB, lb, offB[UNI ? 0 : i], UNI ? kB + i * pieceB : kB);
+            if constexpr (UNI) {
+                if constexpr (isA) wp_dma16p<i * (NW * 1024)>(rsA, lb, offA[0], kA, i * pieceA);
+                else wp_dma16p<i * (NW * 1024) + BM * 128>(rsB, lb, offB[0], kB, i * pieceB);
+            } else {
+                if constexpr (isA) wp_dma16i<i * (NW * 1024)>(rsA, lb, offA[i], kA);
+                else wp_dma16i<i * (NW * 1024) + BM * 128>(rsB, lb, offB[i], kB);
+            }
         };
         auto dma = [&](auto hc, int buf) __attribute__((always_inline)) {
             static_for<0, (decltype(hc)::value ? NH1 : NH0)>([&](auto jc) __attribute__((always_inline)) { dma1(hc, jc, buf); });
