@@ -49,3 +49,25 @@ def test_no_cpu_fallback():
     from distil_whisper_amd.ops_hip import HipOps
     with pytest.raises(RuntimeError, match="no CPU path"):
         HipOps("cuda:0")
+
+
+def test_committed_measurements_are_keyed_by_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py quotes profiles/pmc_traffic.json (roofline.traffic) only when the file was measured with the kernel sources
+    this tree holds (build.kernels_sha16 over csrc/ + the C header); the hash follows every byte of those files."""
+    import argparse
+    import importlib
+    import json
+    from distil_whisper_amd import build
+    sha = build.kernels_sha16()
+    assert len(sha) == 16 and sha == build.kernels_sha16()
+    bench = importlib.import_module("bench")
+    args = argparse.Namespace(model="large-v3", mode="full", batch=32)
+    path = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", "pmc_traffic.json")
+    with open(path) as f:
+        committed = json.load(f)
+    assert "kernels_sha16" in committed and "gemm_t256_NN" in committed["classes"]
+    if committed["kernels_sha16"] == sha:
+        assert bench.pmc_traffic("gemm_t256_NN", args) == committed["classes"]["gemm_t256_NN"]["traffic_bytes_per_launch"]
+    monkeypatch.setattr(bench, "_kernels_sha16", lambda: "0" * 16)          # any other kernel sources: not quoted
+    assert bench.pmc_traffic("gemm_t256_NN", args) is None
+    assert bench.pmc_traffic("gemm_t256_NN", argparse.Namespace(model="small.en", mode="full", batch=32)) is None
