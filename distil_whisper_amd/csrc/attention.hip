@@ -53,7 +53,11 @@ __device__ __forceinline__ void store_t(bf16* base, long ld, long row, bool ok, 
         bf16x4 w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = f2bf(a[g * 4 + e] * mul);
+#ifdef DW_NT_ATTN
+        __builtin_nontemporal_store(w, (bf16x4*)(base + row * ld + cb * 32 + g * 8 + hi * 4));
+#else
         *(bf16x4*)(base + row * ld + cb * 32 + g * 8 + hi * 4) = w;
+#endif
     }
 }
 

@@ -32,6 +32,9 @@ int dw_gemm_wp8_nn_dbg_launch(const GemmP& p, int dbg, hipStream_t s);         /
 int dw_gemm_wp8_nn_launch(const GemmP& p, hipStream_t s);                   // gemm_wp8_*.hip: software-pipelined loop, 8 waves
 int dw_gemm_wp8_nt_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp8_tt_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_nn_w4_launch(const GemmP& p, hipStream_t s);               // gemm_wp16_w4.hip: four waves, 128 x 128 per wave
+int dw_gemm_wp16_nt_w4_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_nn_w4_dbg_launch(const GemmP& p, int dbg, hipStream_t s);
 int dw_gemm_wp16_nn_launch(const GemmP& p, hipStream_t s);                  // gemm_wp16_*.hip: the same loop on v_mfma_f32_16x16x32_bf16
 int dw_gemm_wp16_nn320_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp16_nt_launch(const GemmP& p, hipStream_t s);
@@ -275,6 +278,8 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
                 // (short-K GEMMs with an fp32 residual and fp32 output are epilogue / HBM bound -- 615 MB per launch at
                 // K = 1280 -- and the 16-wave kernel's four waves per SIMD overlap that better: 229 vs 256 us in the step)
                 const bool epi_bound = g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 && g->k <= 2560;
+                if ((v & 16) && wp_ok && !epi_bound && (g_gemm_mi16 & 8) && g_gemm_dbg) return dw_gemm_wp16_nn_w4_dbg_launch(q, g_gemm_dbg, s);
+                if ((v & 16) && wp_ok && !epi_bound && (g_gemm_mi16 & 8)) return dw_gemm_wp16_nn_w4_launch(q, s);
                 if ((v & 16) && wp_ok && !epi_bound && g_gemm_dbg) return dw_gemm_wp8_nn_dbg_launch(q, g_gemm_dbg, s);
                 if ((v & 16) && wp_ok && !epi_bound && (v & 1536)) return dw_gemm_wp8_nn_dbg_launch(q, (v >> 9) & 3, s);
                 if ((v & 16) && wp_ok && !epi_bound && (g_gemm_mi16 & 1) && g_gemm_dbg) return dw_gemm_wp16_nn_dbg_launch(q, g_gemm_dbg, s);
@@ -282,6 +287,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
                 if ((v & 16) && wp_ok && !epi_bound) return (v & 256) ? dw_gemm_wp8_nn_ref_launch(q, s) : dw_gemm_wp8_nn_launch(q, s);
             } else if (!g->trans_a && g->trans_b) {
                 if (((v & 4) && g->k >= 3840 && q.split_k == 1) || (v & 128)) return dw_gemm_phased_launch(q, 0, 1, s);
+                if ((v & 32) && wp_ok && (g_gemm_mi16 & 16)) return dw_gemm_wp16_nt_w4_launch(q, s);
                 if ((v & 32) && wp_ok) return (g_gemm_mi16 & 2) ? dw_gemm_wp16_nt_launch(q, s) : dw_gemm_wp8_nt_launch(q, s);
             } else if (g->trans_a && g->trans_b) {
                 if ((v & 64) && wp_ok) return (g_gemm_mi16 & 4) ? dw_gemm_wp16_tt_launch(q, s) : dw_gemm_wp8_tt_launch(q, s);

@@ -202,6 +202,25 @@ __device__ __forceinline__ int gemm_epi_flavour(const GemmP& p) {
            ((p.zgrad && !p.zg_f16) ? EPI_ZGBF : 0) | (p.r ? EPI_RES : 0) | ((p.r && p.r_dtype == DW_F32) ? EPI_RES_F32 : 0) |
            ((p.r && p.round_res) ? EPI_ROUND : 0) | (p.c_dtype == DW_F32 ? EPI_OUT_F32 : 0) | (p.colsum ? EPI_COLSUM : 0);
 }
+// Stores of the 2-byte outputs (C in bf16, z_out) carry the non-temporal hint.  An output of hundreds of MB written through L2 /
+// the Infinity Cache the default way evicts the operand panels the other workgroups are still reading: sustained, the fc1 shape
+// (N = 5120) gains 4-13 %, fc2 1 %, qkv loses 1 % (tools/gemm_w4_probe.py); the whole step -1.35 % in one process against a
+// build with -DDW_EPI_NT=0 (tools/ab_step.py, tools/build_variant_lib.sh).  fp32 outputs (the residual stream, the weight-gradient
+// slabs) are read again by the next kernel and keep the default policy (NT there: +0.3 %); so do LayerNorm's and the attention
+// kernels' outputs (NT: +0.5 % / +2.9 % -- their consumers run right behind them).
+// Compile time on purpose: with a per-launch flag both store forms sit in every walk and the larger image costs more than the
+// hint returns (and `if (nt) __builtin_nontemporal_store(..) else *p = v` is merged into ONE plain store: the hint is metadata).
+#ifndef DW_EPI_NT
+#define DW_EPI_NT 1
+#endif
+template <class T>
+__device__ __forceinline__ void gemm_store_out(T* dst, const T& v) {
+#if DW_EPI_NT
+    __builtin_nontemporal_store(v, dst);
+#else
+    *dst = v;
+#endif
+}
 template <int F = -1>
 __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], const f32x4& b4, bool plain, bool have_side,
                                               const bf16x4& zs, const f32x4& rs, char* cdst, char* zdst, float (&cs)[4]) {
@@ -217,7 +236,7 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
             bf16x4 z4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) z4[e] = f2bf(v[e]);
-            *(bf16x4*)zdst = z4;
+            gemm_store_out((bf16x4*)zdst, z4);
         }
         if (RT ? p.act == 1 : bool(F & EPI_GELU)) {
             const bool store_g = RT ? (p.z_out && p.zg_f16) : bool(F & EPI_STOREG);
@@ -233,7 +252,7 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
                     g4[e] = (_Float16)g2[0]; g4[e + 1] = (_Float16)g2[1];
                 }
             }
-            if (store_g) *(f16x4*)zdst = g4;
+            if (store_g) gemm_store_out((f16x4*)zdst, g4);
         }
         if (RT ? have_side : (F & (EPI_ZG16 | EPI_ZGBF | EPI_RES)) != 0) {
             if (RT ? (p.zgrad && p.zg_f16) : bool(F & EPI_ZG16)) {    // the forward stored gelu'(z) (fp16 bits in the bf16-typed slots)
@@ -277,7 +296,7 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-        *(bf16x4*)cdst = o;
+        gemm_store_out((bf16x4*)cdst, o);
         if (colsum) {                              // (the values as stored: what a column sum over C would read)
 #pragma unroll
             for (int e = 0; e < 4; ++e) cs[e] += bf2f(o[e]);
@@ -323,7 +342,7 @@ __device__ __forceinline__ void gemm_lds_barrier() {
 // (lane & 15 = row of the 16-row block, register r = column 4 (lane >> 4) + r of the 16-column block).  Either way a lane holds
 // FN * 4 "quads" (4 consecutive columns of one row) per 32-row slab; quad q of slab i sits at row qrow(q) + lane part, column
 // qcol(q) + lane part of the slab.
-template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook, bool SWZ = false, int LAY = 32, class Acc = f32x16[FM][FN]>
+template <int FM, int FN, int TN, int PFDIST = 0, class Hook = GemmNoHook, bool SWZ = false, int LAY = 32, int JOFF = 0, class Acc = f32x16[FM][FN]>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* smem, int wave, int lane,
                                               int m0_, int wm0_, int n0_, int wn0_, int ks_, Hook hook = Hook(),
                                               const float* lds_bias = nullptr, long long* tslot = nullptr) {
@@ -372,7 +391,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
             v4[0] = acc[i][j][g * 4 + 0]; v4[1] = acc[i][j][g * 4 + 1]; v4[2] = acc[i][j][g * 4 + 2]; v4[3] = acc[i][j][g * 4 + 3];
         } else {
             constexpr int h = q / (FN * 2), j = q % (FN * 2);
-            v4 = acc[2 * i + h][j];
+            v4 = acc[2 * i + h][j + JOFF];        // (JOFF: first 16-column block of this call within a wider wave tile)
         }
         return v4;
     };
@@ -514,7 +533,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
                     constexpr long rg = i * 32 + it * 8;
                     const u32x2 lo = *(const u32x2*)(rd + it * 8 * PRS), hi2 = *(const u32x2*)(rd + it * 8 * PRS + 8);
                     u32x4 o4; o4[0] = lo[0]; o4[1] = lo[1]; o4[2] = hi2[0]; o4[3] = hi2[1];
-                    *(u32x4*)(dst_u + rg * ld * 2 + l16) = o4;
+#ifdef DW_EPI_ABLATE      // (profiling builds: key 11 bit 32 = the accumulator-side walk without its global stores)
+                    if (!(p.stage_next & 32) || o4[0] == 0x12345678u)
+#endif
+                    gemm_store_out((u32x4*)(dst_u + rg * ld * 2 + l16), o4);
                 });
             };
             static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {

@@ -51,9 +51,14 @@ __device__ __forceinline__ bf16x8 frag_kmajor16(const char* tile, int x, int ks,
 
 #define PINQ(f) asm volatile("" : "+v"(f))
 
-template <bool TA, bool TB, int BM = 256, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
-    constexpr int BN = 256, WM = 2, WN = 4, NW = 8, TN = 64;
+template <bool TA, bool TB, int BM = 256, int DBG = 0, int WN = 4>
+__global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(const GemmP p) {
+    // WN = 4: eight waves (two per SIMD), 128 x 64 (160 x 64) per wave.  WN = 2: FOUR waves, one per SIMD, 128 x 128 per wave --
+    // 32 fragment reads per 128 MFMAs instead of 24 per 64: the LDS port (128 B per clock: 192 KiB of fragment reads + 64 KiB of
+    // operand DMA per K tile against 2 048 MFMA cycles with eight waves) drops from ~100 % to ~75 % busy.  256 accumulator
+    // registers per wave: the wave owns its SIMD's whole register file (256 VGPR + 256 AGPR).
+    constexpr int BN = 256, WM = 2, NW = WM * WN, TN = BN / WN;
+    static_assert(WN == 4 || (WN == 2 && BM == 256), "wave layouts: 2 x 4, or 2 x 2 on the 256-row tile");
     constexpr int FM = BM / WM / 16, FN = TN / 16;       // 16-row / 16-column blocks of a wave tile: 8 (10) x 4
     constexpr int HM = FM / 2;                           // row blocks of a sub-step
     static_assert(BM == 256 || !TA, "the k-major A image is built for 256-row tiles");
@@ -75,7 +80,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
     GemmJobs jobs;
     gemm_jobs_begin(p, jobs, job_slot);
     while (jobs.cur < jobs.cnt) {
-        gemm_jobs_prefetch(p, jobs, job_slot);
         int tm, tn, ks;
         gemm_job_decode(p, jobs.start + jobs.cur, tm, tn, ks);
         const int m0 = tm * BM, n0 = tn * BN;
@@ -193,18 +197,31 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
         //   * RB: the B fragments of the next k step (kb of buffer bb), each right behind the last MFMA of its column.
         auto substep = [&](auto hc, bf16x8 (&a)[HM], auto lac, bf16x8 (&an)[HM], int kn, int hn, int bn, auto rbc, int kb, int bb,
                            auto vhc, int dbuf) __attribute__((always_inline)) {
-            constexpr int H = decltype(hc)::value;
+            constexpr int H = decltype(hc)::value & 1;
+            constexpr bool TAIL = (decltype(hc)::value & 2) != 0;   // last K tile of the output tile (WN = 2: compiler-visible MFMAs)
             constexpr bool LA = decltype(lac)::value != 0, RB = decltype(rbc)::value != 0;
             constexpr int VH = decltype(vhc)::value;
             constexpr int NLD = VH == 1 ? NH0 : (VH == 2 ? NH1 : 0);
-            constexpr int A0 = NLD > 0 ? HM : 0;          // first slot that carries an A fragment read
-            static_assert(NLD <= HM, "operand loads of a half ride on the MFMAs of column 0");
+            // WN = 4: the operand loads ride on the MFMAs of column 0, the A fragment reads on column 1.  WN = 2: a lone wave per SIMD
+            // stalls on its own VMEM issue when the four waves of the CU push 32 KiB of operand loads at once, so its loads are spread
+            // over the whole sub-step (every DS-th slot, offset 2) and the A fragment reads sit on column 0 (slots 0..HM-1)
+            constexpr int DS = WN == 2 && NLD > 0 ? HM * FN / NLD : 1, DO = WN == 2 ? 2 : 0;
+            constexpr int A0 = WN == 2 ? 0 : (NLD > 0 ? HM : 0);
+            static_assert(WN == 2 || NLD <= HM, "operand loads of a half ride on the MFMAs of column 0");
+            static_assert(DO + (NLD > 0 ? NLD - 1 : 0) * DS < HM * FN, "operand load slots");
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, HM * FN>([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, i = q % HM, j = q / HM;
                 if constexpr (RB && i == 0 && j > 0) ldB1(std::integral_constant<int, j - 1>{}, kb, bb);
-                acc[H * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[H * HM + i][j], 0, 0, 0);
-                if constexpr (q < NLD) dma1(std::integral_constant<int, (VH > 0 ? VH - 1 : 0)>{}, qc, dbuf);
+                if constexpr (WN == 2 && !TAIL)      // all 256 accumulator registers in AGPRs, by constraint: left to the allocator a fifth of
+                    // them live in VGPRs and every MFMA on those is bracketed by v_accvgpr moves behind an s_nop 7
+                    // (the asm is opaque to the hazard recognizer: the LAST K tile, whose results the epilogue's register moves read
+                    // right behind the MFMA, uses the builtin)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[H * HM + i][j]) : "v"(bq[j]), "v"(a[i]));
+                else
+                    acc[H * HM + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[H * HM + i][j], 0, 0, 0);
+                if constexpr (NLD > 0 && q >= DO && (q - DO) % DS == 0 && (q - DO) / DS < NLD)
+                    dma1(std::integral_constant<int, (VH > 0 ? VH - 1 : 0)>{}, std::integral_constant<int, (q - DO) / DS>{}, dbuf);
                 if constexpr (LA && q >= A0 && q < A0 + HM) ldA1(an, std::integral_constant<int, q - A0>{}, kn, hn, bn);
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -224,6 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
         dma(I0{}, 0); dma(I1{}, 0);
         kA += stepA; kB += stepB;
         if (nt > 1) dma(I0{}, 1);
+        gemm_jobs_prefetch(p, jobs, job_slot);      // (behind the operand loads: see gemm_wp.h)
         if (nt > 1) {
             if constexpr (NH0 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (NH0 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -238,17 +256,19 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
         // Entering: aX = A(t, k step 0, half 0), bq = B(t, k step 0).
         auto body = [&](auto m1c, auto m2c, int t) {
             constexpr bool MORE1 = decltype(m1c)::value, MORE2 = decltype(m2c)::value;
+            using H0 = std::integral_constant<int, MORE1 ? 0 : 2>;
+            using H1 = std::integral_constant<int, MORE1 ? 1 : 3>;
             const int buf = t & 1;
             // sub-step 0: (k step 0, half 0); refill aY <- (k step 0, half 1); second half of tile t+1's DMA
             pinA(aX);
-            if constexpr (MORE1) { substep(I0{}, aX, I1{}, aY, 0, 1, buf, I0{}, 0, 0, I2{}, buf ^ 1); kA += stepA; kB += stepB; }
-            else substep(I0{}, aX, I1{}, aY, 0, 1, buf, I0{}, 0, 0, I0{}, 0);
+            if constexpr (MORE1) { substep(H0{}, aX, I1{}, aY, 0, 1, buf, I0{}, 0, 0, I2{}, buf ^ 1); kA += stepA; kB += stepB; }
+            else substep(H0{}, aX, I1{}, aY, 0, 1, buf, I0{}, 0, 0, I0{}, 0);
             // sub-step 1: (k step 0, half 1); refill aX <- (k step 1, half 0), bq <- B(k step 1) column by column
             pinA(aY);
-            substep(I1{}, aY, I1{}, aX, 1, 0, buf, I1{}, 1, buf, I0{}, 0);
+            substep(H1{}, aY, I1{}, aX, 1, 0, buf, I1{}, 1, buf, I0{}, 0);
             // sub-step 2: (k step 1, half 0); refill aY <- (k step 1, half 1)
             pinA(aX);
-            substep(I0{}, aX, I1{}, aY, 1, 1, buf, I0{}, 0, 0, I0{}, 0);
+            substep(H0{}, aX, I1{}, aY, 1, 1, buf, I0{}, 0, 0, I0{}, 0);
             // every wave: its DMA pieces of tile t+1 have landed, its last fragments of tile t are in registers
             pinA(aY);
             if constexpr (MORE1) {
@@ -257,9 +277,9 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // sub-step 3: (k step 1, half 1); refill aX, bq <- tile t+1, k step 0; first half of tile t+2's DMA
-            if constexpr (MORE2) substep(I1{}, aY, I1{}, aX, 0, 0, buf ^ 1, I1{}, 0, buf ^ 1, I1{}, buf);
-            else if constexpr (MORE1) substep(I1{}, aY, I1{}, aX, 0, 0, buf ^ 1, I1{}, 0, buf ^ 1, I0{}, 0);
-            else substep(I1{}, aY, I0{}, aX, 0, 0, 0, I0{}, 0, 0, I0{}, 0);
+            if constexpr (MORE2) substep(H1{}, aY, I1{}, aX, 0, 0, buf ^ 1, I1{}, 0, buf ^ 1, I1{}, buf);
+            else if constexpr (MORE1) substep(H1{}, aY, I1{}, aX, 0, 0, buf ^ 1, I1{}, 0, buf ^ 1, I0{}, 0);
+            else substep(H1{}, aY, I0{}, aX, 0, 0, 0, I0{}, 0, 0, I0{}, 0);
         };
         int t = 0;
         in_loop = true;
@@ -268,9 +288,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
         if (nt >= 2) { body(std::true_type{}, std::false_type{}, t); ++t; }
         body(std::false_type{}, std::false_type{}, t);
 
-        if (!(p.stage_next & 16))
-            gemm_epilogue<FM / 2, FN / 2, TN, (BM == 256 ? 8 : DW_EPF), GemmNoHook, true, 16>(p, acc, smem + STAGE, wave, lane, m0, wm0, n0, wn0, ks,
-                                                                                        GemmNoHook(), tile_in ? bias_lds : nullptr, nullptr);
+        if (!(p.stage_next & 16)) {
+            if constexpr (WN == 4)
+                gemm_epilogue<FM / 2, FN / 2, TN, (BM == 256 ? 8 : DW_EPF), GemmNoHook, true, 16>(p, acc, smem + STAGE, wave, lane, m0, wm0, n0, wn0, ks,
+                                                                                            GemmNoHook(), tile_in ? bias_lds : nullptr, nullptr);
+            else {
+                // 128-column wave tile: the epilogue walks of the 64-column layout, once per column half
+                gemm_epilogue<FM / 2, 2, 64, 8, GemmNoHook, true, 16, 0>(p, acc, smem + STAGE, wave, lane, m0, wm0, n0, wn0, ks,
+                                                                         GemmNoHook(), tile_in ? bias_lds : nullptr, nullptr);
+                gemm_epilogue<FM / 2, 2, 64, 8, GemmNoHook, true, 16, 4>(p, acc, smem + STAGE, wave, lane, m0, wm0, n0, wn0 + 64, ks,
+                                                                         GemmNoHook(), tile_in ? bias_lds : nullptr, nullptr);
+            }
+        }
         else {
             float tsum = 0.f;
 #pragma unroll
@@ -287,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wp16_kernel(const GemmP p) {
     gemm_jobs_end(p, jobs);
 }
 
-template <bool TA, bool TB, int BM = 256, int DBG = 0>
+template <bool TA, bool TB, int BM = 256, int DBG = 0, int WN = 4>
 static int launch_wp16(const GemmP& p0, hipStream_t s) {
     GemmP p = p0;
     const int tiles_m = (p.m + BM - 1) / BM;
@@ -296,7 +325,7 @@ static int launch_wp16(const GemmP& p0, hipStream_t s) {
     p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
     if (nblk > g_gemm_cus) nblk = g_gemm_cus;
-    hipLaunchKernelGGL((gemm_wp16_kernel<TA, TB, BM, DBG>), dim3(nblk), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((gemm_wp16_kernel<TA, TB, BM, DBG, WN>), dim3(nblk), dim3(WN * 128), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -18,6 +18,16 @@ __device__ __forceinline__ f32x4 ld4(const void* x, long off) {
     }
 }
 
+// Output stores.  -DDW_NT_LN=n marks those of level <= n non-temporal (1: y, 2: + the fp32 residual gradient, 3: + its bf16 copy).
+#ifndef DW_NT_LN
+#define DW_NT_LN 0
+#endif
+template <int LEVEL, class T>
+__device__ __forceinline__ void ln_store(T* dst, const T& v) {
+    if constexpr (LEVEL <= DW_NT_LN) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
+}
+
 template <bool XBF, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float* gamma, const float* beta, bf16* y,
                                                      float* mean, float* rstd, int rows, int cols, float eps) {
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float*
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = f2bf((v[j][e] - mu) * rs * g[e] + bt[e]);
-            *(bf16x4*)(y + (long)row * cols + idx * 4) = o;
+            ln_store<1>((bf16x4*)(y + (long)row * cols + idx * 4), o);
         }
     }
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16* x, const
                 o[e] = f2bf((v[j][e] - mu) * rs * g0[e] + b0[e]);
                 o[e + 4] = f2bf((v[j][e + 4] - mu) * rs * g1[e] + b1[e]);
             }
-            *(bf16x8*)(y + (long)row * cols + idx * 8) = o;
+            ln_store<1>((bf16x8*)(y + (long)row * cols + idx * 8), o);
         }
     }
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
@@ -168,14 +178,14 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const v
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] += old[e];
                 }
-                *(f32x4*)dst = o;
+                ln_store<2>((f32x4*)dst, o);
                 if (dres_lowp) {
                     // the low-precision copy the next branch's GEMMs consume (autocast: the gradient of a bf16 Linear
                     // output is bf16) and its column sums = the bias gradient of that Linear
                     bf16x4 lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { lo[e] = f2bf(o[e]); ac[j][e] += bf2f(lo[e]); }
-                    *(bf16x4*)(dres_lowp + (long)row * cols + idx * 4) = lo;
+                    ln_store<3>((bf16x4*)(dres_lowp + (long)row * cols + idx * 4), lo);
                 }
             }
         }

@@ -36,6 +36,9 @@ _libs = {0: ops.lib}
 _base = os.path.join(os.path.dirname(_oh.LIB_PATH), "libdwamd_base.so")
 if os.path.exists(_base):
     _libs[1] = _oh.load_library(_base)
+for _i in (2, 3, 4, 5):
+    if os.path.exists(_base.replace("_base.so", f"_base{_i}.so")):
+        _libs[_i] = _oh.load_library(_base.replace("_base.so", f"_base{_i}.so"))
 step(); torch.cuda.synchronize()
 res = {c: [] for c in configs}
 for r in range(4):
