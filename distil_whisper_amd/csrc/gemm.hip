@@ -74,7 +74,11 @@ static unsigned g_gemm_trace_lo = 0, g_gemm_trace_hi = 0;   // dw_debug_set keys
 // 16-cycle instruction leaves twice the issue gaps for them: 1 127 vs 1 093 TFLOP/s, -2.0 ms per step); the row-major and dX loops
 // tie without their epilogue and lose 1-6 % with it (more live registers around the epilogue walks: 152 / 332 B of scratch), so
 // they keep 32x32x16 (tools/gemm_mi16_probe.py, tools/gemm_mi16_sustained.py, tools/ab_step.py field 15).  Bit-identical results.
-static int g_gemm_mi16 = 4;
+// Bit 32 (default on): row-major GEMMs with K <= 2560, N >= 3840 and a flavour of the accumulator-side walk (QKV, the teacher's fc1)
+// run the 256-row tile on 16x16x32 instead of the 320-row tile on 32x32x16: sustained 1 197 vs 1 182 (N = 3840) and 1 240 vs 1 194
+// TFLOP/s (N = 5120) once the outputs are stored non-temporally (tools/gemm_w4_probe.py), -0.56 % per step; with the fp32 walk
+// (student fc1: two outputs) it loses, +0.5 %.  Bits 8 / 16: the four-wave experiment (gemm_wp16_w4.hip).
+static int g_gemm_mi16 = 36;
 static int g_gemm_dbg = 0;       // dw_debug_set key 19: row-major 256-row GEMMs run the ablation / experiment kernel `value` of gemm_wp8_dbg.hip
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
 
@@ -269,7 +273,11 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
             else if (!g->trans_b) use320 = r320 <= r256 && (!r2rule || (!epi_bound && (g->k >= 2560 || g->n >= 2560)));
             else use320 = r320 < r256 && (r2rule ? g->k >= 2560 : !g->zgrad_in);
         }
+        // Row-major, short K, wide N (QKV and fc1 forward): the 256-row tile on v_mfma_f32_16x16x32_bf16 (dw_debug_set key 20 bit 32)
+        const bool nn16_256 = (g_gemm_mi16 & 32) && (v & 16) && wp_ok && !g->trans_a && !g->trans_b && g->k <= 2560 && g->n >= 3840 &&
+                              !g->r && !g->z_out && !g->zgrad_in && g->c_dtype != DW_F32;      // (the flavours of the accumulator-side walk)
         auto launch256 = [&](const GemmP& q) -> int {
+            if (nn16_256) return dw_gemm_wp16_nn_launch(q, s);
             if (use320) {
                 if (g->trans_b) return (g_gemm_mi16 & 2) ? dw_gemm_wp16_nt320_launch(q, s) : dw_gemm_wp8_nt320_launch(q, s);
                 return (g_gemm_mi16 & 1) ? dw_gemm_wp16_nn320_launch(q, s) : dw_gemm_wp8_nn320_launch(q, s);

@@ -465,10 +465,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
                 constexpr int gi = decltype(gc)::value;
                 constexpr int slot = gi % PFD;
                 constexpr long rg = (gi / NIT) * 32 + (gi % NIT) * RPI;              // first row of the row group in the wave tile
-                if (want_z) zq[slot] = *(const bf16x4*)(zg_u + rg * p.ldzg * 2 + l_zg);
+#ifndef DW_EPI_NT_SIDE
+#define DW_EPI_NT_SIDE 0       // (1: gelu'(z), 2: the residual, 3: both side inputs are read with the non-temporal hint -- experiments)
+#endif
+                if (want_z) {
+                    if constexpr ((DW_EPI_NT_SIDE & 1) != 0) zq[slot] = __builtin_nontemporal_load((const bf16x4*)(zg_u + rg * p.ldzg * 2 + l_zg));
+                    else zq[slot] = *(const bf16x4*)(zg_u + rg * p.ldzg * 2 + l_zg);
+                }
                 if (want_r) {
                     const char* src = r_u + rg * p.ldr * esr + l_r;
-                    if (r_f32) rq[slot] = *(const f32x4*)src;
+                    if (r_f32) {
+                        if constexpr ((DW_EPI_NT_SIDE & 2) != 0) rq[slot] = __builtin_nontemporal_load((const f32x4*)src);
+                        else rq[slot] = *(const f32x4*)src;
+                    }
                     else {
                         const f32x2 t = *(const f32x2*)src;
                         rq[slot][0] = t[0]; rq[slot][1] = t[1];

@@ -79,16 +79,28 @@ __device__ __forceinline__ void wp_dma16u(const i32x4_t& rsrc, unsigned lds_addr
 // ... with the piece's compile-time offset added on the way into M0 (one scalar instruction instead of two)
 // ... and, for the kernels whose pieces differ by a scalar stride (UNI), the piece's scalar offset computed in the wait state the
 // M0 write needs anyway (instead of an s_nop and a separate s_add)
-template <int IMM>
+// (-DDW_DMA_NT=1 / 2 / 3: the loads of the A / B / both operands carry the non-temporal hint -- experiments, see gemm_store_out)
+#ifndef DW_DMA_NT
+#define DW_DMA_NT 0
+#endif
+template <int IMM, bool ISA = true>
 __device__ __forceinline__ void wp_dma16p(const i32x4_t& rsrc, unsigned lds_base, unsigned voffset, int kbase, int piece_off) {
     int so;
-    asm volatile("s_add_u32 m0, %1, %5\n\ts_add_u32 %0, %4, %6\n\tbuffer_load_dwordx4 %2, %3, %0 offen lds"
-                 : "=&s"(so) : "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(kbase), "i"(IMM), "s"(piece_off) : "scc");
+    if constexpr ((DW_DMA_NT & (ISA ? 1 : 2)) != 0)
+        asm volatile("s_add_u32 m0, %1, %5\n\ts_add_u32 %0, %4, %6\n\tbuffer_load_dwordx4 %2, %3, %0 offen nt lds"
+                     : "=&s"(so) : "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(kbase), "i"(IMM), "s"(piece_off) : "scc");
+    else
+        asm volatile("s_add_u32 m0, %1, %5\n\ts_add_u32 %0, %4, %6\n\tbuffer_load_dwordx4 %2, %3, %0 offen lds"
+                     : "=&s"(so) : "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(kbase), "i"(IMM), "s"(piece_off) : "scc");
 }
-template <int IMM>
+template <int IMM, bool ISA = true>
 __device__ __forceinline__ void wp_dma16i(const i32x4_t& rsrc, unsigned lds_base, unsigned voffset, int soffset) {
-    asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset), "i"(IMM) : "scc");
+    if constexpr ((DW_DMA_NT & (ISA ? 1 : 2)) != 0)
+        asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                     :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset), "i"(IMM) : "scc");
+    else
+        asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset), "i"(IMM) : "scc");
 }
 
 // ASMDMA = false builds the same kernel with the operand DMA issued through the compiler builtin (A/B reference only).
@@ -242,10 +254,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
                 const unsigned lb = smem_w + (unsigned)(((DBG & 2) ? (buf & 1) : buf) * STAGE);
                 if constexpr (UNI) {
                     if constexpr (isA) wp_dma16p<i * (NW * 1024)>(ra, lb, offA[0], kA, i * pieceA);
-                    else wp_dma16p<i * (NW * 1024) + BM * 128>(rb, lb, offB[0], kB, i * pieceB);
+                    else wp_dma16p<i * (NW * 1024) + BM * 128, false>(rb, lb, offB[0], kB, i * pieceB);
                 } else {
                     if constexpr (isA) wp_dma16i<i * (NW * 1024)>(ra, lb, offA[i], kA);
-                    else wp_dma16i<i * (NW * 1024) + BM * 128>(rb, lb, offB[i], kB);
+                    else wp_dma16i<i * (NW * 1024) + BM * 128, false>(rb, lb, offB[i], kB);
                 }
             } else {
                 const auto bA = __builtin_amdgcn_make_buffer_rsrc((void*)gA, 0, 0x7fffffff, 0x00020000);

@@ -163,10 +163,10 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
             const unsigned lb = smem_w + (unsigned)(buf * STAGE);
             if constexpr (UNI) {
                 if constexpr (isA) wp_dma16p<i * (NW * 1024)>(rsA, lb, offA[0], kA, i * pieceA);
-                else wp_dma16p<i * (NW * 1024) + BM * 128>(rsB, lb, offB[0], kB, i * pieceB);
+                else wp_dma16p<i * (NW * 1024) + BM * 128, false>(rsB, lb, offB[0], kB, i * pieceB);
             } else {
                 if constexpr (isA) wp_dma16i<i * (NW * 1024)>(rsA, lb, offA[i], kA);
-                else wp_dma16i<i * (NW * 1024) + BM * 128>(rsB, lb, offB[i], kB);
+                else wp_dma16i<i * (NW * 1024) + BM * 128, false>(rsB, lb, offB[i], kB);
             }
         };
         auto dma = [&](auto hc, int buf) __attribute__((always_inline)) {

@@ -112,7 +112,11 @@ __global__ __launch_bounds__(LOSS_NT) void loss_row_kernel(const bf16* s_logits,
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf(0.f);
         }
+#ifdef DW_NT_LOSS        // (experiment)
+        __builtin_nontemporal_store(o, (bf16x8*)(dz + i));
+#else
         *(bf16x8*)(dz + i) = o;
+#endif
     }
 }
 

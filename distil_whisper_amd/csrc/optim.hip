@@ -141,10 +141,17 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* p, const float* g
     const long stride = (long)gridDim.x * 256 * 4;
     for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 3 < n) {
+#ifdef DW_NT_ADAMW      // (experiment: everything this kernel touches is read once and written once per step)
+            f32x4 pv = __builtin_nontemporal_load((f32x4*)(p + i));
+            const f32x4 gv = __builtin_nontemporal_load((const f32x4*)(g + i));
+            f32x4 mv = __builtin_nontemporal_load((f32x4*)(m + i));
+            f32x4 vv = __builtin_nontemporal_load((f32x4*)(v + i));
+#else
             f32x4 pv = *(f32x4*)(p + i);
             const f32x4 gv = *(const f32x4*)(g + i);
             f32x4 mv = *(f32x4*)(m + i);
             f32x4 vv = *(f32x4*)(v + i);
+#endif
             bf16x4 sh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -156,10 +163,17 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* p, const float* g
                 pv[e] -= step_size * (mv[e] / denom);
                 sh[e] = f2bf(pv[e]);
             }
+#ifdef DW_NT_ADAMW
+            __builtin_nontemporal_store(pv, (f32x4*)(p + i));
+            __builtin_nontemporal_store(mv, (f32x4*)(m + i));
+            __builtin_nontemporal_store(vv, (f32x4*)(v + i));
+            if (shadow) __builtin_nontemporal_store(sh, (bf16x4*)(shadow + i));
+#else
             *(f32x4*)(p + i) = pv;
             *(f32x4*)(m + i) = mv;
             *(f32x4*)(v + i) = vv;
             if (shadow) *(bf16x4*)(shadow + i) = sh;
+#endif
         } else {
             for (long j = i; j < n; ++j) {
                 const float gg = g[j] * clip;

@@ -289,7 +289,8 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *           bit 1 K/V append);   key 8  wide LM-head GEMV (default 1)
  *   key 19  row-major 256-row GEMMs run main-loop ablation `value` (1 no fragment reads, 2 no operand DMA, 3 both, 4 DMA that
  *           always hits L2; WRONG results by construction; tools/gemm_dma_diag.py);   key 20  bit mask: software-pipelined GEMM
- *           kernels on v_mfma_f32_16x16x32_bf16 (1 row-major, 2 k-major B, 4 both k-major; default 4; bit-identical results;
+ *           kernels on v_mfma_f32_16x16x32_bf16 (1 row-major, 2 k-major B, 4 both k-major, 32 row-major with K <= 2560 and
+ *           N >= 3840 on the 256-row tile; default 36; bit-identical results;
  *           8 / 16: the four-wave 128 x 128-per-wave experiment for row-major / k-major B, gemm_wp16_w4.hip) */
 int dw_debug_set(int key, int value);
 

@@ -220,7 +220,7 @@ def test_gemm_320_row_tiles_are_bit_identical(ops, ref, tb):
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_16x16x32_main_loop_is_bit_identical(ops, ref, ta, tb):
     """gemm_wp16.h: the software-pipelined main loop on v_mfma_f32_16x16x32_bf16 (dw_debug_set key 20; the default for the
-    weight-gradient layout) -- 16 x 32 fragments under their own LDS swizzles, the k-major image through ds_read_b64_tr_b16 in
+    weight-gradient layout and for wide row-major outputs) -- 16 x 32 fragments under their own LDS swizzles, the k-major image through ds_read_b64_tr_b16 in
     the 16 x 16 x 32 operand order, accumulators as 16 x 16 blocks through the LAY = 16 epilogue.  The hardware accumulates a
     32-deep instruction in the order two 16-deep ones do, so every output bit agrees with the 32x32x16 kernels: each
     layout, 256-row and 320-row tiles, ragged edges, 1..5 and 20 K tiles, persistent walk, every epilogue flavour of the
@@ -241,13 +241,18 @@ def test_gemm_16x16x32_main_loop_is_bit_identical(ops, ref, ta, tb):
             for f in flavours:
                 o = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256, **f)
                 want.append([t.clone() for t in o] if isinstance(o, tuple) else [o.clone()])
-            ops.lib.dw_debug_set(20, 7)
-            for rep in range(2):
-                for f, w in zip(flavours, want):
-                    o = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256, **f)
-                    o = list(o) if isinstance(o, tuple) else [o]
-                    for g_, w_ in zip(o, w):
-                        assert torch.equal(g_, w_), (M, N, K, ta, tb, sorted(f), rep, (g_.float() - w_.float()).abs().max().item())
+            # 7: every layout on 16x16x32; 7 | 32: + the 256-row tile where the 320-row one is the rule's choice; 8 | 16: the four-wave
+            # layout (one wave per SIMD, 128 x 128 per wave, accumulators pinned to AGPRs) for the row-major-A layouts
+            for mask in ((7, 7 | 32) if ta else (7, 7 | 32, 8 | 16)):
+                ops.lib.dw_debug_set(20, mask)
+                if mask & 8: ops.lib.dw_debug_set(0, 115)          # (the four-wave kernels take the 256-row tile's place)
+                for rep in range(2):
+                    for f, w in zip(flavours, want):
+                        o = ops.gemm(a, b, trans_a=ta, trans_b=tb, tile=256, **f)
+                        o = list(o) if isinstance(o, tuple) else [o]
+                        for g_, w_ in zip(o, w):
+                            assert torch.equal(g_, w_), (M, N, K, ta, tb, mask, sorted(f), rep, (g_.float() - w_.float()).abs().max().item())
+                ops.lib.dw_debug_set(0, 2163)
             assert relerr(want[3][0], ref.gemm(a, b, trans_a=ta, trans_b=tb, out_dtype=torch.float32)) < 1e-5
         if ta and tb:       # weight-gradient form with K slices
             a, b = rnd((6400, 1280), 0.5, seed=77), rnd((6400, 384), 0.5, seed=78)
@@ -259,7 +264,8 @@ def test_gemm_16x16x32_main_loop_is_bit_identical(ops, ref, ta, tb):
                 outs.append(o)
             assert torch.equal(outs[0], outs[1])
     finally:
-        ops.lib.dw_debug_set(20, 4)
+        ops.lib.dw_debug_set(20, 36)
+        ops.lib.dw_debug_set(0, 2163)
 
 
 def test_gemm_dynamic_job_handout_is_invisible(ops, ref):

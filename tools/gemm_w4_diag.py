@@ -19,4 +19,4 @@ print("mismatching elements", bad.sum().item(), "of", bad.numel())
 t = bad.view(M // 256, 256, N // 256, 256).any(0).any(1)          # [256 rows of the tile, 256 cols]
 blk = t.view(16, 16, 16, 16).any(1).any(2)                         # 16 x 16 blocks
 for r in range(16): print("".join("X" if blk[r, c] else "." for c in range(16)))
-ops.lib.dw_debug_set(0, 2163); ops.lib.dw_debug_set(20, 4)
+ops.lib.dw_debug_set(0, 2163); ops.lib.dw_debug_set(20, 36)

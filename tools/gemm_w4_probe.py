@@ -14,7 +14,11 @@ bias = torch.randn(5120, device="cuda")
 cases = [c for c in [("NN qkv N=3840 K=1280 bias", 3840, 1280, False, dict(bias=bias[:3840].contiguous())),
          ("NN fc1 N=5120 K=1280 bias", 5120, 1280, False, dict(bias=bias.contiguous())),
          ("NN fc2 N=1280 K=5120 plain", 1280, 5120, False, {}),
-         ("NT dX fc2 N=5120 K=1280 plain", 5120, 1280, True, {})] if os.environ.get("DW_CASE", "") in c[0]]
+         ("NT dX fc2 N=5120 K=1280 plain", 5120, 1280, True, {}),
+         ("NN out N=1280 K=1280 bias+res bf16", 1280, 1280, False, dict(bias=bias[:1280].contiguous(), residual=rnd((M, 1280)))),
+         ("NT dX out N=1280 K=1280 plain", 1280, 1280, True, {}),
+         ("NT dX qkv N=1280 K=3840 plain", 1280, 3840, True, {}),
+         ("NT dX fc1 N=1280 K=5120 plain", 1280, 5120, True, {})] if os.environ.get("DW_CASE", "") in c[0]]
 # (label, GEMM variant key 0, key 20 mask, key 11, key 19)
 configs = [("default", 2163, 4, 1, 0), ("8w-256", 115, 4, 1, 0), ("4w-256", 115, 4 | 8 | 16, 1, 0),
            ("8w-256 no-epi", 115, 4, 17, 0), ("4w-256 no-epi", 115, 4 | 8 | 16, 17, 0), ("8w16-256 no-epi", 115, 7, 17, 0),
@@ -48,4 +52,4 @@ for name, N, K, tb, kw in cases:
             e.record(); torch.cuda.synchronize()
             res[label].append(round(2.0 * M * N * K * n / (s.elapsed_time(e) * 1e-3) / 1e12))
     print(name); [print(f"   {k:24s} {v}", flush=True) for k, v in res.items()]
-ops.lib.dw_debug_set(0, 2163); ops.lib.dw_debug_set(20, 4); ops.lib.dw_debug_set(11, 1); ops.lib.dw_debug_set(19, 0)
+ops.lib.dw_debug_set(0, 2163); ops.lib.dw_debug_set(20, 36); ops.lib.dw_debug_set(11, 1); ops.lib.dw_debug_set(19, 0)
