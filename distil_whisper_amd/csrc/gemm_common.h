@@ -525,7 +525,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
             constexpr bool HAS_G = (F & EPI_STOREG) != 0;
             constexpr int PRS = 136;                  // patch row stride in bytes
             char* const bp = (char*)smem + wave * 8192;
-            const float* const bsrc = lds_bias ? lds_bias + wn0 + lcol : p.bias + n0 + wn0 + lcol;
+            // The bias slice is read from LDS through an LDS-typed pointer.  (It used to be `lds_bias ? lds_bias + .. : p.bias + ..`:
+            // a pointer that may be LDS or global is a GENERIC pointer, every read through it a flat_load, and a flat load's result
+            // is waited for with vmcnt(0) AND lgkmcnt(0) -- eight times per slab the walk stopped until the previous slab's global
+            // stores had been acknowledged.  Tiles without the staged slice take the fp32 walk: see ok16.)
+            typedef __attribute__((address_space(3))) const f32x4 lds_cf32x4_t;
+            typedef __attribute__((address_space(3))) const float lds_cfloat_t;
+            lds_cfloat_t* const bsrc = (lds_cfloat_t*)lds_bias + wn0 + lcol;
             hook();
             gemm_lds_barrier();                       // every wave is done reading the operand tiles
             if (tslot) tslot[5] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -537,47 +543,66 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
             auto flush = [&](char* dst_u, long ld, unsigned l16, auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
+                u32x4 o4[4];           // (all four reads first: one LDS latency per slab instead of four read -> wait -> store rounds)
+                static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
+                    constexpr int it = decltype(itc)::value;
+                    const u32x2 lo = *(const u32x2*)(rd + it * 8 * PRS), hi2 = *(const u32x2*)(rd + it * 8 * PRS + 8);
+                    o4[it][0] = lo[0]; o4[it][1] = lo[1]; o4[it][2] = hi2[0]; o4[it][3] = hi2[1];
+                });
+                __builtin_amdgcn_sched_barrier(0);
                 static_for<0, 4>([&](auto itc) __attribute__((always_inline)) {
                     constexpr int it = decltype(itc)::value;
                     constexpr long rg = i * 32 + it * 8;
-                    const u32x2 lo = *(const u32x2*)(rd + it * 8 * PRS), hi2 = *(const u32x2*)(rd + it * 8 * PRS + 8);
-                    u32x4 o4; o4[0] = lo[0]; o4[1] = lo[1]; o4[2] = hi2[0]; o4[3] = hi2[1];
 #ifdef DW_EPI_ABLATE      // (profiling builds: key 11 bit 32 = the accumulator-side walk without its global stores)
-                    if (!(p.stage_next & 32) || o4[0] == 0x12345678u)
+                    if (!(p.stage_next & 32) || o4[it][0] == 0x12345678u)
 #endif
-                    gemm_store_out((u32x4*)(dst_u + rg * ld * 2 + l16), o4);
+                    gemm_store_out((u32x4*)(dst_u + rg * ld * 2 + l16), o4[it]);
                 });
             };
             static_for<0, FM>([&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 if (i == 1 && tslot) tslot[6] = (long long)__builtin_amdgcn_s_memrealtime();
                 f16x4 gq[HAS_G ? FN * 4 : 1];
-                static_for<0, FN * 4>([&](auto qc) __attribute__((always_inline)) {
-                    constexpr int q = decltype(qc)::value;
+                // (quads in groups of four: their four bias reads are in flight together -- one LDS latency per group, not per quad)
+                static_for<0, FN>([&](auto gc) __attribute__((always_inline)) {
+                f32x4 bb[4];
+                if constexpr ((F & EPI_BIAS) != 0)
+                    static_for<0, 4>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k = decltype(kc)::value;
+                        bb[k] = *(lds_cf32x4_t*)(bsrc + qcol(decltype(gc)::value * 4 + k));
+                    });
+                static_for<0, 4>([&](auto kc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(gc)::value * 4 + decltype(kc)::value;
+                    std::integral_constant<int, q> qc;
+                    // (explicit pairs: left to the vectorizer the four values are paired (1, 2) -- two moves, a packed and two scalar
+                    // adds, three conversions, a permute and an align per quad instead of two packed adds and two packed conversions)
                     const f32x4 a4 = quad(ic, qc);
-                    float v[4] = {a4[0], a4[1], a4[2], a4[3]};
+                    f32x2 p[2];
+                    p[0][0] = a4[0]; p[0][1] = a4[1]; p[1][0] = a4[2]; p[1][1] = a4[3];
                     if constexpr ((F & EPI_BIAS) != 0) {
-                        const f32x4 b4t = *(const f32x4*)(bsrc + qcol(q));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += b4t[e];
+                        const f32x4 b4t = bb[decltype(kc)::value];
+                        f32x2 b0, b1;
+                        b0[0] = b4t[0]; b0[1] = b4t[1]; b1[0] = b4t[2]; b1[1] = b4t[3];
+                        p[0] += b0; p[1] += b1;
                     }
                     if constexpr ((F & EPI_GELU) != 0) {
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
+                        for (int h = 0; h < 2; ++h) {
+                            f32x2 x2; x2[0] = round_bf16(p[h][0]); x2[1] = round_bf16(p[h][1]);
                             f32x2 cdf, pdf;
                             gelu_parts2(x2, cdf, pdf);
-                            v[e] = x2[0] * cdf[0]; v[e + 1] = x2[1] * cdf[1];
+                            p[h] = x2 * cdf;
                             if constexpr (HAS_G) {
                                 const f32x2 g2 = cdf + x2 * pdf;
-                                gq[q][e] = (_Float16)g2[0]; gq[q][e + 1] = (_Float16)g2[1];
+                                gq[q][2 * h] = (_Float16)g2[0]; gq[q][2 * h + 1] = (_Float16)g2[1];
                             }
                         }
                     }
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-                    *(bf16x4*)(wr + qrow(q) * PRS + qcol(q) * 2) = o;
+                    const bf16x2 r0 = __builtin_convertvector(p[0], bf16x2), r1 = __builtin_convertvector(p[1], bf16x2);
+                    u32x2 o;
+                    o[0] = __builtin_bit_cast(unsigned, r0); o[1] = __builtin_bit_cast(unsigned, r1);
+                    *(u32x2*)(wr + qrow(q) * PRS + qcol(q) * 2) = o;
+                });
                 });
                 // (wave-private patch: the compiler's lgkmcnt waits order its LDS writes and reads)
                 flush(c_u, p.ldc, l_c16, ic);
@@ -594,7 +619,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
 #define DW_EPI16 1
 #endif
         // 16-byte accesses of C (and z_out): pointer and leading dimension multiples of 8 elements
-        const bool ok16 = DW_EPI16 && SWZ && p.c_dtype != DW_F32 && ((uintptr_t)p.c & 15) == 0 && (p.ldc & 7) == 0 &&
+        const bool ok16 = DW_EPI16 && SWZ && p.c_dtype != DW_F32 && ((uintptr_t)p.c & 15) == 0 && (p.ldc & 7) == 0 && (!p.bias || lds_bias) &&
                           (!p.z_out || (((uintptr_t)p.z_out & 15) == 0 && (p.ldz & 7) == 0));
 #define DW_EPI_CASE16(F)                                                                             \
     case (F):                                                                                        \
@@ -608,7 +633,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
                 DW_EPI_CASE16(0);                                                              // dX GEMMs, LM head
                 DW_EPI_CASE16(EPI_BIAS);                                                       // QKV / Q / KV projections
                 DW_EPI_CASE16(EPI_BIAS | EPI_GELU);                                            // teacher fc1
-                DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);                               // student fc1 (keeps gelu'(z); two outputs: the fp32 walk is 1 % faster)
+                DW_EPI_CASE(EPI_BIAS | EPI_GELU | EPI_STOREG);                               // student fc1 (keeps gelu'(z); two outputs: the fp32 walk is 1 % faster; 0.5 % per step with non-temporal stores)
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_RES_F32 | EPI_ROUND | EPI_OUT_F32);      // student out-proj / fc2
                 DW_EPI_CASE(EPI_BIAS | EPI_RES | EPI_ROUND);                                  // teacher out-proj / fc2
                 DW_EPI_CASE(EPI_ZG16);                                                        // dX of fc2 (x gelu'(z))

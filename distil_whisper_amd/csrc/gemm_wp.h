@@ -154,6 +154,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     } while (0)
     bool prefetched = false;     // this tile's first operand tile was requested before the previous tile's epilogue
     while (jobs.cur < jobs.cnt) {
+        // The K loop's per-lane addresses (operand-load offsets, fragment addresses) are functions of the lane index alone; derived
+        // from an opaque copy they are recomputed per tile -- a few VALU instructions -- instead of living in 10-16 registers across
+        // the epilogue, whose walks then spill their own addresses (a scratch reload is a VMEM load: its vmcnt wait also waits
+        // for the previous slab's global stores, ~1 us per slab).
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
         DW_TRACE(0);
         gemm_jobs_prefetch(p, jobs, job_slot);
         int tm, tn, ks;
@@ -174,8 +180,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             stepA = 128;
 #pragma unroll
             for (int i = 0; i < CPA; ++i) {
-                const int row = (wave + i * NW) * 8 + (lane >> 3);
-                const int ls = (lane & 7) ^ swz7(row);
+                const int row = (wave + i * NW) * 8 + (lane_k >> 3);
+                const int ls = (lane_k & 7) ^ swz7(row);
                 const int grow = m0 + row < p.m ? row : p.m - 1 - m0;
                 offA[i] = (unsigned)((grow * p.lda + ls * 8) * 2);
             }
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             stepA = 128 * (int)p.lda;
 #pragma unroll
             for (int i = 0; i < CPA; ++i) {
-                const int krow = (wave + i * NW) * 2 + (lane >> 5);
-                const int ls = (lane & 31) ^ ((krow & 3) << 2);
+                const int krow = (wave + i * NW) * 2 + (lane_k >> 5);
+                const int ls = (lane_k & 31) ^ ((krow & 3) << 2);
                 const int gcol = m0 + ls * 8 < p.m ? ls * 8 : 0;
                 offA[i] = (unsigned)((krow * p.lda + gcol) * 2);
             }
@@ -195,8 +201,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             stepB = 128;
 #pragma unroll
             for (int i = 0; i < CP; ++i) {
-                const int row = (wave + i * NW) * 8 + (lane >> 3);
-                const int ls = (lane & 7) ^ swz7(row);
+                const int row = (wave + i * NW) * 8 + (lane_k >> 3);
+                const int ls = (lane_k & 7) ^ swz7(row);
                 const int grow = n0 + row < p.n ? row : p.n - 1 - n0;
                 offB[i] = (unsigned)((grow * p.ldb + ls * 8) * 2);
             }
@@ -205,8 +211,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             stepB = 128 * (int)p.ldb;
 #pragma unroll
             for (int i = 0; i < CP; ++i) {
-                const int krow = (wave + i * NW) * 2 + (lane >> 5);
-                const int ls = (lane & 31) ^ ((krow & 3) << 2);
+                const int krow = (wave + i * NW) * 2 + (lane_k >> 5);
+                const int ls = (lane_k & 31) ^ ((krow & 3) << 2);
                 const int gcol = n0 + ls * 8 < p.n ? ls * 8 : 0;
                 offB[i] = (unsigned)((krow * p.ldb + gcol) * 2);
             }
@@ -280,13 +286,13 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             const char* tB = tA + BM * 128;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                if (TA) af[set][i] = frag_kmajor<BM>(tA, wm0 + i * 32, kk, lane);
-                else af[set][i] = frag_rows(tA, (wm0 >> 5) + i, kk, lane);
+                if (TA) af[set][i] = frag_kmajor<BM>(tA, wm0 + i * 32, kk, lane_k);
+                else af[set][i] = frag_rows(tA, (wm0 >> 5) + i, kk, lane_k);
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                if (TB) bfr[set][j] = frag_kmajor<BN>(tB, wn0 + j * 32, kk, lane);
-                else bfr[set][j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane);
+                if (TB) bfr[set][j] = frag_kmajor<BN>(tB, wn0 + j * 32, kk, lane_k);
+                else bfr[set][j] = frag_rows(tB, (wn0 >> 5) + j, kk, lane_k);
             }
         };
         // The MFMAs of a sub-step with the memory instructions pinned between them: fragment reads in the first gaps

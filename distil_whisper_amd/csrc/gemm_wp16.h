@@ -80,6 +80,12 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
     GemmJobs jobs;
     gemm_jobs_begin(p, jobs, job_slot);
     while (jobs.cur < jobs.cnt) {
+        // The K loop's per-lane addresses (operand-load offsets, fragment addresses) are functions of the lane index alone; derived
+        // from an opaque copy they are recomputed per tile -- a few VALU instructions -- instead of living in 10-16 registers across
+        // the epilogue, whose walks then spill their own addresses (a scratch reload is a VMEM load: its vmcnt wait also waits
+        // for the previous slab's global stores, ~1 us per slab).
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
         int tm, tn, ks;
         gemm_job_decode(p, jobs.start + jobs.cur, tm, tn, ks);
         const int m0 = tm * BM, n0 = tn * BN;
@@ -94,8 +100,8 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
             stepA = 128;
 #pragma unroll
             for (int i = 0; i < CPA; ++i) {
-                const int row = (wave + i * NW) * 8 + (lane >> 3);
-                const int ls = (lane & 7) ^ swz16(row);
+                const int row = (wave + i * NW) * 8 + (lane_k >> 3);
+                const int ls = (lane_k & 7) ^ swz16(row);
                 const int grow = m0 + row < p.m ? row : p.m - 1 - m0;
                 offA[i] = (unsigned)((grow * p.lda + ls * 8) * 2);
             }
@@ -104,8 +110,8 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
             stepA = 128 * (int)p.lda;
 #pragma unroll
             for (int i = 0; i < CPA; ++i) {
-                const int krow = (wave + i * NW) * 2 + (lane >> 5);
-                const int ls = (lane & 31) ^ swk16(krow);
+                const int krow = (wave + i * NW) * 2 + (lane_k >> 5);
+                const int ls = (lane_k & 31) ^ swk16(krow);
                 const int gcol = m0 + ls * 8 < p.m ? ls * 8 : 0;
                 offA[i] = (unsigned)((krow * p.lda + gcol) * 2);
             }
@@ -115,8 +121,8 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
             stepB = 128;
 #pragma unroll
             for (int i = 0; i < CPB; ++i) {
-                const int row = (wave + i * NW) * 8 + (lane >> 3);
-                const int ls = (lane & 7) ^ swz16(row);
+                const int row = (wave + i * NW) * 8 + (lane_k >> 3);
+                const int ls = (lane_k & 7) ^ swz16(row);
                 const int grow = n0 + row < p.n ? row : p.n - 1 - n0;
                 offB[i] = (unsigned)((grow * p.ldb + ls * 8) * 2);
             }
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
             stepB = 128 * (int)p.ldb;
 #pragma unroll
             for (int i = 0; i < CPB; ++i) {
-                const int krow = (wave + i * NW) * 2 + (lane >> 5);
-                const int ls = (lane & 31) ^ swk16(krow);
+                const int krow = (wave + i * NW) * 2 + (lane_k >> 5);
+                const int ls = (lane_k & 31) ^ swk16(krow);
                 const int gcol = n0 + ls * 8 < p.n ? ls * 8 : 0;
                 offB[i] = (unsigned)((krow * p.ldb + gcol) * 2);
             }
@@ -178,15 +184,15 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
             constexpr int i = decltype(ic)::value;
             if constexpr ((DBG & 1) != 0) { if (in_loop) return; }
             const char* tA = smem + buf * STAGE;
-            if (TA) dst[i] = frag_kmajor16<BM>(tA, wm0 + (h * HM + i) * 16, kstep, lane);
-            else dst[i] = frag_rows16(tA, (wm0 >> 4) + h * HM + i, kstep, lane);
+            if (TA) dst[i] = frag_kmajor16<BM>(tA, wm0 + (h * HM + i) * 16, kstep, lane_k);
+            else dst[i] = frag_rows16(tA, (wm0 >> 4) + h * HM + i, kstep, lane_k);
         };
         auto ldB1 = [&](auto jc, int kstep, int buf) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             if constexpr ((DBG & 1) != 0) { if (in_loop) return; }
             const char* tB = smem + buf * STAGE + BM * 128;
-            if (TB) bq[j] = frag_kmajor16<BN>(tB, wn0 + j * 16, kstep, lane);
-            else bq[j] = frag_rows16(tB, (wn0 >> 4) + j, kstep, lane);
+            if (TB) bq[j] = frag_kmajor16<BN>(tB, wn0 + j * 16, kstep, lane_k);
+            else bq[j] = frag_rows16(tB, (wn0 >> 4) + j, kstep, lane_k);
         };
         // One sub-step: the HM x FN MFMAs of row half H (fragments `a`), column-major, in EXACTLY this order with its memory
         // instructions in exactly these gaps (a scheduling barrier closes every slot: left to itself the scheduler bunches the
