@@ -544,12 +544,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
         char* base = smem + buf * 17408;
         stage_tile64<NW, FS>(Q, p.ldq, qt * 64, p.Lq, base, wave, lane);
         stage_tile64<NW, FS>(DO, p.lddo, qt * 64, p.Lq, base + 8192, wave, lane);
-        if (threadIdx.x < 128) {  // waves 0,1: 64 lse + 64 delta values through the same async path (4 B per lane)
-            const int i = threadIdx.x & 63;
-            int qi = qt * 64 + i;
+        if (wave < 2) {  // waves 0,1: 64 lse + 64 delta values through the same async path (4 B per lane; scalar base, 32-bit lane offset)
+            int qi = qt * 64 + lane;
             qi = qi < p.Lq ? qi : p.Lq - 1;
-            const float* src = (threadIdx.x < 64 ? LSE : DEL) + qi;
-            glds4(src, base + 16384 + (threadIdx.x < 64 ? 0 : 256));
+            glds4_so(wave == 0 ? LSE : DEL, (unsigned)qi * 4u, lds_addr_of(base + 16384) + (wave == 0 ? 0 : 256));
         }
     };
 
@@ -755,8 +753,8 @@ extern "C" int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const
     const int fs = g_attn_bwd_stage;
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, block, 0, s, p);
-        if (fs & 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 3>), gk, block, 0, s, p);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 2>), gk, block, 0, s, p);
+        // (two waves per SIMD: since the tile staging went to scalar bases the causal kernel needs 172 registers -- at 168 it spills 9)
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, 2>), gk, block, 0, s, p);
     } else {
         // 384 stationary rows (12 waves = the three waves per SIMD the registers allow, as ONE workgroup) where that pads
         // no more than 128 would: the streamed tiles are fetched and written to LDS once per 384 rows (1500 -> 1536)

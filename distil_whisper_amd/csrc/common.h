@@ -142,18 +142,36 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int cb, int rowbase0
 // Full tiles take the cheap path: a 32-bit per-lane element offset (its lane part is loop invariant, its row0 part
 // is scalar) on top of the uniform base -- the generic 64-bit row * stride product cost ~10 VALU instructions per
 // load in kernels whose VALU is the bottleneck (attention).  Callers guarantee nrows * row_stride < 2^31.
+// Addressing: the tile's base pointer is wave-uniform (scalar registers), the lane part is ONE unsigned 32-bit byte offset and the
+// LDS destination is an integer computed once per call -- `global_load_lds_dwordx4 voffset, s[base]` with M0 = lds + chunk * 1 KiB.
+// (Through a per-lane 64-bit pointer and a generic LDS pointer every chunk cost a 64-bit multiply-add, a 64-bit shift-add and
+// the generic -> LDS conversion with its null check -- ~6 vector and ~8 scalar instructions per chunk in kernels whose vector
+// unit is the bottleneck -- and two 64-bit lane offsets per operand; the dK/dV kernel spilled one and reloaded it inside its loop
+// behind a vmcnt(0) that also waited for the chunk just requested.)
+__device__ __forceinline__ void glds16_so(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void glds4_so(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* lds) {       // wave-uniform LDS byte address of a __shared__ object
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_void_t*)lds);
+}
 template <int NW, bool FAST = true>
 __device__ __forceinline__ void stage_tile64(const bf16* base, long row_stride, int row0, int nrows, char* lds,
                                              int wave, int lane) {
+    static_assert(NW == 4 || NW == 8 || NW == 12 || NW == 2, "chunk c = wave + i * NW: rows 8 c + (lane >> 3)");
     const int ld = (int)row_stride;
-    if (FAST && row0 + 64 <= nrows) {
-        const int off0 = __builtin_amdgcn_readfirstlane(row0 * ld);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_void_t*)lds);
+    if (row0 + 64 <= nrows) {
+        // Full tile (every tile but the last): chunk i of a wave differs from its chunk 0 by i * NW * 8 rows -- the swizzle only
+        // looks at row bits 1-3 -- so ONE loop-invariant lane offset serves all of them and the rest is scalar.
+        const int row = wave * 8 + (lane >> 3);
+        const unsigned voff = (unsigned)(row * ld + (((lane & 7) ^ swz7(row)) << 3)) * 2u;
 #pragma unroll
         for (int c = wave; c < 8; c += NW) {
-            const int row = c * 8 + (lane >> 3);
-            const int ls = (lane & 7) ^ swz7(row);
-            const unsigned off = (unsigned)(off0 + (row * ld + ls * 8));
-            glds16(base + off, lds + c * 1024);
+            const bf16* tb = base + (long)__builtin_amdgcn_readfirstlane((row0 + (c - wave) * 8) * ld);
+            glds16_so(tb, voff, lds0 + c * 1024);
         }
     } else {
 #pragma unroll
@@ -162,7 +180,7 @@ __device__ __forceinline__ void stage_tile64(const bf16* base, long row_stride, 
             const int ls = (lane & 7) ^ swz7(row);
             int grow = row0 + row;
             grow = grow < nrows ? grow : nrows - 1;
-            glds16(base + (unsigned)(grow * ld + ls * 8), lds + c * 1024);
+            glds16_so(base, (unsigned)(grow * ld + ls * 8) * 2u, lds0 + c * 1024);
         }
     }
 }

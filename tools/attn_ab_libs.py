@@ -9,8 +9,9 @@ _new = ops.lib
 _base = ops_hip.load_library(os.path.join(os.path.dirname(ops_hip.LIB_PATH), "libdwamd_base.so"))
 # tag -> (library, {dw_debug_set key: value}): 16 / 17 = waves per workgroup of the forward / backward kernels, 18 = 1: plain
 # workgroup order instead of the XCD-aware one
-libs = {"base": (_base, {}), "new": (_new, {16: 8, 17: 12, 18: 0}), "new plain order": (_new, {16: 8, 17: 12, 18: 1}),
-        "new 4 waves": (_new, {16: 4, 17: 4, 18: 0})}
+libs = {"base": (_base, {16: 4, 17: 4, 18: 0}), "new": (_new, {16: 4, 17: 4, 18: 0})}
+if os.environ.get("DW_ATTN_VARIANTS"):
+    libs.update({"new plain order": (_new, {16: 4, 17: 4, 18: 1}), "new 8 / 12 waves": (_new, {16: 8, 17: 12, 18: 0})})
 D, H = 1280, 20
 def timed(fn, n=10):
     for _ in range(2): fn()
