@@ -20,7 +20,7 @@ def kernels(asm):
     lines = asm.split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
     for s in starts:
-        e = next((i for i in range(s, len(lines)) if lines[i].strip().startswith("s_endpgm")), None)
+        e = next((i for i in range(s, len(lines)) if lines[i].startswith(".Lfunc_end")), None)
         if e is not None:
             yield lines[s].split(":")[0], lines[s:e]
 
