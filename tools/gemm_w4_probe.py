@@ -16,6 +16,8 @@ cases = [c for c in [("NN qkv N=3840 K=1280 bias", 3840, 1280, False, dict(bias=
          ("NN fc2 N=1280 K=5120 plain", 1280, 5120, False, {}),
          ("NT dX fc2 N=5120 K=1280 plain", 5120, 1280, True, {}),
          ("NN out N=1280 K=1280 bias+res bf16", 1280, 1280, False, dict(bias=bias[:1280].contiguous(), residual=rnd((M, 1280)))),
+         ("NN out32 N=1280 K=1280 bias+res fp32", 1280, 1280, False, dict(bias=bias[:1280].contiguous(), residual=torch.randn(M, 1280, device="cuda"), out_dtype=torch.float32)),
+         ("NN fc2-32 N=1280 K=5120 bias+res fp32", 1280, 5120, False, dict(bias=bias[:1280].contiguous(), residual=torch.randn(M, 1280, device="cuda"), out_dtype=torch.float32)),
          ("NT dX out N=1280 K=1280 plain", 1280, 1280, True, {}),
          ("NT dX qkv N=1280 K=3840 plain", 1280, 3840, True, {}),
          ("NT dX fc1 N=1280 K=5120 plain", 1280, 5120, True, {})] if os.environ.get("DW_CASE", "") in c[0]]
@@ -28,7 +30,7 @@ if os.environ.get('DW_CFG'): configs = eval(os.environ['DW_CFG'])
 SEC = float(os.environ.get("DW_SEC", "1.5"))
 for name, N, K, tb, kw in cases:
     a = rnd((M, K)); b = rnd((K, N) if tb else (N, K), 0.05)
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty(M, N, device="cuda", dtype=kw.pop("out_dtype", torch.bfloat16))
     ref = None
     res = {c[0]: [] for c in configs}
     for r in range(2):
