@@ -6,10 +6,14 @@ from distil_whisper_amd import ops_hip
 from distil_whisper_amd.ops_hip import HipOps
 ops = HipOps("cuda:0")
 _new = ops.lib
-_base = ops_hip.load_library(os.path.join(os.path.dirname(ops_hip.LIB_PATH), "libdwamd_base.so"))
+_bp = os.path.join(os.path.dirname(ops_hip.LIB_PATH), "libdwamd_base.so")
+_base = ops_hip.load_library(_bp) if os.path.exists(_bp) else _new
 # tag -> (library, {dw_debug_set key: value}): 16 / 17 = waves per workgroup of the forward / backward kernels, 18 = 1: plain
 # workgroup order instead of the XCD-aware one
 libs = {"base": (_base, {16: 4, 17: 4, 18: 0}), "new": (_new, {16: 4, 17: 4, 18: 0})}
+if os.environ.get("DW_ATTN_STAGE"):      # dw_debug_set key 3 (bit 0: dq, bit 1: dkv 32-bit staging flag, bit 2: dkv at three waves per SIMD)
+    libs = {f"stage {v}": (_new, {16: 4, 17: 4, 18: 0, 3: v}) for v in (5, 1, 7, 3)}
+    libs["base"] = libs.pop("stage 5")
 if os.environ.get("DW_ATTN_VARIANTS"):
     libs.update({"new plain order": (_new, {16: 4, 17: 4, 18: 1}), "new 8 / 12 waves": (_new, {16: 8, 17: 12, 18: 0})})
 D, H = 1280, 20
