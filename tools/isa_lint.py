@@ -36,14 +36,39 @@ def census(seg):
 
 
 def loops(body):
+    """Innermost loops that hold MFMAs.  A loop may be rotated (its latch block sits in front of the header label): the loop runs
+    from the closest back-edge target at or before an `Inner Loop Header` label to the last branch to that target."""
     labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    def is_header(i):        # (the remark is on the label's line, or on one of the comment lines right under it when the loop is nested)
+        if not re.match(r"^\.LBB\d+_\d+:", body[i]):
+            return False
+        j = i
+        while True:
+            if "Inner Loop Header" in body[j]:
+                return True
+            j += 1
+            if j >= len(body) or j > i + 6 or not body[j].lstrip().startswith(";"):
+                return False
+    headers = [i for i in range(len(body)) if is_header(i)]
+    back = []
     for i, l in enumerate(body):
         m = re.match(r"\s+s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
-            seg = body[labels[m.group(1)]:i]
-            n = sum("v_mfma" in x for x in seg)
-            if 0 < n <= 256 and not any("Loop Header" in x and x.startswith(".LBB") for x in seg[1:]):
-                yield labels[m.group(1)], i, seg
+            back.append((i, labels[m.group(1)]))
+    seen = set()
+    for h in headers:
+        nxt = min([x for x in headers if x > h], default=len(body))
+        cand = [(i, t) for i, t in back if h < i and t <= h and i < nxt + 4000]
+        if not cand:
+            continue
+        t0 = max(t for _, t in cand)
+        end = max(i for i, t in cand if t == t0)
+        if (t0, end) in seen:
+            continue
+        seen.add((t0, end))
+        seg = body[t0:end]
+        if any("v_mfma" in x for x in seg):
+            yield t0, end, seg
 
 
 def main():
