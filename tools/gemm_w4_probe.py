@@ -37,6 +37,7 @@ for name, N, K, tb, kw in cases:
         for label, v, mi, sn, dbg, *rest in configs:
             ops.lib = libs[rest[0] if rest else 0]
             ops.lib.dw_debug_set(0, v); ops.lib.dw_debug_set(20, mi); ops.lib.dw_debug_set(11, sn); ops.lib.dw_debug_set(19, dbg)
+            ops.lib.dw_debug_set(1, rest[1] if len(rest) > 1 else 0)          # optional 7th config field: strip width override
             out.zero_()
             for _ in range(3): ops.gemm(a, b, trans_b=tb, out=out, tile=256, **kw)
             torch.cuda.synchronize()
@@ -54,4 +55,4 @@ for name, N, K, tb, kw in cases:
             e.record(); torch.cuda.synchronize()
             res[label].append(round(2.0 * M * N * K * n / (s.elapsed_time(e) * 1e-3) / 1e12))
     print(name); [print(f"   {k:24s} {v}", flush=True) for k, v in res.items()]
-ops.lib.dw_debug_set(0, 2163); ops.lib.dw_debug_set(20, 36); ops.lib.dw_debug_set(11, 1); ops.lib.dw_debug_set(19, 0)
+ops.lib.dw_debug_set(0, 2163); ops.lib.dw_debug_set(20, 36); ops.lib.dw_debug_set(11, 1); ops.lib.dw_debug_set(19, 0); ops.lib.dw_debug_set(1, 0)
