@@ -342,7 +342,7 @@ def main():
                         "avg_launch_ms": p["ms"] / p["n"], "flops_per_launch": p["flops"] / p["n"],
                         "achieved": p["flops"] / (p["ms"] * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                         "frac": p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
-                        "traffic": pmc_traffic(key, args),
+                        "traffic": pmc_traffic(key, args, p["n"]),
                         "vendor_library_tflops": vendor_ceiling(),
                         "attention_vendor_tflops": attn_vendor_ceiling(),
                         "all_gemm_ms": sum(v["ms"] for k, v in prof.items() if k.startswith("gemm")),
@@ -560,7 +560,7 @@ def attn_vendor_ceiling():
     return None
 
 
-def pmc_traffic(key, args):
+def pmc_traffic(key, args, launches_counted=None):
     """L2-fabric-side bytes per launch of the reported kernel class, from the committed PMC passes of this same
     workload (tools/pmc_traffic.py; FETCH_SIZE and WRITE_SIZE cannot be collected inside a timed run).  None -- with the
     reason logged -- when the committed summary is for another workload, does not hold the class, or was measured with
@@ -576,7 +576,17 @@ def pmc_traffic(key, args):
             f"this run has {sha}: not quoted (re-take it with tools/profile_round.sh)")
         return None
     c = j.get("classes", {}).get(key)
-    return None if c is None else c["traffic_bytes_per_launch"]
+    if c is None:
+        log(f"roofline.traffic: profiles/pmc_traffic.json holds no class {key}: not quoted")
+        return None
+    # the PMC passes must have seen the launches this run's instrumented step counted for the class: a kernel symbol missing
+    # from tools/pmc_traffic.py's table (round 4: gemm_wp16_kernel) silently drops launches from the average otherwise
+    per_step = c.get("launches_per_step", c["launches"] / max(1, j.get("steps_profiled", 2)))
+    if launches_counted is not None and abs(per_step - launches_counted) > 0.02 * launches_counted:
+        log(f"roofline.traffic: profiles/pmc_traffic.json covers {per_step:.0f} launches per step of {key}, the instrumented "
+            f"step counted {launches_counted}: not quoted (a kernel symbol is missing from tools/pmc_traffic.py CLASS_OF?)")
+        return None
+    return c["traffic_bytes_per_launch"]
 
 
 def log(msg):
