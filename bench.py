@@ -89,6 +89,13 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one device); a test of the "
                          "launcher, the rank plumbing and the data-parallel step, not a measurement")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="seconds a gradient bucket may stay pending before the rank ends with an error naming it "
+                         "(distill.BucketWatchdog; N > 1 only)")
+    ap.add_argument("--cu-hog", type=int, default=0,
+                    help="emulate a resident communication kernel: keep this many CUs busy on a side stream during every timed "
+                         "step (tools/cu_hog.hip; a one-GPU stand-in for RCCL's channels, used with --share-device)")
+    ap.add_argument("--cu-hog-ms", type=float, default=400.0, help="milliseconds of CU occupancy queued per step with --cu-hog")
     ap.add_argument("--no-reference-loop", action="store_true",
                     help="skip the `via_reference_loop` leg (the reference's loop body -- model(**batch), its own fp32 softmax / "
                          "KL lines, loss.backward(), clip_grad_norm_, torch.optim.AdamW -- over the drop-in modules)")
@@ -125,10 +132,16 @@ def main():
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         os.environ.setdefault("NCCL_MIN_NCHANNELS", "4")
         torch.cuda.set_device(local_rank)
+        # a collective that never completes must end the run with a message, not hang it: torch's own watchdog gets the same
+        # deadline as the per-bucket one (distill.BucketWatchdog names the bucket; this one covers init and the barriers)
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=max(60.0, 4 * args.comm_timeout))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"),
+                                    timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
     dev = f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
 
@@ -154,7 +167,8 @@ def main():
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
                              mel_filters=filt, overlap_teacher=side and not args.no_teacher_overlap,
                              overlap_wgrad=side and not args.no_wgrad_overlap,
-                             pad_teacher_rows=not args.no_pad_teacher_rows)
+                             pad_teacher_rows=not args.no_pad_teacher_rows,
+                             comm_watchdog_s=args.comm_timeout if world > 1 else 0.0)
     del t_sd, s_sd
     torch.cuda.empty_cache()
 
@@ -201,6 +215,27 @@ def main():
         lab_i, lens_i = fresh[fresh_i[0] % len(fresh)]
         fresh_i[0] += 1
         return tr.train_step_graphed(audio, dec_in, lab_i, valid_len=lens_i)
+
+    if args.cu_hog > 0:
+        # `--cu-hog N`: N workgroups that each hold a CU (64 KiB of LDS: no GEMM workgroup fits beside one) spin on a side
+        # stream while the step runs -- what RCCL's channel kernels do to the persistent GEMM grids, on one GPU
+        import ctypes
+        import subprocess
+        tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
+        so = os.path.join(tools, "libcuhog.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
+                                   os.path.join(tools, "cu_hog.hip"), "-o", so])
+        hog = ctypes.CDLL(so)
+        hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        hog_stream, hog_sink = torch.cuda.Stream(), torch.zeros(4, device=dev)
+        hog_reps = max(1, int(args.cu_hog_ms / 5.0 + 0.5))
+        plain_step = one_step
+
+        def one_step():
+            for _ in range(hog_reps):
+                hog.hog_launch(args.cu_hog, 5000, hog_sink.data_ptr(), ctypes.c_void_p(hog_stream.cuda_stream))
+            return plain_step()
 
     def sync():
         if world > 1:
@@ -394,7 +429,7 @@ def main():
                           "parallelism": f"dp{world}" + (f" ({args.backend}, ranks share cuda:0: plumbing test)" if args.share_device else ""), "mode": args.mode, "includes": "logmel+teacher_fwd+student_fwd_"
                           "bwd+allreduce+clip+adamw", "loss": loss_val},
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
-               "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": step_mode,
+               "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": step_mode, "cu_hog": args.cu_hog or None,
                "mode_selection": selection, "step_stats": step_stats,
                "kernels_sha16": _kernels_sha16(),
                "ab": ab, "via_reference_loop": via_loop, "roofline": roofline, "cpu_baseline": cpu_baseline}
@@ -431,9 +466,12 @@ def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_hos
         student.freeze_encoder()
     out = {"steps": steps, "warmup": warm, "optimizer": "torch.optim.AdamW (two groups) + clip_grad_norm_", "unit": "ms/step"}
 
-    def leg(with_len, fused):
+    def leg(with_len, fused, fused_opt=False):
+        import functools
+        from distil_whisper_amd.optim import FusedAdamW
         loop = ReferenceLoop(student, teacher, M.BaseModelOutput, share_hidden_states=recipe, teacher_dtype=torch.bfloat16,
-                             fused_loss=M.fused_distillation_loss if fused else None)
+                             fused_loss=M.fused_distillation_loss if fused else None,
+                             optimizer_cls=functools.partial(FusedAdamW, model=student) if fused_opt else None)
 
         def one():
             feats = ops.logmel(audio, filt)                      # (the front end is part of the step, as in the main run)
@@ -452,9 +490,14 @@ def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_hos
         t = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         return {"median_ms": t[len(t) // 2], "audio_s_per_s": B * 30e3 / t[len(t) // 2], "loss": float(m["loss"].item())}
     out["verbatim"] = leg(False, False)
+    # the same loop body with distil_whisper_amd.optim.FusedAdamW in place of torch.optim.AdamW and its clip_grad_norm_ in
+    # place of accelerator.clip_grad_norm_ (two changed lines of the script; same parameter groups, same LambdaLR)
+    out["verbatim_with_fused_optimizer"] = leg(False, False, True)
     if not recipe:       # (the shared-encoder teacher call of the reference passes labels only: no lengths reach it)
         out["with_valid_len"] = leg(True, False)
         out["with_valid_len_and_fused_kd_loss"] = leg(True, True)
+    # (shared encoder: the one-call loss takes the student's rows out of the teacher's full logits)
+    out["with_valid_len_fused_kd_loss_and_fused_optimizer"] = leg(True, True, True)
     return out
 
 

@@ -275,7 +275,8 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         }
         // Row-major, short K, wide N (QKV and fc1 forward): the 256-row tile on v_mfma_f32_16x16x32_bf16 (dw_debug_set key 20 bit 32)
         const bool nn16_256 = (g_gemm_mi16 & 32) && (v & 16) && wp_ok && !g->trans_a && !g->trans_b && g->k <= 2560 && g->n >= 3840 &&
-                              !g->r && !g->z_out && !g->zgrad_in && g->c_dtype != DW_F32;      // (the flavours of the accumulator-side walk)
+                              !g->r && !g->z_out && !g->zgrad_in && g->c_dtype != DW_F32 &&    // (the flavours of the accumulator-side walk)
+                              !one_round_320 && !(v & 4096) && !g_gemm_dbg;   // (a forced / single-round 320-row tile and the ablation path keep their kernel)
         auto launch256 = [&](const GemmP& q) -> int {
             if (nn16_256) return dw_gemm_wp16_nn_launch(q, s);
             if (use320) {

@@ -12,6 +12,11 @@ Data parallelism: the flat fp32 gradient buffer is all-reduced with RCCL (torch.
 in layer-ordered buckets on a side stream while the backward of earlier layers is still running.
 """
 import numbers
+import os
+import queue
+import sys
+import threading
+import time
 
 import torch
 
@@ -26,11 +31,52 @@ def shift_tokens_right(labels, pad_token_id, decoder_start_token_id):
     return out.masked_fill(out == -100, pad_token_id)
 
 
+class BucketWatchdog(threading.Thread):
+    """A collective that never completes (a rank that died, a wedged xGMI link, mismatched bucket sizes) shows up as a
+    silent hang at the next synchronisation, minutes later and far from its cause.  Every gradient bucket therefore leaves
+    an event behind itself; this daemon thread polls them (`Event.query()`, no synchronisation, nothing on the enqueuing
+    thread's path) and, when one is still pending `timeout_s` after it was issued, prints ONE line naming the step, the
+    bucket and its element range and ends the process (exit code 124) -- the other ranks' own watchdogs then do the same.
+    `on_timeout` replaces the exit (tests)."""
+
+    def __init__(self, timeout_s, rank=0, on_timeout=None, poll_s=0.05):
+        super().__init__(daemon=True, name="grad-bucket-watchdog")
+        self.timeout_s, self.rank, self.on_timeout, self.poll_s = float(timeout_s), rank, on_timeout, poll_s
+        self.q = queue.Queue()
+        self.fired = None
+
+    def submit(self, label, done):
+        """done: a zero-argument callable that is True once the bucket has completed (Event.query for device buckets)."""
+        self.q.put((time.monotonic(), label, done))
+
+    def run(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            t0, label, done = item
+            while not done():
+                if time.monotonic() - t0 > self.timeout_s:
+                    msg = (f"[rank {self.rank}] gradient all-reduce watchdog: {label} still pending {self.timeout_s:.0f} s after it "
+                           f"was issued -- a peer rank is gone or the collective is wedged; ending this rank")
+                    self.fired = msg
+                    sys.stderr.write(msg + "\n")
+                    sys.stderr.flush()
+                    if self.on_timeout is not None:
+                        self.on_timeout(msg)
+                        break
+                    os._exit(124)
+                time.sleep(self.poll_s)
+
+    def stop(self):
+        self.q.put(None)
+
+
 class GradReducer:
     """Bucketed all-reduce (sum) of ranges of the flat gradient buffer, issued on a communication stream as soon as a
-    range is final.  With world_size 1 (or no process group) it is a no-op."""
+    range is final.  With world_size 1 (or no process group) it is a no-op.  `watchdog_s` > 0: see BucketWatchdog."""
 
-    def __init__(self, flat, group=None, bucket_bytes=256 << 20, always_reduce=False):
+    def __init__(self, flat, group=None, bucket_bytes=256 << 20, always_reduce=False, watchdog_s=0.0, on_timeout=None):
         import torch.distributed as dist
         self.flat, self.group, self.dist = flat, group, dist
         self.initialized = dist.is_available() and dist.is_initialized()
@@ -43,9 +89,18 @@ class GradReducer:
         self.cuda = flat.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.active) else None
         self.also_wait = []
+        self.labels = []
+        self.step = 0
+        self.watchdog = None
+        if self.active and watchdog_s and watchdog_s > 0:
+            rank = dist.get_rank(group) if self.initialized else 0
+            self.watchdog = BucketWatchdog(watchdog_s, rank, on_timeout)
+            self.watchdog.start()
 
     def _launch(self, lo, hi):
         view = self.flat[lo:hi]
+        self.labels.append(f"step {self.step} bucket {len(self.handles)}: elements [{lo}, {hi}) of the flat gradient "
+                           f"({(hi - lo) * 4 / 2**20:.0f} MiB)")
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
             for w in self.also_wait:      # streams that also write gradients (the engine's weight-gradient stream)
@@ -72,6 +127,7 @@ class GradReducer:
         """Sum a small device tensor over the ranks on the communication stream (joined by wait())."""
         if not self.active:
             return
+        self.labels.append(f"step {self.step} small tensor {tuple(t.shape)} (optimizer-skip gate)")
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.stream):
@@ -86,9 +142,23 @@ class GradReducer:
 
     def wait(self):
         self.flush()
-        for h in self.handles:
-            h.wait()
-        self.handles = []
+        # the handles complete in issue order on the communication stream: h.wait() makes that stream wait for the
+        # collective (it does not block the host for device tensors); an event behind each one tells the watchdog WHICH
+        # bucket is the first that never finished
+        watch = self.watchdog is not None and self.stream is not None and not torch.cuda.is_current_stream_capturing()
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                for h, label in zip(self.handles, self.labels):
+                    h.wait()
+                    if watch:
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                        self.watchdog.submit(label, ev.query)
+        else:
+            for h in self.handles:
+                h.wait()
+        self.handles, self.labels = [], []
+        self.step += 1
         if self.stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
 
@@ -137,7 +207,7 @@ class DistillationTrainer:
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
                  share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None,
                  overlap_teacher=False, overlap_wgrad=False, pad_teacher_rows=False, bucket_bytes=256 << 20,
-                 always_reduce=False):
+                 always_reduce=False, comm_watchdog_s=0.0):
         self.ops = ops
         self.sdims, self.tdims = WhisperDims.from_any(student_dims), WhisperDims.from_any(teacher_dims)
         frozen = []
@@ -164,7 +234,8 @@ class DistillationTrainer:
         self._gate = None            # f32[1] on the device: labels counted in the micro-batches of the current step
         self._graph = None           # the captured whole-step HIP graph in use (train_step_graphed)
         self._graphs, self._graph_inputs = {}, None   # every captured plan by (shapes, live decoder positions); shared inputs
-        self.reducer = GradReducer(st.G, process_group, bucket_bytes, always_reduce) if st.G is not None else None
+        self.reducer = GradReducer(st.G, process_group, bucket_bytes, always_reduce, watchdog_s=comm_watchdog_s) \
+            if st.G is not None else None
         self.world = self.reducer.world if self.reducer else 1
         self.mel_filters = mel_filters
         # optional: the frozen teacher forward is independent of the student forward until the loss and can run on a

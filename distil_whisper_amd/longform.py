@@ -203,7 +203,10 @@ class LongFormTranscriber:
             # start and prompt ids this decoder knows are always added; a tokenizer's all_special_ids can be passed)
             self.special_ids = set(range(int(eos_token_id), self.timestamp_begin)) if special_ids is None else set(special_ids)
             self.special_ids |= {int(eos_token_id), int(d.pad_token_id), int(d.decoder_start_token_id)}
-            self.special_ids |= {int(t) for t in self.prompt.tolist()}
+            # prompt ids: only the control tokens (>= the first special id).  A prompt that carries previous-text conditioning
+            # (<|startofprev|> + text ids + <|startoftranscript|> ...) holds ordinary vocabulary ids too; adding those would
+            # drop every later occurrence of the same words from the stitched segments.
+            self.special_ids |= {int(t) for t in self.prompt.tolist() if int(t) >= int(self.first_special)}
             rules = dict(begin_index=len(self.prompt), no_timestamps_token_id=int(no_timestamps_token_id),
                          max_initial_timestamp_index=max_initial_timestamp_index)
         self.decoder = GreedyDecoder(model.engine, self.B, len(self.prompt) + self.max_new, eos_token_id=eos_token_id,

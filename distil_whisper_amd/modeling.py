@@ -457,9 +457,18 @@ def fused_distillation_loss(student_outputs, teacher_outputs, labels, temperatur
         raise ValueError("fused_distillation_loss needs outputs of distil_whisper_amd.WhisperForConditionalGeneration")
     model = student_outputs._model
     sel = student_outputs._rows
-    if (sel is None) != (teacher_outputs._rows is None) or (sel is not None and not sel.same_as(teacher_outputs._rows)):
+    t_sel = teacher_outputs._rows
+    if sel is not None and t_sel is None:
+        # The reference's shared-encoder call `teacher_model(encoder_outputs=..., labels=...)` (run_distillation.py:1478)
+        # carries no `valid_len`: the teacher computed all B * T rows.  Take the student's rows out of them (a row gather of
+        # the teacher's low-precision logits: B * Te * V * 2 B of traffic, against a step-0 ValueError before).
+        BT = sel.B * sel.T
+        if t_buf.shape[0] < BT:
+            raise ValueError("fused_distillation_loss: the teacher's logits do not cover the student's batch")
+        t_buf = sel.select(t_buf[:BT]).contiguous()
+    elif (sel is None) != (t_sel is None) or (sel is not None and not sel.same_as(t_sel)):
         raise ValueError("fused_distillation_loss: student and teacher outputs were computed over different decoder "
-                         "positions (pass the same valid_len to both forwards)")
+                         "positions (pass the same valid_len to both forwards, or none to the teacher)")
     loss, losses = _FusedLossFn.apply(student_outputs.logits, model.ops, s_buf, t_buf, labels, model.dims.vocab,
                                       float(temperature), float(ce_weight), float(kl_weight), sel)
     return loss, {"loss": losses[2], "ce_loss": losses[0], "kl_loss": losses[1]}

@@ -1,0 +1,177 @@
+"""`torch.optim.Optimizer` over the fused clip + AdamW kernels, for users of the REFERENCE's training loop.
+
+The reference builds `torch.optim.AdamW` over two parameter groups (decay / no decay for LayerNorm parameters and biases,
+run_distillation.py:1377-1407), clips with `accelerator.clip_grad_norm_` (1611) and steps (1612-1614).  Over the drop-in
+modules that costs ~44 ms of a 430 ms step at large-v3 (round 4: `via_reference_loop`): `clip_grad_norm_` and the
+multi-tensor AdamW each make several passes over 3 GB of parameters, gradients and moments, and the bf16 GEMM operands are
+re-cast afterwards.  `FusedAdamW` keeps the loop's shape --
+
+    optimizer = FusedAdamW(optimizer_grouped_parameters, lr=..., betas=..., eps=...)          # instead of torch.optim.AdamW
+    ...
+    loss.backward()
+    grad_norm = optimizer.clip_grad_norm_(max_grad_norm)      # instead of accelerator.clip_grad_norm_(params, max_grad_norm)
+    optimizer.step(); lr_scheduler.step(); optimizer.zero_grad()
+
+-- and runs ONE read of the gradients for the norm (`dw_sumsq_f32`) and ONE pass per parameter group segment
+(`dw_adamw_dev`: clip coefficient from the device-resident norm, AdamW, bf16 shadow refresh) over the model's flat
+parameter / moment buffers.  Same arithmetic as `DistillationTrainer.optimizer_step` (same kernels); `torch.optim.AdamW`
+semantics: decoupled weight decay, bias corrections in double, a parameter without a gradient is not touched, `lr` is read
+from the group every step (LR schedulers work unchanged), `state_dict()` / `load_state_dict()` round-trip the moments.
+"""
+import torch
+
+__all__ = ["FusedAdamW"]
+
+
+def _unwrap(model):
+    while hasattr(model, "module") and not hasattr(model, "store"):
+        model = model.module
+    return model
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, *, model, max_grad_norm=None):
+        """`params`: parameters or parameter-group dicts of ONE `distil_whisper_amd.WhisperForConditionalGeneration`
+        (`model`, possibly DDP-wrapped), as `torch.optim.AdamW` takes them.  `max_grad_norm`: clip inside `step()` without a
+        separate `clip_grad_norm_` call (the norm is still available as `last_grad_norm`)."""
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
+            raise ValueError("FusedAdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.model = _unwrap(model)
+        st = self.model.store
+        if st.G is None:
+            raise ValueError("FusedAdamW: the model has no trainable parameters (dtype=bfloat16 models are inference-only)")
+        self.ops, self.st = self.model.ops, st
+        by_id = {id(p): n for n, p in zip(self.model._param_names, self.model._param_list)}
+        self._ranges = {}                       # id(param) -> (offset, padded end, name)
+        for group in self.param_groups:
+            for p in group["params"]:
+                name = by_id.get(id(p))
+                if name is None:
+                    raise ValueError("FusedAdamW: every parameter must belong to `model` (a distil_whisper_amd module)")
+                off, shape, _ = st.entries[name]
+                if off < st.train_start:
+                    raise ValueError(f"FusedAdamW: {name} lies in the model's frozen region")
+                n = 1
+                for d in shape:
+                    n *= d
+                self._ranges[id(p)] = (off, off + ((n + 63) // 64) * 64, name)
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            group["_adam"] = self.ops.adam_state(group["lr"], b1, b2, 0)      # device-resident [lr, step, beta1, beta2, ...]
+            group["_lr_dev"] = group["lr"]
+        self._sumsq = self.ops.zeros((1,), torch.float32)
+        self._segments = None
+        self._seg_key = None
+        self._gathered = False
+        self._max_norm = float(max_grad_norm) if max_grad_norm else 0.0
+        self._clip_once = None
+        self.last_grad_norm = None
+
+    # -- flat gradient -----------------------------------------------------------------------------------------------
+    def _plan(self):
+        """Contiguous [start, end) segments per group over the parameters that HAVE a gradient (torch.optim.AdamW skips the
+        others entirely: no decay, no moment update)."""
+        key = tuple(id(p) for g in self.param_groups for p in g["params"] if p.grad is not None)
+        if key == self._seg_key:
+            return
+        plan = []
+        for gi, group in enumerate(self.param_groups):
+            rs = sorted(self._ranges[id(p)][:2] for p in group["params"] if p.grad is not None)
+            segs = []
+            for a, b in rs:
+                if segs and segs[-1][1] == a:
+                    segs[-1][1] = b
+                else:
+                    segs.append([a, b])
+            plan.append(segs)
+        self._segments, self._seg_key = plan, key
+
+    def _gather(self):
+        """p.grad (separate tensors: autograd clones, DDP bucket views, accumulated micro-batches) -> the flat buffer the
+        kernels read; one multi-tensor copy."""
+        if self._gathered:
+            return
+        self._plan()
+        dst, src = [], []
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is not None:
+                    a, _, name = self._ranges[id(p)]
+                    dst.append(self.st.G[a:a + p.numel()].view(p.shape))
+                    src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self._sumsq.zero_()
+        for segs in self._segments:
+            for a, b in segs:
+                self.ops.sumsq(self.st.G[a:b], self._sumsq)
+        self.last_grad_norm = torch.sqrt(self._sumsq[0])
+        self._gathered = True
+
+    @torch.no_grad()
+    def clip_grad_norm_(self, max_norm, norm_type=2.0):
+        """`torch.nn.utils.clip_grad_norm_` / `accelerator.clip_grad_norm_` for this optimizer's parameters: returns the total
+        gradient norm (device scalar, no host sync); the scaling by min(1, max_norm / (norm + 1e-6)) happens inside the next
+        `step()` (fused into the update: `p.grad` itself is left as it is)."""
+        if float(norm_type) != 2.0:
+            raise NotImplementedError("FusedAdamW.clip_grad_norm_: the fused kernels compute the 2-norm")
+        self._gather()
+        self._clip_once = float(max_norm)
+        return self.last_grad_norm
+
+    # -- step --------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._gather()
+        max_norm = self._clip_once if self._clip_once is not None else self._max_norm
+        st, ops = self.st, self.ops
+        for group, segs in zip(self.param_groups, self._segments):
+            if not segs:
+                continue
+            if group["lr"] != group["_lr_dev"]:              # an LR scheduler moved it
+                group["_adam"][0:1].fill_(group["lr"])
+                group["_lr_dev"] = group["lr"]
+            ops.adam_tick(group["_adam"], None)
+            for a, b in segs:
+                ops.adamw_dev(st.P[a:b], st.G[a:b], st.M[a:b], st.V[a:b], st.S[a:b], self._sumsq, max_norm, 1.0, group["_adam"],
+                              group["eps"], group["weight_decay"])
+        if any(self._ranges[id(p)][2].startswith("model.encoder.conv") for g in self.param_groups for p in g["params"]
+               if p.grad is not None):
+            st.repack_conv()                                  # conv weights are consumed in a packed GEMM layout
+        self._clip_once = None
+        self._gathered = False
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        self._gathered = False
+        super().zero_grad(set_to_none=set_to_none)
+
+    # -- checkpointing (accelerator.save_state / load_state) -------------------------------------------------------------
+    def state_dict(self):
+        st = self.st
+        lo, hi = st.train_start, st.train_end
+        groups = [{k: v for k, v in g.items() if k not in ("params", "_adam", "_lr_dev")} for g in self.param_groups]
+        for g, src in zip(groups, self.param_groups):
+            g["params"] = [self._ranges[id(p)][2] for p in src["params"]]
+            g["step"] = float(src["_adam"][1].item())
+        return {"state": {"exp_avg": st.M[lo:hi].clone(), "exp_avg_sq": st.V[lo:hi].clone(), "range": (lo, hi)},
+                "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        st = self.st
+        lo, hi = state_dict["state"]["range"]
+        if (lo, hi) != (st.train_start, st.train_end) or len(state_dict["param_groups"]) != len(self.param_groups):
+            raise ValueError("FusedAdamW.load_state_dict: the checkpoint is for another parameter layout")
+        st.M[lo:hi].copy_(state_dict["state"]["exp_avg"])
+        st.V[lo:hi].copy_(state_dict["state"]["exp_avg_sq"])
+        for g, saved in zip(self.param_groups, state_dict["param_groups"]):
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                g[k] = saved[k]
+            b1, b2 = g["betas"]
+            g["_adam"] = self.ops.adam_state(g["lr"], b1, b2, saved.get("step", 0.0))
+            g["_lr_dev"] = g["lr"]

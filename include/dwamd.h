@@ -283,8 +283,8 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *   key 2   persistent workgroups on/off;   key 9  persistent grid size in CUs (multiple of 8, default 256)
  *   key 10  dynamic per-XCD tile hand-out (default 1);   key 11  profiling: bit 4 (16) makes the software-pipelined
  *           kernels skip their epilogue (nothing is stored; tools/gemm_overhead.py); other bits unused (default 1)
- *   key 3   attention backward variant (bit 0 dQ, bit 1 dK/dV fast tile staging, bit 2 dK/dV at 3 waves per SIMD;
- *           default 5);   key 4  single-query attention kernel (bit 0 on [default], bit 1 all-loads-up-front variant)
+ *   key 3   attention backward variant (bit 0 dQ, bit 1 dK/dV fast tile staging, bit 2 dK/dV at 3 waves per SIMD -- bits 1
+ *           and 2 apply to the NON-causal dK/dV kernel only: the causal launch always runs two waves per SIMD; default 5);   key 4  single-query attention kernel (bit 0 on [default], bit 1 all-loads-up-front variant)
  *   key 5   log-mel DFT on the matrix cores (default 1);   key 7  decode-step fusions off (bit 0 LayerNorm-on-load,
  *           bit 1 K/V append);   key 8  wide LM-head GEMV (default 1)
  *   key 19  row-major 256-row GEMMs run main-loop ablation `value` (1 no fragment reads, 2 no operand DMA, 3 both, 4 DMA that

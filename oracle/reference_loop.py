@@ -25,8 +25,9 @@ def get_parameter_names(model, forbidden_layer_types, forbidden_module=None):
     return result
 
 
-def make_optimizer(student_model, learning_rate=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8):
-    """run_distillation.py:1377-1407."""
+def make_optimizer(student_model, learning_rate=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, optimizer_cls=None):
+    """run_distillation.py:1377-1407.  `optimizer_cls(groups, lr=, betas=, eps=)` replaces torch.optim.AdamW (the drop-in
+    distil_whisper_amd.optim.FusedAdamW bound to its model); the parameter groups are the reference's either way."""
     decay_parameters = get_parameter_names(student_model, [nn.LayerNorm])
     decay_parameters = [name for name in decay_parameters if "bias" not in name]
     optimizer_grouped_parameters = [
@@ -35,6 +36,8 @@ def make_optimizer(student_model, learning_rate=1e-4, weight_decay=0.0, betas=(0
         {"params": [p for n, p in student_model.named_parameters() if n not in decay_parameters and p.requires_grad],
          "weight_decay": 0.0},
     ]
+    if optimizer_cls is not None:
+        return optimizer_cls(optimizer_grouped_parameters, lr=learning_rate, betas=betas, eps=eps)
     return torch.optim.AdamW(params=optimizer_grouped_parameters, lr=learning_rate, betas=betas, eps=eps)
 
 
@@ -52,8 +55,8 @@ def kl_divergence(target_distribution, log_predicted_distribution, labels):
 class ReferenceLoop:
     def __init__(self, student_model, teacher_model, BaseModelOutput, *, share_hidden_states=False,
                  teacher_dtype=torch.float32, kl_weight=1.0, max_grad_norm=1.0, learning_rate=1e-4, weight_decay=0.0,
-                 lr_lambda=None, wrap=None, fused_loss=None, autocast=None):
-        self.optimizer = make_optimizer(student_model, learning_rate, weight_decay)   # (built before `prepare`, as in the script)
+                 lr_lambda=None, wrap=None, fused_loss=None, autocast=None, optimizer_cls=None):
+        self.optimizer = make_optimizer(student_model, learning_rate, weight_decay, optimizer_cls=optimizer_cls)   # (built before `prepare`, as in the script)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda or (lambda step: 1.0))
         self.student_model = wrap(student_model) if wrap is not None else student_model
         self.teacher_model = teacher_model
@@ -121,7 +124,10 @@ class ReferenceLoop:
         """run_distillation.py:1606-1614.  Returns (metrics, gradient norm before clipping)."""
         loss, train_metric = self.train_step(batch, temperature=temperature)
         loss.backward()                                                             # accelerator.backward(loss)
-        grad_norm = torch.nn.utils.clip_grad_norm_(self.student_model.parameters(), self.max_grad_norm)
+        if hasattr(self.optimizer, "clip_grad_norm_"):          # the drop-in optimizer's own (fused) form of line 1611
+            grad_norm = self.optimizer.clip_grad_norm_(self.max_grad_norm)
+        else:
+            grad_norm = torch.nn.utils.clip_grad_norm_(self.student_model.parameters(), self.max_grad_norm)
         self.optimizer.step()
         self.lr_scheduler.step()
         self.optimizer.zero_grad()

@@ -190,3 +190,46 @@ def test_generated_ids_are_gathered_in_rank_order(tmp_path):
     assert r0["texts"] == texts and r1["texts"] == texts
     part = lf([audios[2], audios[3], audios[4]])
     assert r0["partial"] == part[:2] + [None] and r1["partial"] == [None, None] + part[2:]
+
+
+def test_bucket_watchdog_names_the_bucket_that_never_completes():
+    """distill.BucketWatchdog: buckets that complete are silent; the first one still pending after the deadline produces one
+    message naming step, bucket and element range (bench.py ends the rank with it instead of hanging in the next barrier)."""
+    import time
+    from distil_whisper_amd.distill import BucketWatchdog
+    fired = []
+    wd = BucketWatchdog(0.3, rank=3, on_timeout=fired.append, poll_s=0.01)
+    wd.start()
+    t0 = time.monotonic()
+    wd.submit("step 7 bucket 0: elements [100, 200) of the flat gradient (1 MiB)", lambda: True)
+    wd.submit("step 7 bucket 1: elements [0, 100) of the flat gradient (1 MiB)", lambda: time.monotonic() - t0 > 0.1)   # slow, fine
+    wd.submit("step 8 bucket 0: elements [100, 200) of the flat gradient (1 MiB)", lambda: False)                          # wedged
+    deadline = time.monotonic() + 5.0
+    while not fired and time.monotonic() < deadline:
+        time.sleep(0.02)
+    wd.stop()
+    assert len(fired) == 1
+    assert "[rank 3]" in fired[0] and "step 8 bucket 0" in fired[0] and "[100, 200)" in fired[0]
+
+
+def test_grad_reducer_labels_its_buckets_and_counts_steps():
+    """The reducer labels every collective it issues (what the watchdog prints); world 1 with always_reduce exercises it."""
+    import torch.distributed as dist
+    from distil_whisper_amd.distill import GradReducer
+    import tempfile
+    f = tempfile.NamedTemporaryFile(delete=False)
+    dist.init_process_group("gloo", init_method=f"file://{f.name}", rank=0, world_size=1)
+    try:
+        flat = torch.ones(1000)
+        fired = []
+        r = GradReducer(flat, bucket_bytes=4 * 300, always_reduce=True, watchdog_s=5.0, on_timeout=fired.append)
+        r.ready(600, 1000)
+        r.ready(200, 600)
+        r.ready(0, 200)
+        assert len(r.labels) == 2 and "[600, 1000)" in r.labels[0] and "[200, 600)" in r.labels[1]
+        r.wait()
+        assert r.step == 1 and r.handles == [] and r.labels == [] and not fired
+        assert float(flat.sum()) == 1000.0
+        r.watchdog.stop()
+    finally:
+        dist.destroy_process_group()
