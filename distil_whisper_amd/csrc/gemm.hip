@@ -51,6 +51,7 @@ extern int g_attn_bwd_waves;
 extern int g_logmel_mfma;     // logmel.hip
 extern int g_decode_fuse_off; // decode.hip
 extern int g_skinny_wide;     // gemm_skinny.hip
+extern int g_ln_variant;      // norm.hip
 int g_gemm_persistent = 1;
 // Kernel selection for the 256x256 block tile (bit mask; dw_debug_set(0, v)):
 //   bits 0-1 (3): base = 16-wave tile kernel (gemm_kernel.h) for everything, 8-wave 128x128 tile for small grids;
@@ -120,6 +121,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 17) { g_attn_bwd_waves = value; return DW_OK; }
     if (key == 19) { g_gemm_dbg = value; return DW_OK; }
     if (key == 20) { g_gemm_mi16 = value; return DW_OK; }
+    if (key == 21) { g_ln_variant = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
     if (key == 16) { g_attn_fwd_waves = value; return DW_OK; }
     if (key == 15) { g_attn_ablate = value; return DW_OK; }

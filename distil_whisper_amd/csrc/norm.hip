@@ -73,6 +73,65 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float*
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// Persistent form of the fp32-input forward (the student's residual stream, 6 B per element): a resident grid walks the rows
+// and every wave requests its NEXT row before it reduces the current one -- one-row waves (5 KiB each) spend a third of their
+// life being launched and retired, and have nothing in flight while they reduce (dw_debug_set key 21 bit 0).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, const float* gamma, const float* beta, bf16* y,
+                                                             float* mean, float* rstd, int rows, int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = cols >> 2;
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    f32x4 v[NV], nx[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < nvec) v[j] = *(const f32x4*)(x + (long)row * cols + idx * 4);
+    }
+    for (; row < rows; row += stride) {
+        const int nrow = row + stride;
+        if (nrow < rows) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int idx = lane + 64 * j;
+                if (idx < nvec) nx[j] = *(const f32x4*)(x + (long)nrow * cols + idx * 4);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (lane + 64 * j < nvec) s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+        s = wave_sum(s);
+        const float mu = s / cols;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+            if (lane + 64 * j < nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q += d * d; }
+            }
+        q = wave_sum(q);
+        const float rs = rsqrtf(q / cols + eps);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+                const f32x4 g = *(const f32x4*)(gamma + idx * 4);
+                const f32x4 bt = *(const f32x4*)(beta + idx * 4);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf((v[j][e] - mu) * rs * g[e] + bt[e]);
+                ln_store<1>((bf16x4*)(y + (long)row * cols + idx * 4), o);
+            }
+        }
+        if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = nx[j];
+    }
+}
+
 // bf16 input (the teacher's residual stream) with 16-byte accesses: 8 elements per lane per vector.  With 8-byte loads the
 // row of a bf16 stream is half as many bytes per request as an fp32 row and the kernel ran at 3.0 TB/s against 4.5 for
 // fp32 input (tools/stream_kernels_bench.py).
@@ -222,6 +281,138 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const v
     }
 }
 
+// The same backward with the NEXT row's x / dy and the CURRENT row's residual gradient requested before the row reductions
+// (two dependent memory round trips per row otherwise: operands -> reductions -> old residual gradient -> stores).  Needs the
+// registers of two waves per SIMD (NW = 8, one workgroup per CU); dw_debug_set key 21 bit 1.
+template <bool XBF, int NV, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, const void* x, const float* mean,
+                                                         const float* rstd, const float* gamma, float* dres,
+                                                         int accumulate, float* dgamma, float* dbeta, bf16* dres_lowp,
+                                                         float* dres_colsum, int rows, int cols) {
+    __shared__ float red[3 * NW * 512];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nvec = cols >> 2;
+    f32x4 gm[NV], ag[NV], ab[NV], ac[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = lane + 64 * j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 0.f; ac[j][e] = 0.f; }
+        if (idx < nvec) gm[j] = *(const f32x4*)(gamma + idx * 4);
+    }
+    const int stride = gridDim.x * NW;
+    int row = blockIdx.x * NW + wave;
+    f32x4 xv[NV], dv[NV];
+    float mu = 0.f, rs = 0.f;
+    if (row < rows) {
+        mu = mean[row]; rs = rstd[row];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) { xv[j] = ld4<XBF>(x, (long)row * cols + idx * 4); dv[j] = ld4<true>(dy, (long)row * cols + idx * 4); }
+        }
+    }
+    for (; row < rows; row += stride) {
+        const int nrow = row + stride;
+        // requests first: the old residual gradient of this row, then the next row's operands
+        f32x4 old[NV], nxv[NV], ndv[NV];
+        float nmu = 0.f, nrs = 0.f;
+        if (accumulate) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int idx = lane + 64 * j;
+                if (idx < nvec) old[j] = *(const f32x4*)(dres + (long)row * cols + idx * 4);
+            }
+        }
+        if (nrow < rows) {
+            nmu = mean[nrow]; nrs = rstd[nrow];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int idx = lane + 64 * j;
+                if (idx < nvec) { nxv[j] = ld4<XBF>(x, (long)nrow * cols + idx * 4); ndv[j] = ld4<true>(dy, (long)nrow * cols + idx * 4); }
+            }
+        }
+        f32x4 xh[NV], g[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[j][e] = (xv[j][e] - mu) * rs;
+                    g[j][e] = dv[j][e] * gm[j][e];
+                    c1 += g[j][e];
+                    c2 += g[j][e] * xh[j][e];
+                    ag[j][e] += dv[j][e] * xh[j][e];
+                    ab[j][e] += dv[j][e];
+                }
+            }
+        }
+        c1 = wave_sum(c1) / cols;
+        c2 = wave_sum(c2) / cols;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < nvec) {
+                float* dst = dres + (long)row * cols + idx * 4;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
+                if (accumulate) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += old[j][e];
+                }
+                ln_store<2>((f32x4*)dst, o);
+                if (dres_lowp) {
+                    bf16x4 lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { lo[e] = f2bf(o[e]); ac[j][e] += bf2f(lo[e]); }
+                    ln_store<3>((bf16x4*)(dres_lowp + (long)row * cols + idx * 4), lo);
+                }
+            }
+        }
+        mu = nmu; rs = nrs;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { xv[j] = nxv[j]; dv[j] = ndv[j]; }
+    }
+    float* r0 = red;
+    float* r1 = red + NW * 512;
+    float* r2 = red + 2 * NW * 512;
+    for (int base = 0; base < cols; base += 512) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int idx = lane + 64 * j;
+            const int col = idx * 4;
+            if (idx < nvec && col >= base && col < base + 512) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r0[wave * 512 + (col - base) + e] = ag[j][e];
+                    r1[wave * 512 + (col - base) + e] = ab[j][e];
+                    r2[wave * 512 + (col - base) + e] = ac[j][e];
+                }
+            }
+        }
+        __syncthreads();
+        for (int cidx = threadIdx.x; cidx < 512 && base + cidx < cols; cidx += NW * 64) {
+            float sg = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { sg += r0[w * 512 + cidx]; sb += r1[w * 512 + cidx]; sc += r2[w * 512 + cidx]; }
+            atomicAdd(dgamma + base + cidx, sg);
+            atomicAdd(dbeta + base + cidx, sb);
+            if (dres_colsum) atomicAdd(dres_colsum + base + cidx, sc);
+        }
+        __syncthreads();
+    }
+}
+
+// dw_debug_set key 21: bit 0 persistent forward with next-row prefetch (fp32 input, <= 1280 columns: 84.9 -> 72.0 us at
+// [48000 x 1280], 4.3 -> 5.1 TB/s; bits 8-11: workgroups per CU, default 5), bit 1 backward with prefetch (1025-1280 columns:
+// 225 -> 179 us, 4.4 -> 5.5 TB/s of its 16 B per element).  tools/ln_ab.py.  The same treatment of the bf16-input forward
+// (the teacher's stream, cache resident) measured neutral (52.7 vs 51.7 us) and is not built.
+int g_ln_variant = 3;
+
 extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
                                 float* mean, float* rstd, int rows, int cols, float eps, void* stream) {
     DW_CLEAR_ERR();
@@ -240,6 +431,13 @@ extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
         return DW_OK;
     }
     const int nv = ((cols >> 2) + 63) / 64;
+    if ((g_ln_variant & 1) && x_dtype != DW_BF16 && nv <= 5 && rows >= 8192) {
+        // resident grid: 5 workgroups of 4 waves per CU (v + next row + parameters: ~100 registers)
+        dim3 pg(256 * ((g_ln_variant >> 8) & 15 ? (g_ln_variant >> 8) & 15 : 5));
+        hipLaunchKernelGGL((ln_fwd_persist_kernel<5>), pg, block, 0, s, (const float*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps);
+        DW_CHECK_LAUNCH();
+        return DW_OK;
+    }
 #define LN_FWD(NVV)                                                                                                   \
     do {                                                                                                              \
         if (x_dtype == DW_BF16)                                                                                       \
@@ -284,6 +482,18 @@ extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, cons
                                mean, rstd, gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum,     \
                                rows, cols);                                                                           \
     } while (0)
+    if ((g_ln_variant & 2) && nv == 5) {
+        int nb = (rows + 7) / 8;
+        if (nb > 256) nb = 256;
+        if (x_dtype == DW_BF16)
+            hipLaunchKernelGGL((ln_bwd_pf_kernel<true, 5, 8>), dim3(nb), dim3(512), 0, s, (const bf16*)dy, x, mean, rstd, gamma, dres,
+                               accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols);
+        else
+            hipLaunchKernelGGL((ln_bwd_pf_kernel<false, 5, 8>), dim3(nb), dim3(512), 0, s, (const bf16*)dy, x, mean, rstd, gamma, dres,
+                               accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols);
+        DW_CHECK_LAUNCH();
+        return DW_OK;
+    }
     if (nv <= 2) LN_BWD(2, 4); else if (nv <= 3) LN_BWD(3, 4); else if (nv <= 5) LN_BWD(5, 12); else LN_BWD(8, 4);
 #undef LN_BWD
     DW_CHECK_LAUNCH();

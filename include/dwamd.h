@@ -291,7 +291,9 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *           always hits L2; WRONG results by construction; tools/gemm_dma_diag.py);   key 20  bit mask: software-pipelined GEMM
  *           kernels on v_mfma_f32_16x16x32_bf16 (1 row-major, 2 k-major B, 4 both k-major, 32 row-major with K <= 2560 and
  *           N >= 3840 on the 256-row tile; default 36; bit-identical results;
- *           8 / 16: the four-wave 128 x 128-per-wave experiment for row-major / k-major B, gemm_wp16_w4.hip) */
+ *           8 / 16: the four-wave 128 x 128-per-wave experiment for row-major / k-major B, gemm_wp16_w4.hip)
+ *   key 21  LayerNorm kernels: bit 0 persistent fp32-input forward with next-row prefetch (bits 8-11: workgroups per CU),
+ *           bit 1 backward with next-row / residual-gradient prefetch at two waves per SIMD (default 3; tools/ln_ab.py) */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus
