@@ -352,6 +352,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
     // (interior tiles only).  A bias read from global memory here is an ordinary load whose vmcnt wait also drains every
     // operand DMA the caller has in flight for the NEXT tile (the counter retires in order).
     static_assert(!SWZ || TN == 64, "swizzled patch: 16 slots of 16 bytes per row");
+#ifndef DW_EPI_LAUNDER
+#define DW_EPI_LAUNDER 1
+#endif
+    // Every lane-dependent value of the walks below (patch addresses under their swizzle, lane offsets of C / z / residual)
+    // is a function of `lane` alone, i.e. invariant over the persistent workgroup's tile loop: hoisted in front of it they are
+    // live across the K loop, where every register is taken, and get SPILLED -- and a scratch reload inside a walk is a VMEM
+    // load whose vmcnt(0) wait also waits for the acknowledgement of the global store issued just before it (the fp32-residual
+    // walk of the 320-row kernel did that once per row group: 100 B of scratch, 163 scratch instructions).  An opaque
+    // redefinition of `lane` per tile keeps the few instructions that derive them inside the epilogue.
+    if constexpr (DW_EPI_LAUNDER != 0) asm volatile("" : "+v"(lane));
     // tile and wave coordinates are the same in every lane: say so (the job index comes out of an LDS slot, which the
     // compiler must otherwise treat as a per-lane value, and every row address would be 64-bit vector arithmetic)
     const int m0 = __builtin_amdgcn_readfirstlane(m0_), wm0 = __builtin_amdgcn_readfirstlane(wm0_);
@@ -412,10 +422,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
         }
     }
     auto to_patch = [&](auto ic) __attribute__((always_inline)) {
+        // (the FN * 4 write addresses are re-derived per slab from an opaque copy of the lane index: held across the slabs, two
+        // of them were spilled and reloaded behind a vmcnt(0) that waited for the previous slab's stores)
+        int l2 = lane;
+        if constexpr (DW_EPI_LAUNDER != 0) asm volatile("" : "+v"(l2));
+        const int lrow2 = LAY == 32 ? (l2 & 31) : (l2 & 15), lcol2 = LAY == 32 ? (l2 >> 5) * 4 : (l2 >> 4) * 4;
         static_for<0, FN * 4>([&](auto qc) __attribute__((always_inline)) {
             constexpr int q = decltype(qc)::value;
             const f32x4 v4 = quad(ic, qc);
-            const int row = lrow + qrow(q), col = lcol + qcol(q);
+            const int row = lrow2 + qrow(q), col = lcol2 + qcol(q);
             if constexpr (SWZ) *(f32x4*)(patch + row * PLD + (((col >> 2) ^ (row & 15)) << 2)) = v4;
             else *(f32x4*)(patch + row * PLD + col) = v4;
         });

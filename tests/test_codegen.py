@@ -21,7 +21,16 @@ def _lint():
     return m
 
 
+_ASM_CACHE = {}
+
+
 def _asm(lint, tu):
+    if tu not in _ASM_CACHE:
+        _ASM_CACHE[tu] = _compile(lint, tu)
+    return _ASM_CACHE[tu]
+
+
+def _compile(lint, tu):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         r = subprocess.run([HIPCC] + lint.FLAGS + [os.path.join(lint.CSRC, tu + ".hip"), "-o", out], capture_output=True, text=True, cwd=lint.CSRC)
@@ -48,3 +57,38 @@ def test_hot_loops_have_no_flat_accesses_and_no_scratch_traffic(tu, loops_at_lea
             assert c["scratch"] == 0, (name, a, b, "scratch traffic inside an MFMA loop")
             assert c["flat"] == 0, (name, a, b)
     assert seen >= loops_at_least, seen
+
+
+# Whole-kernel scratch budgets of the kernels the default dispatch launches (round-4 review: the 320-row kernels sat on a register
+# cliff -- 100 B of scratch, 163 scratch instructions, one reload behind a vmcnt(0) per row group of the fp32-residual walk; a
+# compiler bump could cost 8 % of the step unnoticed).  Since round 5 the epilogue re-derives its lane addresses per tile
+# (gemm_common.h DW_EPI_LAUNDER) and the budgets are: nothing for the 256-row kernels and the attention kernels, 16 B / 6
+# instructions (the run-time-flavour walk's end and the kernel exit) for the 320-row kernels.
+SCRATCH_BUDGET = [
+    ("attention", r"attn_(fwd_kernel<(true|false), 4, 0>|bwd_dq_kernel<(true|false), (true|false), 4>|bwd_dkv_kernel<true, false, 2, 4>)", 0, 0),
+    ("attention", r"attn_bwd_dkv_kernel<false, false, 3, 4>", 8, 2),     # (three waves per SIMD: one value at kernel entry / exit)
+    ("gemm_wp8_nn", r"gemm_wp_kernel<false, false, 2, 4, true, 0, 256>", 0, 0),
+    ("gemm_wp8_nt", r"gemm_wp_kernel<false, true, 2, 4, true, 0, 256>", 0, 0),
+    ("gemm_wp8_m320", r"gemm_wp_kernel<false, (true|false), 2, 4, true, 0, 320>", 16, 6),
+    ("gemm_wp16_tt", r"gemm_wp16_kernel<true, true, 256, 0, 4>", 0, 0),
+    ("gemm_wp16_nn", r"gemm_wp16_kernel<false, false, 256, 0, 4>", 0, 0),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="needs the ROCm compiler")
+@pytest.mark.parametrize("tu,pattern,max_bytes,max_ops", SCRATCH_BUDGET)
+def test_default_kernels_stay_within_their_scratch_budget(tu, pattern, max_bytes, max_ops):
+    import re
+    lint = _lint()
+    asm = _asm(lint, tu)
+    names = subprocess.run(["c++filt"], input="\n".join(n for n, _ in lint.kernels(asm)), capture_output=True, text=True).stdout.split("\n")
+    hit = 0
+    for (name, body), pretty in zip(lint.kernels(asm), names):
+        if not re.search(pattern, pretty):
+            continue
+        hit += 1
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", asm[asm.index(".amdhsa_kernel " + name):])
+        scratch_bytes = int(m.group(1))
+        ops = sum(1 for l in body if l.strip().startswith("scratch_"))
+        assert scratch_bytes <= max_bytes and ops <= max_ops, (pretty, scratch_bytes, ops)
+    assert hit >= 1, f"no kernel of {tu} matches {pattern}"
