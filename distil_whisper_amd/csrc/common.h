@@ -66,15 +66,48 @@ __device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
     cdf[1] = x[1] >= 0.f ? 1.0f - half_tail[1] : half_tail[1];
     pdf = e * 0.39894228040143268f;
 }
+// The same approximation arranged for the epilogues (round 5: 32 -> 26 vector instructions per pair in the fc1 walks): with
+// s = 1 - tail = erf(|x| / sqrt2),  gelu(x) = x * cdf(x) = (x + |x| * s) / 2 for either sign of x -- no compare / select pair per
+// element and no separate multiply by x; cdf itself (gelu' = cdf + x * pdf, the student's stored by-product) is
+// 1/2 + copysign(s, x) / 2: one bit-field insert per element.
+__device__ __forceinline__ void gelu_y_s_pdf2(f32x2 x, f32x2& y, f32x2& s, f32x2& pdf) {
+    f32x2 ax; ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+    const f32x2 u = ax * 0.70710678118654752f;
+    f32x2 den = u * 0.3275911f + 1.0f;
+    f32x2 t; t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
+    const f32x2 xx = x * x * -0.72134752044448170f;
+    f32x2 e; e[0] = __builtin_amdgcn_exp2f(xx[0]); e[1] = __builtin_amdgcn_exp2f(xx[1]);
+    f32x2 yy = t * 1.061405429f + (-1.453152027f);
+    yy = yy * t + 1.421413741f;
+    yy = yy * t + (-0.284496736f);
+    yy = yy * t + 0.254829592f;
+    const f32x2 tail = yy * t * e;
+    s = 1.0f - tail;
+    y = (ax * s + x) * 0.5f;
+    pdf = e * 0.39894228040143268f;
+}
+__device__ __forceinline__ f32x2 gelu_cdf_from_s2(f32x2 x, f32x2 s) {
+    f32x2 c;
+    c[0] = __builtin_copysignf(s[0], x[0]); c[1] = __builtin_copysignf(s[1], x[1]);
+    return c * 0.5f + 0.5f;
+}
+// two fp32 values rounded to bf16 and widened again, through ONE packed conversion (the scalar form is a conversion and a
+// shift per value)
+__device__ __forceinline__ f32x2 round_bf16_pair(f32x2 v) {
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    const unsigned u = __builtin_bit_cast(unsigned, r);
+    f32x2 o; o[0] = __uint_as_float(u << 16); o[1] = __uint_as_float(u & 0xffff0000u);
+    return o;
+}
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
-    f32x2 cdf, pdf;
-    gelu_parts2(x, cdf, pdf);
-    return x * cdf;
+    f32x2 y, s, pdf;
+    gelu_y_s_pdf2(x, y, s, pdf);
+    return y;
 }
 __device__ __forceinline__ f32x2 gelu_grad_fast2(f32x2 x) {
-    f32x2 cdf, pdf;
-    gelu_parts2(x, cdf, pdf);
-    return cdf + x * pdf;
+    f32x2 y, s, pdf;
+    gelu_y_s_pdf2(x, y, s, pdf);
+    return gelu_cdf_from_s2(x, s) + x * pdf;
 }
 __device__ __forceinline__ float gelu_fast(float x) { f32x2 v; v[0] = x; v[1] = x; return gelu_fast2(v)[0]; }
 __device__ __forceinline__ float gelu_grad_fast(float x) { f32x2 v; v[0] = x; v[1] = x; return gelu_grad_fast2(v)[0]; }

@@ -243,12 +243,13 @@ __device__ __forceinline__ void gemm_epi_vec4(const GemmP& p, float (&v)[4], con
             f16x4 g4;
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-                f32x2 x2; x2[0] = round_bf16(v[e]); x2[1] = round_bf16(v[e + 1]);
-                f32x2 cdf, pdf;
-                gelu_parts2(x2, cdf, pdf);                  // one exp + one rcp per element serve gelu AND gelu'
-                v[e] = x2[0] * cdf[0]; v[e + 1] = x2[1] * cdf[1];
+                f32x2 vin; vin[0] = v[e]; vin[1] = v[e + 1];
+                const f32x2 x2 = round_bf16_pair(vin);
+                f32x2 y2, s2, pdf;
+                gelu_y_s_pdf2(x2, y2, s2, pdf);             // one exp + one rcp per element serve gelu AND gelu'
+                v[e] = y2[0]; v[e + 1] = y2[1];
                 if (store_g) {
-                    const f32x2 g2 = cdf + x2 * pdf;
+                    const f32x2 g2 = gelu_cdf_from_s2(x2, s2) + x2 * pdf;
                     g4[e] = (_Float16)g2[0]; g4[e + 1] = (_Float16)g2[1];
                 }
             }
@@ -603,12 +604,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
                     if constexpr ((F & EPI_GELU) != 0) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            f32x2 x2; x2[0] = round_bf16(p[h][0]); x2[1] = round_bf16(p[h][1]);
-                            f32x2 cdf, pdf;
-                            gelu_parts2(x2, cdf, pdf);
-                            p[h] = x2 * cdf;
+                            const f32x2 x2 = round_bf16_pair(p[h]);
+                            f32x2 s2, pdf;
+                            gelu_y_s_pdf2(x2, p[h], s2, pdf);
                             if constexpr (HAS_G) {
-                                const f32x2 g2 = cdf + x2 * pdf;
+                                const f32x2 g2 = gelu_cdf_from_s2(x2, s2) + x2 * pdf;
                                 gq[q][2 * h] = (_Float16)g2[0]; gq[q][2 * h + 1] = (_Float16)g2[1];
                             }
                         }
