@@ -17,6 +17,7 @@
 #include "../../include/dwamd.h"
 
 #define NEG_BIG (-1.0e30f)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct AttnP {
     const bf16* q; const bf16* k; const bf16* v; bf16* o; float* lse;
@@ -59,6 +60,41 @@ __device__ __forceinline__ void store_t(bf16* base, long ld, long row, bool ok, 
         *(bf16x4*)(base + row * ld + cb * 32 + g * 8 + hi * 4) = w;
 #endif
     }
+}
+
+// The same store through a wave-private LDS patch (32 rows x 144 B): the lanes hold a ROW each (8-byte pieces of it per
+// register group), so a direct store instruction touches 64 different 128-byte lines for 8 bytes each; turned row-major in
+// LDS, a store instruction writes 8 complete 128-byte rows (16 bytes per lane).  Without any output store the kernels run
+// 5 % (encoder shape) to 13 % (cross-attention backward) faster -- the row-per-lane stores were most of that (section 14).
+// `patch`: this wave's 4608 bytes; the caller has made sure that no wave still reads the operand tiles it overlays.
+#ifndef DW_ATTN_ROWSTORE
+#define DW_ATTN_ROWSTORE 1
+#endif
+__device__ __forceinline__ void store_rows(bf16* base, long ld, int row0, int nrows, char* patch, int lane,
+                                           const f32x16& a0, const f32x16& a1, float mul) {
+    const int hi = lane >> 5, ln = lane & 31;
+    char* const wr = patch + ln * 144 + hi * 8;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const f32x16& a = cb == 0 ? a0 : a1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = f2bf(a[g * 4 + e] * mul);
+            *(bf16x4*)(wr + cb * 64 + g * 16) = w;
+        }
+    }
+    // (wave-private: the compiler's lgkmcnt wait orders the writes before the reads)
+    const int rr = lane >> 3, sc = lane & 7;
+    u32x4 o[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) o[it] = *(const u32x4*)(patch + (it * 8 + rr) * 144 + sc * 16);
+    const unsigned loff = (unsigned)(rr * (int)ld + sc * 8) * 2u;
+    char* const rb = (char*)(base + (long)row0 * ld);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        if (row0 + it * 8 + rr < nrows) *(u32x4*)(rb + (long)it * 8 * ld * 2 + loff) = o[it];
 }
 
 // Column sums of a transposed 32x32 accumulator block as it is stored (bf16-rounded, rows that are not `ok` excluded),
@@ -218,8 +254,13 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
     }
     const float inv = 1.0f / l_run;
     bf16* O = p.o + (long)b * p.q_rows * p.ldo + h * 64;
-    store_t(O, p.ldo, q, q_ok, 0, hi, o[0], inv);
-    store_t(O, p.ldo, q, q_ok, 1, hi, o[1], inv);
+    if (DW_ATTN_ROWSTORE && NW <= 7 && (p.ldo & 7) == 0 && ((uintptr_t)p.o & 15) == 0) {
+        __syncthreads();                              // every wave is done with the last K/V tile: the patches overlay the tiles
+        store_rows(O, p.ldo, qb0 + wave * 32, p.Lq, smem + wave * 4608, lane, o[0], o[1], inv);
+    } else {
+        store_t(O, p.ldo, q, q_ok, 0, hi, o[0], inv);
+        store_t(O, p.ldo, q, q_ok, 1, hi, o[1], inv);
+    }
     if (p.lse && q_ok && hi == 0) p.lse[((long)b * p.H + h) * p.Lq + q] = m_run * p.scale + __logf(l_run);
 }
 
@@ -492,8 +533,13 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) 
         }
     }
     bf16* DQ = p.dq + (long)b * p.Lq * p.lddq + h * 64;
-    store_t(DQ, p.lddq, q, q_ok, 0, hi, acc[0], p.scale);
-    store_t(DQ, p.lddq, q, q_ok, 1, hi, acc[1], p.scale);
+    if (DW_ATTN_ROWSTORE && NW <= 7 && (p.lddq & 7) == 0 && ((uintptr_t)p.dq & 15) == 0) {
+        __syncthreads();
+        store_rows(DQ, p.lddq, qb0 + wave * 32, p.Lq, smem + wave * 4608, lane, acc[0], acc[1], p.scale);
+    } else {
+        store_t(DQ, p.lddq, q, q_ok, 0, hi, acc[0], p.scale);
+        store_t(DQ, p.lddq, q, q_ok, 1, hi, acc[1], p.scale);
+    }
     if (p.dq_colsum) {
         colsum_t(p.dq_colsum + ((long)b * p.H + h) * 64, q_ok, 0, hi, ln, acc[0], p.scale);
         colsum_t(p.dq_colsum + ((long)b * p.H + h) * 64, q_ok, 1, hi, ln, acc[1], p.scale);
@@ -619,10 +665,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
     }
     bf16* DK = p.dk + (long)b * p.Lk * p.lddk + h * 64;
     bf16* DV = p.dv + (long)b * p.Lk * p.lddv + h * 64;
-    store_t(DK, p.lddk, key, k_ok, 0, hi, ak[0], p.scale);
-    store_t(DK, p.lddk, key, k_ok, 1, hi, ak[1], p.scale);
-    store_t(DV, p.lddv, key, k_ok, 0, hi, av[0], 1.0f);
-    store_t(DV, p.lddv, key, k_ok, 1, hi, av[1], 1.0f);
+    if (DW_ATTN_ROWSTORE && NW <= 7 && ((p.lddk | p.lddv) & 7) == 0 && (((uintptr_t)p.dk | (uintptr_t)p.dv) & 15) == 0) {
+        __syncthreads();
+        store_rows(DK, p.lddk, kb0 + wave * 32, p.Lk, smem + wave * 4608, lane, ak[0], ak[1], p.scale);
+        store_rows(DV, p.lddv, kb0 + wave * 32, p.Lk, smem + wave * 4608, lane, av[0], av[1], 1.0f);
+    } else {
+        store_t(DK, p.lddk, key, k_ok, 0, hi, ak[0], p.scale);
+        store_t(DK, p.lddk, key, k_ok, 1, hi, ak[1], p.scale);
+        store_t(DV, p.lddv, key, k_ok, 0, hi, av[0], 1.0f);
+        store_t(DV, p.lddv, key, k_ok, 1, hi, av[1], 1.0f);
+    }
     if (p.dv_colsum) {
         colsum_t(p.dv_colsum + ((long)b * p.H + h) * 64, k_ok, 0, hi, ln, av[0], 1.0f);
         colsum_t(p.dv_colsum + ((long)b * p.H + h) * 64, k_ok, 1, hi, ln, av[1], 1.0f);

@@ -508,11 +508,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
                 constexpr int i = decltype(ic)::value;
                 if (i == 1 && tslot) tslot[6] = (long long)__builtin_amdgcn_s_memrealtime();
                 to_patch(ic);
+#ifndef DW_EPI_READS_FIRST
+#define DW_EPI_READS_FIRST 1
+#endif
+#ifndef DW_EPI_RG5
+#define DW_EPI_RG5 2
+#endif
+                // (8-wave kernels: all row groups of the slab are read back from the patch first -- the slab's 32 accumulator
+                // registers have just died -- instead of one read -> lgkmcnt(0) -> arithmetic -> store round per row group with
+                // the LDS latency exposed every time)
+                constexpr bool RF = SWZ && DW_EPI_READS_FIRST != 0;
+                constexpr int RG = FM == 5 ? DW_EPI_RG5 : NIT;     // (the 320-row kernel has no 32 free registers: a part of a slab at a time)
+                f32x4 a4s[RF ? RG : 1];
                 static_for<0, NIT>([&](auto itc) __attribute__((always_inline)) {
                     constexpr int it = decltype(itc)::value;
+                    if constexpr (RF && it % RG == 0) {
+                        static_for<0, RG>([&](auto jc) __attribute__((always_inline)) {
+                            constexpr int j = decltype(jc)::value;
+                            const int rlj = (it + j) * RPI + pr;
+                            a4s[j] = *(const f32x4*)(patch + rlj * PLD + (((pc >> 2) ^ (rlj & 15)) << 2));
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     const int rl = it * RPI + pr;
                     constexpr long rg = i * 32 + it * RPI;
-                    const f32x4 a4 = *(const f32x4*)(patch + rl * PLD + (SWZ ? (((pc >> 2) ^ (rl & 15)) << 2) : pc));
+                    f32x4 a4;
+                    if constexpr (RF) a4 = a4s[it % RG];
+                    else a4 = *(const f32x4*)(patch + rl * PLD + (SWZ ? (((pc >> 2) ^ (rl & 15)) << 2) : pc));
                     bf16x4 zs;
                     f32x4 rs;
                     if constexpr (side) {

@@ -65,8 +65,9 @@ def test_hot_loops_have_no_flat_accesses_and_no_scratch_traffic(tu, loops_at_lea
 # (gemm_common.h DW_EPI_LAUNDER) and the budgets are: nothing for the 256-row kernels and the attention kernels, 16 B / 6
 # instructions (the run-time-flavour walk's end and the kernel exit) for the 320-row kernels.
 SCRATCH_BUDGET = [
-    ("attention", r"attn_(fwd_kernel<(true|false), 4, 0>|bwd_dq_kernel<(true|false), (true|false), 4>|bwd_dkv_kernel<true, false, 2, 4>)", 0, 0),
-    ("attention", r"attn_bwd_dkv_kernel<false, false, 3, 4>", 8, 2),     # (three waves per SIMD: one value at kernel entry / exit)
+    ("attention", r"attn_(fwd_kernel<(true|false), 4, 0>|bwd_dkv_kernel<true, false, 2, 4>)", 0, 0),
+    # (three waves per SIMD, 168 registers: up to three values parked between kernel entry and the output stores, outside the loops)
+    ("attention", r"attn_(bwd_dkv_kernel<false, false, 3, 4>|bwd_dq_kernel<(true|false), (true|false), 4>)", 12, 3),
     ("gemm_wp8_nn", r"gemm_wp_kernel<false, false, 2, 4, true, 0, 256>", 0, 0),
     ("gemm_wp8_nt", r"gemm_wp_kernel<false, true, 2, 4, true, 0, 256>", 0, 0),
     ("gemm_wp8_m320", r"gemm_wp_kernel<false, (true|false), 2, 4, true, 0, 320>", 16, 6),

@@ -5,7 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distil_whisper_amd import ops_hip as oh
 from distil_whisper_amd.ops_hip import HipOps
 ops = HipOps("cuda:0")
-libs = {"base": oh.load_library(os.path.join(os.path.dirname(oh.LIB_PATH), "libdwamd_base.so")), "new": ops.lib}
+libs = {"base": oh.load_library(os.path.join(os.path.dirname(oh.LIB_PATH), "libdwamd_base.so"))}
+_b2 = os.path.join(os.path.dirname(oh.LIB_PATH), "libdwamd_base2.so")      # (optional third build: tools/build_variant_lib.sh "<flags>" libdwamd_base2.so)
+if os.path.exists(_b2) and not os.environ.get("DW_NO_BASE2"):
+    libs["base2"] = oh.load_library(_b2)
+libs["new"] = ops.lib
 def rnd(shape, s=1.0, dt=torch.bfloat16): return (torch.randn(shape, device="cuda") * s).to(dt)
 M = 48000
 cases = [
@@ -56,8 +60,8 @@ for name, m, N, K, tb, mk in cases:
             res[k].append(s.elapsed_time(e) / 12 * 1e3)
     med = {k: sorted(v)[len(v) // 2] for k, v in res.items()}
     for k in med: tot[k] += med[k]
-    print(f"{name:34s} us/launch base {med['base']:7.1f}  new {med['new']:7.1f}  ({med['base'] / med['new']:.3f}x, {2.0 * m * N * K / med['new'] / 1e6:.0f} TF/s)  "
-          f"{'bit-identical' if same else 'DIFFERENT'}", flush=True)
+    print(f"{name:34s} us/launch " + "  ".join(f"{k} {v:7.1f}" for k, v in med.items()) +
+          f"  ({med['base'] / med['new']:.3f}x, {2.0 * m * N * K / med['new'] / 1e6:.0f} TF/s)  {'bit-identical' if same else 'DIFFERENT'}", flush=True)
     del As, outs, kw, b, got
     torch.cuda.empty_cache()
 print("sum of medians: " + ", ".join(f"{k} {v:.0f} us" for k, v in tot.items()))
