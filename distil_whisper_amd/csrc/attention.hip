@@ -410,36 +410,6 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// backward pre-pass: delta[b][h][q] = -sum_d dO[q][d] * O[q][d], delta[B*H*Lq + ...] = -lse / scale
-// (one wave handles 8 rows x 8 lanes)
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnP p) {
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long row = gid >> 3;  // (b, h, q) flattened
-    const int part = gid & 7;
-    const long total = (long)p.B * p.H * p.Lq;
-    float acc = 0.f;
-    long idx = row < total ? row : total - 1;
-    const int qi = idx % p.Lq;
-    const long bh = idx / p.Lq;
-    const int h = bh % p.H;
-    const long b = bh / p.H;
-    const bf16x8 a = *(const bf16x8*)(p.o + (b * p.Lq + qi) * p.ldo + h * 64 + part * 8);
-    const bf16x8 g = *(const bf16x8*)(p.d_o + (b * p.Lq + qi) * p.lddo + h * 64 + part * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc += bf2f(a[e]) * bf2f(g[e]);
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
-    // the dK/dV kernel starts its S and dP accumulators from these two tables (one LDS read instead of per-element
-    // subtractions): -delta, and -lse / scale (so that P = exp2(scale * log2e * (S - lse / scale)))
-    if (part == 0 && row < total) {
-        p.delta[row] = -acc;
-        p.delta[total + row] = -p.lse[row] / p.scale;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // backward dQ: stationary = 32 queries per wave (Q, dO fragments + lse, delta in registers); stream K, V tiles
 //   S^T = K.Q^T, dP^T = V.dO^T, dS^T = P^T*(dP^T - delta), dQ^T[d][q] += K^T . dS^T
 // ---------------------------------------------------------------------------------------------------------------
@@ -468,10 +438,28 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) 
     }
     const long sidx = ((long)b * p.H + h) * p.Lq + qc;
     const float c = p.scale * 1.4426950408889634f;
-    // the S and dP accumulators start from -lse / scale and -delta of the lane's query (the tables the delta pre-pass
-    // writes for the dK/dV kernel), so P = exp2(c * S) and dS = P * dP are packed multiplies with nothing to subtract
-    const float s0 = p.delta[(long)p.B * p.H * p.Lq + sidx];
-    const float dp0 = p.delta[sidx];
+    // delta[q] = sum_d dO[q][d] * O[q][d] is computed HERE, from the dO fragments the lane already holds and the matching
+    // pieces of its O row (round 5: the separate pre-pass read O and dO once more -- 246 MB and a launch per attention
+    // backward, 1.8 ms per step).  The S and dP accumulators start from -lse / scale and -delta of the lane's query, so
+    // P = exp2(c * S) and dS = P * dP are packed multiplies with nothing to subtract; the two tables are also written out
+    // for the dK/dV kernel, which streams them with its Q / dO tiles and is launched behind this kernel.
+    float dsum = 0.f;
+    {
+        const bf16* Orow = p.o + (long)b * p.Lq * p.ldo + h * 64;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 o8 = ldg8(Orow, qc, p.ldo, kk * 16 + hi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum += bf2f(o8[e]) * bf2f(gf[kk][e]);
+        }
+        dsum += __shfl_xor(dsum, 32);
+    }
+    const float s0 = -p.lse[sidx] / p.scale;
+    const float dp0 = -dsum;
+    if (q_ok && hi == 0) {
+        p.delta[sidx] = dp0;
+        p.delta[(long)p.B * p.H * p.Lq + sidx] = s0;
+    }
 
     int nkt = (p.Lk + 63) >> 6;
     if (CAUSAL) nkt = min(nkt, (min(qb0 + 32 * NW - 1, p.Lq - 1) >> 6) + 1);
@@ -796,9 +784,6 @@ extern "C" int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const
     p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.scale = scale;
     p.dq_colsum = dq_colsum; p.dv_colsum = dv_colsum;
     hipStream_t s = (hipStream_t)stream;
-    const long rows = (long)B * H * Lq;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((rows * 8 + 255) / 256), dim3(256), 0, s, p);
-    DW_CHECK_LAUNCH();
     const int q4 = (Lq + 127) / 128, k4 = (Lk + 127) / 128;
     dim3 gq(q4 * H * B), gk(k4 * H * B), block(256);
     p.plain_order = g_attn_plain_order;

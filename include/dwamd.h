@@ -128,8 +128,9 @@ int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_batch_rows, int64_t kv_batch_rows,
                    int causal, float scale, void* stream);
-/* delta: caller-owned f32 scratch of 2*B*H*Lq elements (the pre-pass stores -rowsum(dO*O) and -lse/scale there; the
- * dK/dV kernel starts its accumulators from them).  dq/dk/dv bf16 with row strides lddq/lddk/lddv. */
+/* delta: caller-owned f32 scratch of 2*B*H*Lq elements (the dQ kernel stores -rowsum(dO*O) and -lse/scale of its queries
+ * there; the dK/dV kernel, launched behind it, starts its accumulators from them).  dq/dk/dv bf16 with row strides
+ * lddq/lddk/lddv. */
 int dw_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                 float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int64_t ldq, int64_t ldk,
                 int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int64_t lddk, int64_t lddv, int causal,

@@ -28,7 +28,7 @@ CLASS_OF = [  # kernel symbol -> the per-class key bench.py / ops_hip.py use
     (r"gemm_wp16_kernel<false, false", "gemm_t256_NN"), (r"gemm_wp16_kernel<false, true", "gemm_t256_NT"),
     (r"gemm_wp16_kernel<true, true", "gemm_t256_TT"), (r"gemm_wp16_kernel<true, false", "gemm_t256_TN"),
     (r"gemm_phased_kernel", "gemm_t256_NT"), (r"gemm_skinny", "gemm_skinny"), (r"attn_fwd_kernel", "attn_fwd"), (r"attn_bwd_dkv", "attn_bwd_dkv"),
-    (r"attn_bwd_dq", "attn_bwd_dq"), (r"attn_delta", "attn_delta"), (r"attn_decode", "attn_decode"),
+    (r"attn_bwd_dq", "attn_bwd_dq"), (r"attn_decode", "attn_decode"),
     (r"ln_fwd", "ln_fwd"), (r"ln_bwd", "ln_bwd"), (r"adamw", "adamw"), (r"loss_row", "loss"),
     (r"colsum", "colsum"), (r"logmel", "logmel"), (r"sumsq", "sumsq"), (r"reduce_slices", "reduce_slices"),
     (r"move_rows", "move_rows"), (r"im2col|col2im", "conv_im2col"), (r"cast_f32_bf16|cast_bf16_f32", "cast"), (r"gelu_bwd", "gelu_bwd"),
