@@ -19,8 +19,8 @@ fe = WhisperFeatureExtractor(feature_size=128, ops=ops)
 CLIPS, NEW, B = int(os.environ.get("CLIPS", 4)), int(os.environ.get("NEW", 128)), int(os.environ.get("B", 16))
 audio = [0.1 * torch.randn(4_800_000, device=dev) for _ in range(CLIPS)]
 res = {"clips": CLIPS, "clip_s": 300, "batch": B, "new_tokens": NEW}
-if os.environ.get("DW_FUSE_AB"):              # decode-pass fusions (key 7): 3 = both off, 2 = LN on load only, 1 = K/V append only, 0 = both
-    for mode in (3, 2, 1, 0, 3, 0):
+if os.environ.get("DW_FUSE_AB"):              # decode-pass fusions OFF bits (key 7): 1 LN on load, 2 K/V append, 4 final LN inside the LM head, 8 fused cross-attention
+    for mode in eval(os.environ.get("DW_FUSE_MODES", "(3, 2, 1, 0, 3, 0)")):
         ops.lib.dw_debug_set(7, mode)
         tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True)
         feats = torch.randn(B, 128, 3000, device=dev) * 0.5
