@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (!(ABL & 16) || kt == 0) {
-            wait_vm0();
+            wait_vm0_seen();    // (seen by the compiler: its counted waits for the Q fragment loads otherwise sit inside this loop)
             __syncthreads();
         }
         if (kt + 1 < nkt && !(ABL & 8)) {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = xhalf_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float mc = m_new * c;
         // two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32): the softmax's vector
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
             }
         rs2[0] += rs2[1];
         float rs = rs2[0][0] + rs2[0][1];
-        rs += __shfl_xor(rs, 32);
+        rs = xhalf_sum(rs);
         if (__any(m_new != m_run)) {  // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             l_run *= alpha;
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) 
 #pragma unroll
             for (int e = 0; e < 8; ++e) dsum += bf2f(o8[e]) * bf2f(gf[kk][e]);
         }
-        dsum += __shfl_xor(dsum, 32);
+        dsum = xhalf_sum(dsum);
     }
     const float s0 = -p.lse[sidx] / p.scale;
     const float dp0 = -dsum;
@@ -469,18 +469,30 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) 
 
     stage_tile64<NW, FS>(K, p.ldk, 0, p.Lk, smem, wave, lane);
     stage_tile64<NW, FS>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
-    for (int kt = 0; kt < nkt; ++kt) {
+    // The tile loop exists per mask mode (0 none, 1 every pair, 2 decided per tile: the causal kernels) and the non-causal launch
+    // runs the full key tiles through mode 0 and the last, partial one through mode 1: tested inside ONE unrolled body the
+    // wave-uniform flag became sixteen taken branches per tile (round 5, from the generated code).
+    auto tiles = [&](auto modec, int kt_begin, int kt_end) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(modec)::value;
+    // lane-derived values of the staging and of the mask are re-derived per loop copy from an opaque copy of the lane index: held
+    // across both copies they are spilled, and a scratch reload in front of an operand load waits (vmcnt) for the load before it
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int hi_o = lane_o >> 5, q_o = qb0 + wave * 32 + (lane_o & 31);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int buf = kt & 1;
         wait_vm0();
         __syncthreads();
         if (kt + 1 < nkt) {
-            stage_tile64<NW, FS>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
-            stage_tile64<NW, FS>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
+            int lane_s = lane_o;           // (per iteration: hoisted out of the loop, the staging's lane offsets are what gets spilled)
+            asm volatile("" : "+v"(lane_s));
+            stage_tile64<NW, FS>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane_s);
+            stage_tile64<NW, FS>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane_s);
         }
         const char* tK = smem + buf * 16384;
         const char* tV = tK + 8192;
         const int wq0 = qb0 + wave * 32;
-        const bool need_mask = ((kt + 1) * 64 > p.Lk) || (CAUSAL && kt * 64 + 63 > wq0);
+        const bool need_mask = MODE == 1 || (MODE == 2 && (((kt + 1) * 64 > p.Lk) || (CAUSAL && kt * 64 + 63 > wq0)));
         if (CAUSAL && kt * 64 > wq0 + 31) continue;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -501,8 +513,8 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) 
                 if (need_mask) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const int key = kt * 64 + kb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hi;
-                        pv[e] = (key < p.Lk && (!CAUSAL || key <= q)) ? pv[e] : 0.f;
+                        const int key = kt * 64 + kb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hi_o;
+                        pv[e] = (key < p.Lk && (!CAUSAL || key <= q_o)) ? pv[e] : 0.f;
                     }
                 }
                 const f32x2 d2 = {dp[r], dp[r + 1]};
@@ -519,6 +531,13 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) 
                     acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tK, db, rb, rb + 8, lane), df, acc[db], 0, 0, 0);
             }
         }
+    }
+    };
+    if constexpr (CAUSAL) tiles(std::integral_constant<int, 2>{}, 0, nkt);
+    else {
+        const int nfull = p.Lk >> 6;
+        tiles(std::integral_constant<int, 0>{}, 0, nfull);
+        tiles(std::integral_constant<int, 1>{}, nfull, nkt);
     }
     bf16* DQ = p.dq + (long)b * p.Lq * p.lddq + h * 64;
     if (DW_ATTN_ROWSTORE && NW <= 7 && (p.lddq & 7) == 0 && ((uintptr_t)p.dq & 15) == 0) {
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { av[0][r] = 0.f; av[1][r] = 0.f; ak[0][r] = 0.f; ak[1][r] = 0.f; }
 
-    auto stage = [&](int qt, int buf) {
+    auto stage = [&](int qt, int buf, int lane) __attribute__((always_inline)) {
         char* base = smem + buf * 17408;
         stage_tile64<NW, FS>(Q, p.ldq, qt * 64, p.Lq, base, wave, lane);
         stage_tile64<NW, FS>(DO, p.lddo, qt * 64, p.Lq, base + 8192, wave, lane);
@@ -585,19 +604,30 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
         }
     };
 
-    if (qt0 < nqt) stage(qt0, 0);
-    for (int qt = qt0; qt < nqt; ++qt) {
+    if (qt0 < nqt) stage(qt0, 0, lane);
+    const int wk0 = kb0 + wave * 32;
+    // (one copy of the tile loop per mask mode: see the dQ kernel)
+    auto tiles = [&](auto modec, int qt_begin, int qt_end) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(modec)::value;
+    int lane_o = lane;                     // (see the dQ kernel)
+    asm volatile("" : "+v"(lane_o));
+    const int hi_o = lane_o >> 5, key_o = kb0 + wave * 32 + (lane_o & 31);
+    const bool k_ok_o = key_o < p.Lk;
+    for (int qt = qt_begin; qt < qt_end; ++qt) {
         const int buf = (qt - qt0) & 1;
-        wait_vm0();
+        wait_vm0_seen();    // (seen by the compiler: its counted waits for the K / V fragment loads otherwise sit inside this loop)
         __syncthreads();
-        if (qt + 1 < nqt) stage(qt + 1, buf ^ 1);
+        if (qt + 1 < nqt) {
+            int lane_s = lane_o;           // (per iteration: see the dQ kernel)
+            asm volatile("" : "+v"(lane_s));
+            stage(qt + 1, buf ^ 1, lane_s);
+        }
         const char* tQ = smem + buf * 17408;
         const char* tG = tQ + 8192;
         const float* tL = (const float*)(tQ + 16384);
         const float* tD = tL + 64;
-        const int wk0 = kb0 + wave * 32;
         // mask needed on the query tail, on a partially valid key block, or on the causal diagonal
-        const bool need_mask = ((qt + 1) * 64 > p.Lq) || (wk0 + 31 >= p.Lk) || (CAUSAL && wk0 + 31 > qt * 64);
+        const bool need_mask = MODE == 1 || (MODE == 2 && (((qt + 1) * 64 > p.Lq) || (wk0 + 31 >= p.Lk) || (CAUSAL && wk0 + 31 > qt * 64)));
         if (CAUSAL && wk0 > qt * 64 + 63) continue;  // all 64 queries of this tile precede every key of this wave
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -627,8 +657,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
                 if (need_mask) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const int qi = qt * 64 + qb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hi;
-                        pv[e] = (qi < p.Lq && k_ok && (!CAUSAL || key <= qi)) ? pv[e] : 0.f;
+                        const int qi = qt * 64 + qb * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hi_o;
+                        pv[e] = (qi < p.Lq && k_ok_o && (!CAUSAL || key_o <= qi)) ? pv[e] : 0.f;
                     }
                 }
                 pr[r] = pv[0];
@@ -650,6 +680,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
                 }
             }
         }
+    }
+    };
+    if constexpr (CAUSAL) tiles(std::integral_constant<int, 2>{}, qt0, nqt);
+    else {
+        // a wave whose 32 keys are not all valid masks every tile; the others only the last, partial query tile
+        const int nfull = wk0 + 31 >= p.Lk ? 0 : (p.Lq >> 6);
+        tiles(std::integral_constant<int, 0>{}, 0, nfull);
+        tiles(std::integral_constant<int, 1>{}, nfull, nqt);
     }
     bf16* DK = p.dk + (long)b * p.Lk * p.lddk + h * 64;
     bf16* DV = p.dv + (long)b * p.Lk * p.lddv + h * 64;

@@ -139,6 +139,26 @@ __device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
 }
 
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The same wait as an instruction the COMPILER sees (s_waitcnt vmcnt(0), expcnt / lgkmcnt untouched).  Needed where ordinary
+// global loads issued in front of a loop (the stationary operand's fragments) are first used inside it: the compiler's own
+// counted waits for them (vmcnt(3) .. vmcnt(0) in front of the first MFMAs) stay in the loop body for every iteration, where
+// they also wait for the tile prefetch the asm above has just issued -- the wave sat out the prefetch latency once per tile
+// (round 5, found in the generated code of attn_fwd_kernel / attn_bwd_dkv_kernel).  Behind this instruction the compiler knows
+// that nothing of its own is in flight and emits none.
+__device__ __forceinline__ void wait_vm0_seen() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" ::: "memory");
+}
+// max / sum across the two 32-lane halves of a wave through v_permlane32_swap (one vector instruction; __shfl_xor(v, 32) is
+// a ds_bpermute: an LDS round trip with an lgkmcnt wait on the softmax's serial path)
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // Fragment of a row-major [rows][64] swizzled tile for v_mfma_f32_32x32x16_bf16:
 // lane holds X[rb*32 + (lane&31)][kk*16 + 8*(lane>>5) + 0..7].
