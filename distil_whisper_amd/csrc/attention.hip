@@ -17,6 +17,9 @@
 #include "../../include/dwamd.h"
 
 #define NEG_BIG (-1.0e30f)
+#ifndef DW_ATTN_DEFER
+#define DW_ATTN_DEFER 8
+#endif
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct AttnP {
@@ -207,7 +210,12 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = xhalf_max(mx);
-        const float m_new = fmaxf(m_run, mx);
+        // Deferred maximum: the reference point of the running softmax moves only when some row's tile maximum exceeds it by more
+        // than 2^DW_ATTN_DEFER (probabilities then stay below 2^8 -- nothing for fp32 sums or the bf16 P operand, whose relative
+        // precision does not depend on the scale); with the exact rule some row of the wave's 32 sees a new maximum in three tiles
+        // out of four at 1500 keys, and every such tile pays the 32-register rescale of O.  -DDW_ATTN_DEFER=0 is the exact rule.
+        const bool move = __any((mx - m_run) * c > (float)DW_ATTN_DEFER);
+        const float m_new = move ? fmaxf(m_run, mx) : m_run;
         const float mc = m_new * c;
         // two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32): the softmax's vector
         // instructions, not the matrix pipe, bound this loop at head_dim 64
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
         rs2[0] += rs2[1];
         float rs = rs2[0][0] + rs2[0][1];
         rs = xhalf_sum(rs);
-        if (__any(m_new != m_run)) {  // rescale only when some row's running max moved (exact: alpha == 1 otherwise)
+        if (move) {  // rescale only when the reference moved (exact: alpha == 1 for the rows whose maximum stayed)
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
             l_run *= alpha;
 #pragma unroll
