@@ -341,7 +341,8 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
 
         // ---- prologue: tile 0 whole, first half of tile 1, fragments of (0, 0) ----
         const bool tile_in = m0 + BM <= p.m && n0 + BN <= p.n;
-        if (p.bias && tile_in && wave == 0) glds16(p.bias + n0 + lane * 4, bias_lds);   // (issued first: lands with tile 0)
+        // (issued first: lands with tile 0; scalar base + 32-bit lane offset, see gemm_wp16.h)
+        if (p.bias && tile_in && wave == 0) glds16_so(p.bias + n0, (unsigned)lane_k * 16u, lds_addr_of(bias_lds));
         if (!prefetched) { dma(I0{}, (DBG & 2) ? 8 : 0); dma(I1{}, (DBG & 2) ? 8 : 0); }
         kA += stepA; kB += stepB;
         if (nt > 1) dma(I0{}, (DBG & 2) ? 9 : 1);

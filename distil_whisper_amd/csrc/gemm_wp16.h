@@ -246,7 +246,9 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
 
         // ---- prologue: tile 0 whole, first half of tile 1, fragments of (tile 0, k step 0): A half 0 and B ----
         const bool tile_in = m0 + BM <= p.m && n0 + BN <= p.n;
-        if (p.bias && tile_in && wave == 0) glds16(p.bias + n0 + lane * 4, bias_lds);
+        // (scalar base + 32-bit lane offset: as a per-lane 64-bit pointer the address was held across the tile loop, spilled, and its
+        // reload -- a VMEM load -- waited with vmcnt(0) for the previous tile's stores in front of this tile's first operand load)
+        if (p.bias && tile_in && wave == 0) glds16_so(p.bias + n0, (unsigned)lane_k * 16u, lds_addr_of(bias_lds));
         dma(I0{}, 0); dma(I1{}, 0);
         kA += stepA; kB += stepB;
         if (nt > 1) dma(I0{}, 1);

@@ -287,7 +287,8 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *   key 3   attention backward variant (bit 0 dQ, bit 1 dK/dV fast tile staging, bit 2 dK/dV at 3 waves per SIMD -- bits 1
  *           and 2 apply to the NON-causal dK/dV kernel only: the causal launch always runs two waves per SIMD; default 5);   key 4  single-query attention kernel (bit 0 on [default], bit 1 all-loads-up-front variant)
  *   key 5   log-mel DFT on the matrix cores (default 1);   key 7  decode-step fusions off (bit 0 LayerNorm-on-load,
- *           bit 1 K/V append);   key 8  wide LM-head GEMV (default 1)
+ *           bit 1 K/V append, bit 2 self-attention with its q / k / v projection inside, bit 3 cross-attention with its q
+ *           projection inside; default 4);   key 8  wide LM-head GEMV (default 1)
  *   key 19  row-major 256-row GEMMs run main-loop ablation `value` (1 no fragment reads, 2 no operand DMA, 3 both, 4 DMA that
  *           always hits L2; WRONG results by construction; tools/gemm_dma_diag.py);   key 20  bit mask: software-pipelined GEMM
  *           kernels on v_mfma_f32_16x16x32_bf16 (1 row-major, 2 k-major B, 4 both k-major, 32 row-major with K <= 2560 and

@@ -141,6 +141,24 @@ def test_decode_family_eager_equals_graph_replay_gpu():
         _check_short(ops, SC[name], graphs=False)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fuse_off", [0, 8, 12])
+def test_decode_fixtures_under_every_token_step_fusion_mode_gpu(fuse_off):
+    """dw_debug_set key 7: 4 is the default (cross-attention with its q projection inside, self-attention as separate launches);
+    0 adds the self-attention kernel with its q / k / v projection and cache append inside (measured slower, kept behind the
+    switch), 8 / 12 are the separate-launch forms.  Every mode must reproduce the reference's tokens."""
+    ops = _ops("hip")
+    assert ops.lib.dw_debug_set(7, fuse_off) == 0
+    try:
+        for name in ("greedy_suppress_student", "timestamps_single_call"):
+            _check_short(ops, SC[name], graphs=True)
+        for s in GOLD["scenarios"]:
+            if s["kind"] == "longform":
+                _check_longform(ops, s, True)
+    finally:
+        ops.lib.dw_debug_set(7, 4)
+
+
 def _encoder_outputs_and_shared_assistant(ops):
     """`generate(encoder_outputs=...)` in every accepted layout (run_eval.py:806-844 `benchmark_gen`) and an assistant
     that re-uses the target's encoder output (run_eval.py:578-599), on the margin-selected fixture cases: the same

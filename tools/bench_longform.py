@@ -19,7 +19,7 @@ fe = WhisperFeatureExtractor(feature_size=128, ops=ops)
 CLIPS, NEW, B = int(os.environ.get("CLIPS", 4)), int(os.environ.get("NEW", 128)), int(os.environ.get("B", 16))
 audio = [0.1 * torch.randn(4_800_000, device=dev) for _ in range(CLIPS)]
 res = {"clips": CLIPS, "clip_s": 300, "batch": B, "new_tokens": NEW}
-if os.environ.get("DW_FUSE_AB"):              # decode-pass fusions OFF bits (key 7): 1 LN on load, 2 K/V append, 4 final LN inside the LM head, 8 fused cross-attention
+if os.environ.get("DW_FUSE_AB"):              # decode-pass fusions OFF bits (key 7): 1 LN on load, 2 K/V append, 4 self-attention with its QKV projection inside, 8 cross-attention with its q projection inside
     for mode in eval(os.environ.get("DW_FUSE_MODES", "(3, 2, 1, 0, 3, 0)")):
         ops.lib.dw_debug_set(7, mode)
         tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True)
@@ -32,7 +32,7 @@ if os.environ.get("DW_FUSE_AB"):              # decode-pass fusions OFF bits (ke
         for _ in range(3): tr.decoder.run(enc, prompt, NEW)
         torch.cuda.synchronize()
         print(f"fuse_off={mode}: {(time.perf_counter() - t0) / 3 / NEW * 1e3:.4f} ms per decode step (graphs)", file=sys.stderr)
-    ops.lib.dw_debug_set(7, 0)
+    ops.lib.dw_debug_set(7, 4)
 if os.environ.get("DW_DECODE_AB"):            # streaming single-query attention kernel off (tile kernel) vs on
     for mode in (0, 1):
         ops.lib.dw_debug_set(4, mode)

@@ -16,7 +16,7 @@ del t_sd
 model = WhisperForConditionalGeneration(sdims, ops=ops, state_dict=s_sd)
 fe = WhisperFeatureExtractor(feature_size=128, ops=ops)
 B, NEW = int(os.environ.get("B", 16)), int(os.environ.get("NEW", 64))
-ops.lib.dw_debug_set(7, int(os.environ.get("FUSE_OFF", 0)))
+ops.lib.dw_debug_set(7, int(os.environ.get("FUSE_OFF", 4)))
 tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=bool(int(os.environ.get("GRAPHS", 1))))
 feats = torch.randn(B, 128, 3000, device=dev) * 0.5
 enc, _ = model.engine.encode(feats, save=False)
