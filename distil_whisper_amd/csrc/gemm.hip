@@ -82,6 +82,7 @@ static unsigned g_gemm_trace_lo = 0, g_gemm_trace_hi = 0;   // dw_debug_set keys
 static int g_gemm_mi16 = 36;
 static int g_gemm_dbg = 0;       // dw_debug_set key 19: row-major 256-row GEMMs run the ablation / experiment kernel `value` of gemm_wp8_dbg.hip
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
+static int g_gemm_row_tail = 1;  // dw_debug_set key 22: the partial last row block of a wide 256-row launch goes to the 128-tile kernel when that saves a round
 
 // Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never
 // overlap and the last workgroup of a launch leaves them zeroed).  64 bytes are allocated the first time a stream
@@ -122,6 +123,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 19) { g_gemm_dbg = value; return DW_OK; }
     if (key == 20) { g_gemm_mi16 = value; return DW_OK; }
     if (key == 21) { g_ln_variant = value; return DW_OK; }
+    if (key == 22) { g_gemm_row_tail = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
     if (key == 16) { g_attn_fwd_waves = value; return DW_OK; }
     if (key == 15) { g_attn_ablate = value; return DW_OK; }
@@ -280,7 +282,31 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
                               !g->r && !g->z_out && !g->zgrad_in && g->c_dtype != DW_F32 &&    // (the flavours of the accumulator-side walk)
                               !one_round_320 && !(v & 4096) && !g_gemm_dbg;   // (a forced / single-round 320-row tile and the ablation path keep their kernel)
         auto launch256 = [&](const GemmP& q) -> int {
-            if (nn16_256) return dw_gemm_wp16_nn_launch(q, s);
+            if (nn16_256) {
+                // Row tail (round 5; dw_debug_set key 22, default on): M = 48 000 is 187.5 row tiles -- 2 820 tiles = 11.02 rounds of the
+                // CUs, and with the per-XCD job ranges four XCDs run a TWELFTH round for four tiles (8 % of the launch).  The last,
+                // partial row block (<= 128 rows: 30 small tiles) goes to the 128-tile kernel when the full row blocks alone need a
+                // round less: 2 805 tiles = 10.96 rounds + a ~15 us launch instead of 12 rounds.  (Splitting a whole partial ROUND off was
+                // measured 8 ms slower in round 2 -- the second launch waits for the slowest workgroup of the first; this is a 30-tile
+                // launch.)  Same arithmetic per output element in both kernels: bit-identical to the single launch.
+                const int tm_full = q.m / 256, rem = q.m - tm_full * 256;
+                const long tn = (q.n + 255) / 256;
+                const long rounds_all = ((long)(tm_full + 1) * tn + g_gemm_cus - 1) / g_gemm_cus;
+                const long rounds_full = ((long)tm_full * tn + g_gemm_cus - 1) / g_gemm_cus;
+                if (g_gemm_row_tail && g->tile != 256 && rem > 0 && rem <= 128 && tm_full > 0 && rounds_full < rounds_all && !q.colsum) {
+                    GemmP q1 = q, q2 = q;
+                    q1.m = tm_full * 256;
+                    const size_t es = q.c_dtype == DW_F32 ? 4 : 2;
+                    q2.m = rem;
+                    q2.a = q.a + (long)q1.m * q.lda;
+                    q2.c = (char*)q.c + (size_t)q1.m * q.ldc * es;
+                    q2.sched = nullptr;
+                    const int rc1 = dw_gemm_wp16_nn_launch(q1, s);
+                    if (rc1 != DW_OK) return rc1;
+                    return dw_gemm_tile128_launch(q2, 0, 0, s);
+                }
+                return dw_gemm_wp16_nn_launch(q, s);
+            }
             if (use320) {
                 if (g->trans_b) return (g_gemm_mi16 & 2) ? dw_gemm_wp16_nt320_launch(q, s) : dw_gemm_wp8_nt320_launch(q, s);
                 return (g_gemm_mi16 & 1) ? dw_gemm_wp16_nn320_launch(q, s) : dw_gemm_wp8_nn320_launch(q, s);

@@ -295,7 +295,9 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *           N >= 3840 on the 256-row tile; default 36; bit-identical results;
  *           8 / 16: the four-wave 128 x 128-per-wave experiment for row-major / k-major B, gemm_wp16_w4.hip)
  *   key 21  LayerNorm kernels: bit 0 persistent fp32-input forward with next-row prefetch (bits 8-11: workgroups per CU),
- *           bit 1 backward with next-row / residual-gradient prefetch at two waves per SIMD (default 3; tools/ln_ab.py) */
+ *           bit 1 backward with next-row / residual-gradient prefetch at two waves per SIMD (default 3; tools/ln_ab.py)
+ *   key 22  wide row-major 256-row launches hand a partial last row block (<= 128 rows) to the 128-tile kernel when the full
+ *           row blocks alone need one round of the CUs less (default 1; bit-identical) */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus

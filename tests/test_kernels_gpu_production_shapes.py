@@ -96,6 +96,25 @@ def test_lm_head_and_weight_gradient_gemms(ops, ref):
     assert relerr(w1, w2) < 2e-3
 
 
+def test_row_tail_of_the_wide_256_row_launches_is_bit_identical(ops):
+    """dw_debug_set key 22 (default on): QKV / teacher-fc1 launches at M = 48 000 hand their 128-row tail to the 128-tile kernel
+    (2 805 tiles = 10.96 rounds + 30 small tiles instead of 11.02 rounds -> 12).  Same fp32 chain per output element: the
+    results must equal the single launch bit for bit, also for a ragged tail and with the GELU epilogue."""
+    try:
+        for M, N, kw in ((M_ENC, 3 * D, dict(bias=rnd((3 * D,), 1.0, torch.float32, seed=3))),
+                         (M_ENC, F, dict(bias=rnd((F,), 1.0, torch.float32, seed=4), act=1)),
+                         (M_ENC - 37, 3 * D, dict(bias=rnd((3 * D,), 1.0, torch.float32, seed=5)))):
+            a = rnd((M, D), 1.0, seed=6)
+            b = rnd((N, D), 0.03, seed=7)
+            assert ops.lib.dw_debug_set(22, 0) == 0
+            one = ops.gemm(a, b, **kw).clone()
+            assert ops.lib.dw_debug_set(22, 1) == 0
+            two = ops.gemm(a, b, **kw)
+            assert torch.equal(one, two), (M, N)
+    finally:
+        ops.lib.dw_debug_set(22, 1)
+
+
 @pytest.mark.parametrize("Lq,Lk,causal", [(1500, 1500, False), (447, 447, True), (447, 1500, False)])
 def test_attention_at_model_shapes(ops, ref, Lq, Lk, causal):
     B = 4
