@@ -96,3 +96,26 @@ def test_default_kernels_stay_within_their_scratch_budget(tu, pattern, max_bytes
         ops = sum(1 for l in body if l.strip().startswith("scratch_"))
         assert scratch_bytes <= max_bytes and ops <= max_ops, (pretty, scratch_bytes, ops)
     assert hit >= 1, f"no kernel of {tu} matches {pattern}"
+
+@pytest.mark.skipif(not os.path.exists(HIPCC) or shutil.which("c++filt") is None, reason="needs the ROCm compiler")
+def test_attention_tile_loops_wait_for_vmem_only_at_their_top():
+    """Round 5 finding: the compiler's counted waits for ordinary loads issued in front of a tile loop (the stationary operand's
+    fragments) stayed inside the loop -- `s_waitcnt vmcnt(3) .. vmcnt(0)` in front of the first MFMAs -- where they also waited for
+    the tile prefetch the inline-assembly DMA had just issued.  With the loop-top wait as an instruction the compiler sees
+    (common.h wait_vm0_seen) the only VMEM wait of a forward / dK-dV tile loop is that one; a dQ loop has exactly one as well."""
+    import re
+    lint = _lint()
+    asm = _asm(lint, "attention")
+    names = subprocess.run(["c++filt"], input="\n".join(n for n, _ in lint.kernels(asm)), capture_output=True, text=True).stdout.split("\n")
+    seen = 0
+    for (name, body), pretty in zip(lint.kernels(asm), names):
+        if not re.search(r"attn_(fwd_kernel<(true|false), 4, 0>|bwd_dkv_kernel<false, false, 3, 4>|bwd_dq_kernel<false, (true|false), 4>)", pretty):
+            continue
+        for a, b, seg in lint.loops(body):
+            n, c = lint.census(seg)
+            if c["mfma"] == 0 or c["mfma"] > 64:
+                continue
+            waits = [l.strip() for l in seg if re.search(r"s_waitcnt.*vmcnt\(", l)]
+            seen += 1
+            assert len(waits) == 1 and "vmcnt(0)" in waits[0], (pretty, a, b, waits)
+    assert seen >= 5, seen
