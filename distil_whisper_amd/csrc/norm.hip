@@ -30,7 +30,7 @@ __device__ __forceinline__ void ln_store(T* dst, const T& v) {
 
 template <bool XBF, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float* gamma, const float* beta, bf16* y,
-                                                     float* mean, float* rstd, int rows, int cols, float eps) {
+                                                     float* mean, float* rstd, int rows, int cols, float eps, long ldx, long ldy) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float*
     for (int j = 0; j < NV; ++j) {
         const int idx = lane + 64 * j;
         if (idx < nvec) {
-            v[j] = ld4<XBF>(x, (long)row * cols + idx * 4);
+            v[j] = ld4<XBF>(x, (long)row * ldx + idx * 4);
             s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
         }
     }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float*
             bf16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = f2bf((v[j][e] - mu) * rs * g[e] + bt[e]);
-            ln_store<1>((bf16x4*)(y + (long)row * cols + idx * 4), o);
+            ln_store<1>((bf16x4*)(y + (long)row * ldy + idx * 4), o);
         }
     }
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float*
 // life being launched and retired, and have nothing in flight while they reduce (dw_debug_set key 21 bit 0).
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, const float* gamma, const float* beta, bf16* y,
-                                                             float* mean, float* rstd, int rows, int cols, float eps) {
+                                                             float* mean, float* rstd, int rows, int cols, float eps, long ldx, long ldy) {
     const int lane = threadIdx.x & 63;
     const int nvec = cols >> 2;
     const int stride = gridDim.x * 4;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, con
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = lane + 64 * j;
-        if (idx < nvec) v[j] = *(const f32x4*)(x + (long)row * cols + idx * 4);
+        if (idx < nvec) v[j] = *(const f32x4*)(x + (long)row * ldx + idx * 4);
     }
     for (; row < rows; row += stride) {
         const int nrow = row + stride;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, con
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int idx = lane + 64 * j;
-                if (idx < nvec) nx[j] = *(const f32x4*)(x + (long)nrow * cols + idx * 4);
+                if (idx < nvec) nx[j] = *(const f32x4*)(x + (long)nrow * ldx + idx * 4);
             }
         }
         float s = 0.f;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, con
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = f2bf((v[j][e] - mu) * rs * g[e] + bt[e]);
-                ln_store<1>((bf16x4*)(y + (long)row * cols + idx * 4), o);
+                ln_store<1>((bf16x4*)(y + (long)row * ldy + idx * 4), o);
             }
         }
         if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, con
 // fp32 input (tools/stream_kernels_bench.py).
 template <int NV8>
 __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16* x, const float* gamma, const float* beta, bf16* y,
-                                                            float* mean, float* rstd, int rows, int cols, float eps) {
+                                                            float* mean, float* rstd, int rows, int cols, float eps, long ldx, long ldy) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16* x, const
     for (int j = 0; j < NV8; ++j) {
         const int idx = lane + 64 * j;
         if (idx < nvec) {
-            const bf16x8 t = *(const bf16x8*)(x + (long)row * cols + idx * 8);
+            const bf16x8 t = *(const bf16x8*)(x + (long)row * ldx + idx * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[j][e] = bf2f(t[e]); s += v[j][e]; }
         }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16* x, const
                 o[e] = f2bf((v[j][e] - mu) * rs * g0[e] + b0[e]);
                 o[e + 4] = f2bf((v[j][e + 4] - mu) * rs * g1[e] + b1[e]);
             }
-            ln_store<1>((bf16x8*)(y + (long)row * cols + idx * 8), o);
+            ln_store<1>((bf16x8*)(y + (long)row * ldy + idx * 8), o);
         }
     }
     if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
@@ -188,7 +188,8 @@ template <bool XBF, int NV, int NW>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const void* x, const float* mean,
                                                      const float* rstd, const float* gamma, float* dres,
                                                      int accumulate, float* dgamma, float* dbeta, bf16* dres_lowp,
-                                                     float* dres_colsum, int rows, int cols) {
+                                                     float* dres_colsum, int rows, int cols, long lddy, long ldx, long lddres,
+                                                         long ldlowp) {
     __shared__ float red[3 * NW * 512];  // [dgamma|dbeta|colsum][wave][512-column window]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const v
         for (int j = 0; j < NV; ++j) {
             const int idx = lane + 64 * j;
             if (idx < nvec) {
-                const f32x4 xv = ld4<XBF>(x, (long)row * cols + idx * 4);
-                const f32x4 dv = ld4<true>(dy, (long)row * cols + idx * 4);
+                const f32x4 xv = ld4<XBF>(x, (long)row * ldx + idx * 4);
+                const f32x4 dv = ld4<true>(dy, (long)row * lddy + idx * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     xh[j][e] = (xv[e] - mu) * rs;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const v
         for (int j = 0; j < NV; ++j) {
             const int idx = lane + 64 * j;
             if (idx < nvec) {
-                float* dst = dres + (long)row * cols + idx * 4;
+                float* dst = dres + (long)row * lddres + idx * 4;
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const v
                     bf16x4 lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { lo[e] = f2bf(o[e]); ac[j][e] += bf2f(lo[e]); }
-                    ln_store<3>((bf16x4*)(dres_lowp + (long)row * cols + idx * 4), lo);
+                    ln_store<3>((bf16x4*)(dres_lowp + (long)row * ldlowp + idx * 4), lo);
                 }
             }
         }
@@ -288,7 +289,8 @@ template <bool XBF, int NV, int NW>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, const void* x, const float* mean,
                                                          const float* rstd, const float* gamma, float* dres,
                                                          int accumulate, float* dgamma, float* dbeta, bf16* dres_lowp,
-                                                         float* dres_colsum, int rows, int cols) {
+                                                         float* dres_colsum, int rows, int cols, long lddy, long ldx, long lddres,
+                                                         long ldlowp) {
     __shared__ float red[3 * NW * 512];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int idx = lane + 64 * j;
-            if (idx < nvec) { xv[j] = ld4<XBF>(x, (long)row * cols + idx * 4); dv[j] = ld4<true>(dy, (long)row * cols + idx * 4); }
+            if (idx < nvec) { xv[j] = ld4<XBF>(x, (long)row * ldx + idx * 4); dv[j] = ld4<true>(dy, (long)row * lddy + idx * 4); }
         }
     }
     for (; row < rows; row += stride) {
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int idx = lane + 64 * j;
-                if (idx < nvec) old[j] = *(const f32x4*)(dres + (long)row * cols + idx * 4);
+                if (idx < nvec) old[j] = *(const f32x4*)(dres + (long)row * lddres + idx * 4);
             }
         }
         if (nrow < rows) {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int idx = lane + 64 * j;
-                if (idx < nvec) { nxv[j] = ld4<XBF>(x, (long)nrow * cols + idx * 4); ndv[j] = ld4<true>(dy, (long)nrow * cols + idx * 4); }
+                if (idx < nvec) { nxv[j] = ld4<XBF>(x, (long)nrow * ldx + idx * 4); ndv[j] = ld4<true>(dy, (long)nrow * lddy + idx * 4); }
             }
         }
         f32x4 xh[NV], g[NV];
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
         for (int j = 0; j < NV; ++j) {
             const int idx = lane + 64 * j;
             if (idx < nvec) {
-                float* dst = dres + (long)row * cols + idx * 4;
+                float* dst = dres + (long)row * lddres + idx * 4;
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - c1 - xh[j][e] * c2);
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
                     bf16x4 lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { lo[e] = f2bf(o[e]); ac[j][e] += bf2f(lo[e]); }
-                    ln_store<3>((bf16x4*)(dres_lowp + (long)row * cols + idx * 4), lo);
+                    ln_store<3>((bf16x4*)(dres_lowp + (long)row * ldlowp + idx * 4), lo);
                 }
             }
         }
@@ -413,20 +415,30 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
 // (the teacher's stream, cache resident) measured neutral (52.7 vs 51.7 us) and is not built.
 int g_ln_variant = 3;
 
+extern "C" int dw_layernorm_fwd_ld(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                                   float* mean, float* rstd, int rows, int cols, float eps, int64_t ldx_, int64_t ldy_, void* stream);
 extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
                                 float* mean, float* rstd, int rows, int cols, float eps, void* stream) {
+    return dw_layernorm_fwd_ld(x, x_dtype, gamma, beta, y, mean, rstd, rows, cols, eps, cols, cols, stream);
+}
+// The same with row pitches (elements) of x and y: activation buffers whose rows are padded against L2-channel camping
+// (engine.row_pad; tools/gemm_stride_probe.py).
+extern "C" int dw_layernorm_fwd_ld(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                                   float* mean, float* rstd, int rows, int cols, float eps, int64_t ldx_, int64_t ldy_, void* stream) {
     DW_CLEAR_ERR();
     if (!x || !gamma || !beta || !y || rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
+    if (ldx_ < cols || ldy_ < cols || (ldx_ & 3) || (ldy_ & 3)) return DW_EINVAL;
+    const long ldx = ldx_, ldy = ldy_;
     if ((mean == nullptr) != (rstd == nullptr)) return DW_EINVAL;
     dim3 grid((rows + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (x_dtype == DW_BF16 && (cols & 7) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+    if (x_dtype == DW_BF16 && (cols & 7) == 0 && ((ldx | ldy) & 7) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
         ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0) {
         const int nv8 = ((cols >> 3) + 63) / 64;
-        if (nv8 <= 1) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<1>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps);
-        else if (nv8 <= 2) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<2>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps);
-        else if (nv8 <= 3) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<3>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps);
-        else hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<4>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps);
+        if (nv8 <= 1) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<1>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, ldx, ldy);
+        else if (nv8 <= 2) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<2>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, ldx, ldy);
+        else if (nv8 <= 3) hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<3>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, ldx, ldy);
+        else hipLaunchKernelGGL((ln_fwd_bf16x8_kernel<4>), grid, block, 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, ldx, ldy);
         DW_CHECK_LAUNCH();
         return DW_OK;
     }
@@ -434,7 +446,7 @@ extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     if ((g_ln_variant & 1) && x_dtype != DW_BF16 && nv <= 5 && rows >= 8192) {
         // resident grid: 5 workgroups of 4 waves per CU (v + next row + parameters: ~100 registers)
         dim3 pg(256 * ((g_ln_variant >> 8) & 15 ? (g_ln_variant >> 8) & 15 : 5));
-        hipLaunchKernelGGL((ln_fwd_persist_kernel<5>), pg, block, 0, s, (const float*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps);
+        hipLaunchKernelGGL((ln_fwd_persist_kernel<5>), pg, block, 0, s, (const float*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, ldx, ldy);
         DW_CHECK_LAUNCH();
         return DW_OK;
     }
@@ -442,10 +454,10 @@ extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     do {                                                                                                              \
         if (x_dtype == DW_BF16)                                                                                       \
             hipLaunchKernelGGL((ln_fwd_kernel<true, NVV>), grid, block, 0, s, x, gamma, beta, (bf16*)y, mean, rstd,   \
-                               rows, cols, eps);                                                                      \
+                               rows, cols, eps, ldx, ldy);                                                                      \
         else                                                                                                          \
             hipLaunchKernelGGL((ln_fwd_kernel<false, NVV>), grid, block, 0, s, x, gamma, beta, (bf16*)y, mean, rstd,  \
-                               rows, cols, eps);                                                                      \
+                               rows, cols, eps, ldx, ldy);                                                                      \
     } while (0)
     if (nv <= 2) LN_FWD(2); else if (nv <= 3) LN_FWD(3); else if (nv <= 5) LN_FWD(5); else LN_FWD(8);
 #undef LN_FWD
@@ -453,12 +465,26 @@ extern "C" int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     return DW_OK;
 }
 
+extern "C" int dw_layernorm_bwd_ld(const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
+                                   const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta,
+                                   void* dres_lowp, float* dres_colsum, int rows, int cols, int64_t lddy_, int64_t ldx_,
+                                   int64_t lddres_, int64_t ldlowp_, void* stream);
 extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
                                 const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta,
                                 void* dres_lowp, float* dres_colsum, int rows, int cols, void* stream) {
+    return dw_layernorm_bwd_ld(dy, x, x_dtype, mean, rstd, gamma, dres, accumulate, dgamma, dbeta, dres_lowp, dres_colsum, rows,
+                               cols, cols, cols, cols, cols, stream);
+}
+// ... with row pitches (elements) of dy, x, the fp32 residual gradient and its bf16 copy
+extern "C" int dw_layernorm_bwd_ld(const void* dy, const void* x, int x_dtype, const float* mean, const float* rstd,
+                                   const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta,
+                                   void* dres_lowp, float* dres_colsum, int rows, int cols, int64_t lddy_, int64_t ldx_,
+                                   int64_t lddres_, int64_t ldlowp_, void* stream) {
     DW_CLEAR_ERR();
     if (!dy || !x || !mean || !rstd || !gamma || !dres || !dgamma || !dbeta) return DW_EINVAL;
     if (rows <= 0 || cols <= 0 || (cols & 3) || cols > LN_MAXV * 256) return DW_EINVAL;
+    if (lddy_ < cols || ldx_ < cols || lddres_ < cols || ldlowp_ < cols || ((lddy_ | ldx_ | lddres_ | ldlowp_) & 3)) return DW_EINVAL;
+    const long lddy = lddy_, ldx = ldx_, lddres = lddres_, ldlowp = ldlowp_;
     hipStream_t s = (hipStream_t)stream;
     const int nv = ((cols >> 2) + 63) / 64;
     // grid = exactly the workgroups that are resident at once: a grid-stride loop over rows on a grid of 1.33 rounds left
@@ -476,21 +502,21 @@ extern "C" int dw_layernorm_bwd(const void* dy, const void* x, int x_dtype, cons
         if (x_dtype == DW_BF16)                                                                                       \
             hipLaunchKernelGGL((ln_bwd_kernel<true, NVV, NWW>), dim3(nb), dim3(NWW * 64), 0, s, (const bf16*)dy, x,   \
                                mean, rstd, gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum,     \
-                               rows, cols);                                                                           \
+                               rows, cols, lddy, ldx, lddres, ldlowp);                                                                           \
         else                                                                                                          \
             hipLaunchKernelGGL((ln_bwd_kernel<false, NVV, NWW>), dim3(nb), dim3(NWW * 64), 0, s, (const bf16*)dy, x,  \
                                mean, rstd, gamma, dres, accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum,     \
-                               rows, cols);                                                                           \
+                               rows, cols, lddy, ldx, lddres, ldlowp);                                                                           \
     } while (0)
     if ((g_ln_variant & 2) && nv == 5) {
         int nb = (rows + 7) / 8;
         if (nb > 256) nb = 256;
         if (x_dtype == DW_BF16)
             hipLaunchKernelGGL((ln_bwd_pf_kernel<true, 5, 8>), dim3(nb), dim3(512), 0, s, (const bf16*)dy, x, mean, rstd, gamma, dres,
-                               accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols);
+                               accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols, lddy, ldx, lddres, ldlowp);
         else
             hipLaunchKernelGGL((ln_bwd_pf_kernel<false, 5, 8>), dim3(nb), dim3(512), 0, s, (const bf16*)dy, x, mean, rstd, gamma, dres,
-                               accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols);
+                               accumulate, dgamma, dbeta, (bf16*)dres_lowp, dres_colsum, rows, cols, lddy, ldx, lddres, ldlowp);
         DW_CHECK_LAUNCH();
         return DW_OK;
     }

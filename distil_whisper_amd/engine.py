@@ -264,14 +264,32 @@ class WhisperEngine:
         self.pad_lm_rows = True             # training passes: zero pad rows behind hf / logits for the LM-head backward
 
     # ---- helpers -------------------------------------------------------------------------------------------------
-    def act(self, rows, cols, dtype=None, zero_pad=True):
+    # Row pitch of the wide activation buffers (round 5, tools/gemm_stride_probe.py): a [48000 x 5120] bf16 operand has 10 240-byte
+    # rows, and a GEMM tile reads 128 bytes of each of 256-320 consecutive rows -- addresses 10 KiB apart fall on two of an XCD's
+    # sixteen L2 channels.  With 64 more elements per row (128 bytes) the rows of a tile spread over all channels: fc2 forward
+    # 1 117-1 126 -> 1 269-1 323 TFLOP/s (+14..17 %), the fc1 weight gradient +10 %, dX of fc1 +4 %.  The pad columns are never
+    # read or written (every consumer takes the row pitch: GEMM operands / outputs, stored gelu').
+    ffn_row_pad = 64
+    # ... and of the d_model-wide bf16 buffers inside the layers (LayerNorm outputs, the fused QKV / Q / KV projections and their
+    # gradients, attention outputs, the bf16 copy of the residual gradient): 2 560 / 7 680-byte rows fall on 8 of the 16 channels --
+    # QKV forward +4 %, fc1 forward +2 %, the fc1 weight gradient (h is its second operand) +10 % in the probe.  The encoder's
+    # and decoder's final LayerNorm outputs (handed to callers / the LM head) and the convolution stem keep dense rows.
+    row_pad = 64
+    # ... and of the residual stream the out-proj / fc2 epilogues read and write (fp32 for the student: 5 120-byte rows, four channels
+    # per 32-row slab of a wave; 128 bytes = 32 floats / 64 bf16 of pad)
+    stream_row_pad = 128
+
+    def act(self, rows, cols, dtype=None, zero_pad=True, pad=0):
         """Activation buffer with rows padded to a multiple of 64 and the pad rows zeroed: the weight-gradient GEMMs
         contract over the token dimension in K-steps of 64 and must see zeros there.  zero_pad=False (forward-only
         passes: nothing contracts over the rows) leaves the pad rows as they are -- a decoder pass of the frozen
-        teacher was ~350 five-microsecond fill launches otherwise."""
+        teacher was ~350 five-microsecond fill launches otherwise.  pad > 0: a [rows, cols] view of a buffer whose rows
+        are cols + pad elements apart (see ffn_row_pad)."""
         dtype = self.lowp if dtype is None else dtype
         rp = _rup(rows, 64)
-        t = self.ops.empty((rp, cols), dtype)
+        t = self.ops.empty((rp, cols + pad), dtype)
+        if pad:
+            t = t[:, :cols]
         if rp > rows and zero_pad:
             t[rows:].zero_()
         return t
@@ -282,8 +300,8 @@ class WhisperEngine:
         Rg = _rup(R, 320)
         return Rg if Rg - R <= R * self.pad_gemm_rows_slack else R
 
-    def _ln(self, name, x, R, save, rows_alloc=None, zero_pad=None):
-        y = self.act(R if rows_alloc is None else rows_alloc, x.shape[1], zero_pad=save if zero_pad is None else zero_pad)
+    def _ln(self, name, x, R, save, rows_alloc=None, zero_pad=None, pad=0):
+        y = self.act(R if rows_alloc is None else rows_alloc, x.shape[1], zero_pad=save if zero_pad is None else zero_pad, pad=pad)
         _, mu, rs = self.ops.layernorm_fwd(x[:R] if x.shape[0] != R else x, self.st.p[f"{name}.weight"],
                                            self.st.p[f"{name}.bias"], 1e-5, save_stats=save, out=y[:R])
         return y, mu, rs
@@ -296,7 +314,7 @@ class WhisperEngine:
             dg, db = self.st.g[f"{name}.weight"], self.st.g[f"{name}.bias"]
         else:
             dg, db = self._scratch_vec(x.shape[1]), self._scratch_vec(x.shape[1], 1)
-        nxt = self.act(R, x.shape[1]) if emit else None
+        nxt = self.act(R, x.shape[1], pad=self.row_pad) if emit else None
         dres = self.ops.layernorm_bwd(dy[:R], x[:R] if x.shape[0] != R else x, mu, rs, self.st.p[f"{name}.weight"],
                                       dres, dg, db, out_lowp=nxt[:R] if emit else None,
                                       colsum=colsum_to if emit else None)
@@ -432,7 +450,7 @@ class WhisperEngine:
 
         def attend(q_src, k, v, Lkv, is_causal, cols):
             """q_src [>= R, cols] with the queries in its first D columns -> o [Rg, D]"""
-            o = self.act(Rg, D, zero_pad=save)
+            o = self.act(Rg, D, zero_pad=save, pad=self.row_pad)
             if live is None:
                 _, lse = ops.attn_fwd(q_src[:R, :D], k, v, B, H, L, Lkv, is_causal, 0.125, out=o[:R])
                 return o, lse
@@ -448,14 +466,15 @@ class WhisperEngine:
             return o, None
         # --- self attention
         av = st.attn_views(f"{p}.self_attn")
-        h, mu, rs = self._ln(f"{p}.self_attn_layer_norm", x, R, save, Rg)
-        qkv = self.act(Rg, 3 * D, zero_pad=save)
+        h, mu, rs = self._ln(f"{p}.self_attn_layer_norm", x, R, save, Rg, pad=self.row_pad)
+        qkv = self.act(Rg, 3 * D, zero_pad=save, pad=self.row_pad)
         ops.gemm(h[:Rg], av["wqkv"], bias=av["bqkv"], out=qkv[:Rg])
         if live is None:
             o, lse = attend(qkv, qkv[:R, D:2 * D], qkv[:R, 2 * D:], L, causal, 3 * D)
         else:
             o, lse = attend(qkv, None, None, L, causal, 3 * D)
-        x1 = ops.gemm(o[:Rg], av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream)
+        xp = self.stream_row_pad // (4 if self.stream == torch.float32 else 2)
+        x1 = ops.gemm(o[:Rg], av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream, out_row_pad=xp)
         if save:
             lc.update(x0=x, mu0=mu, rs0=rs, h0=h, qkv=qkv, o0=o, lse0=lse)
         x = x1
@@ -463,24 +482,25 @@ class WhisperEngine:
         if enc_out is not None:
             cv = st.attn_views(f"{p}.encoder_attn")
             Re = B * Lk
-            h, mu, rs = self._ln(f"{p}.encoder_attn_layer_norm", x, R, save, Rg)
-            q = self.act(Rg, D, zero_pad=save)
+            h, mu, rs = self._ln(f"{p}.encoder_attn_layer_norm", x, R, save, Rg, pad=self.row_pad)
+            q = self.act(Rg, D, zero_pad=save, pad=self.row_pad)
             ops.gemm(h[:Rg], cv["wqkv"][:D], bias=cv["bqkv"][:D], out=q[:Rg])
-            kv = self.act(Re, 2 * D, zero_pad=save)
+            kv = self.act(Re, 2 * D, zero_pad=save, pad=self.row_pad)
             ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=kv[:Re])
             o, lse = attend(q, kv[:Re, :D], kv[:Re, D:], Lk, False, D)
-            x1 = ops.gemm(o[:Rg], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream)
+            x1 = ops.gemm(o[:Rg], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream, out_row_pad=xp)
             if save:
                 lc.update(x1=x, mu1=mu, rs1=rs, h1=h, q1=q, kv1=kv, o1=o, lse1=lse)
             x = x1
         # --- feed forward
-        h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save, Rg)
-        a = self.act(Rg, d.ffn, zero_pad=save)
+        h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save, Rg, pad=self.row_pad)
+        a = self.act(Rg, d.ffn, zero_pad=save, pad=self.ffn_row_pad)
         res = ops.gemm(h[:Rg], st.s[f"{p}.fc1.weight"], bias=st.p[f"{p}.fc1.bias"], act=1,
-                       want_z=("grad" if self.ffn_keeps_gelu_grad else True) if save else False, out=a[:Rg])
+                       want_z=("grad" if self.ffn_keeps_gelu_grad else True) if save else False, out=a[:Rg],
+                       z_row_pad=self.ffn_row_pad)
         z = res[1] if save else None
         x2 = ops.gemm(a[:Rg], st.s[f"{p}.fc2.weight"], bias=st.p[f"{p}.fc2.bias"], residual=x, round_res=True,
-                      out_dtype=self.stream)
+                      out_dtype=self.stream, out_row_pad=xp)
         if save:
             lc.update(x2=x, mu2=mu, rs2=rs, h2=h, a=a, z=z)
         return x2, lc
@@ -735,7 +755,7 @@ class WhisperEngine:
         tr = st.is_trainable(f"{p}.fc1.weight")
         cross = "x1" in lc
         # --- feed forward
-        dz = self.act(R, d.ffn)
+        dz = self.act(R, d.ffn, pad=self.ffn_row_pad)
         # (fc1.bias gradient = column sums of dz: accumulated by this GEMM's epilogue, no separate pass over dz)
         fuse_cs = tr and self.fuse_fc1_bias_grad and R > 64
         ops.gemm(dy[:R], st.s[f"{p}.fc2.weight"], trans_b=True, zgrad=lc["z"], out=dz[:R],
@@ -753,8 +773,8 @@ class WhisperEngine:
             cv = st.attn_views(f"{p}.encoder_attn")
             Re = B * Lk
             do = ops.gemm(dy[:R], cv["wo"], trans_b=True)
-            dq = self.act(R, D)
-            dkv = self.act(Re, 2 * D)
+            dq = self.act(R, D, pad=self.row_pad)
+            dkv = self.act(Re, 2 * D, pad=self.row_pad)
             fb = tr and self.fuse_attn_bias_grad      # q / v bias gradients from the attention-backward kernels
             ops.attn_bwd(lc["q1"][:R], lc["kv1"][:Re, :D], lc["kv1"][:Re, D:], lc["o1"][:R], do, lc["lse1"], B, H, L,
                          Lk, False, 0.125, dq=dq[:R], dk=dkv[:Re, :D], dv=dkv[:Re, D:],
@@ -773,7 +793,7 @@ class WhisperEngine:
         # --- self attention
         av = st.attn_views(f"{p}.self_attn")
         do = ops.gemm(dy[:R], av["wo"], trans_b=True)
-        dqkv = self.act(R, 3 * D)
+        dqkv = self.act(R, 3 * D, pad=self.row_pad)
         qkv = lc["qkv"]
         fb = tr and self.fuse_attn_bias_grad
         ops.attn_bwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], lc["o0"][:R], do, lc["lse0"], B, H, L, L, causal,

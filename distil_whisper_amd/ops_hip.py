@@ -58,6 +58,10 @@ _SIGS = {
                           C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_layernorm_bwd": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_layernorm_fwd_ld": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                             C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_void_p], C.c_int),
+    "dw_layernorm_bwd_ld": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_int64] * 4 + [C.c_void_p], C.c_int),
     "dw_attn_fwd": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_fwd_ex": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 6 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_bwd": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
@@ -207,7 +211,7 @@ class HipOps:
 
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
              r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
-             kv_append=None, colsum=None):
+             kv_append=None, colsum=None, z_row_pad=0, out_row_pad=0):
         """C = op(a) @ op(b) with the fused epilogue of dw_gemm_bf16.  a: [M,K] (or [K,M] if trans_a);
         b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1.
         atomic_acc: out (fp32) += result via float atomics, with the K range split over several workgroups when the
@@ -227,7 +231,9 @@ class HipOps:
             N, Kb = b.shape
         assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
         if out is None:
-            out = self.empty((M, N), self.lowp if out_dtype is None else out_dtype)
+            out = self.empty((M, N + out_row_pad), self.lowp if out_dtype is None else out_dtype)
+            if out_row_pad:                     # (row pitch of an output this call allocates: engine.row_pad)
+                out = out[:, :N]
         assert out.shape == (M, N) and out.stride(1) == 1
         g = DwGemm()
         g.a, g.b, g.c = a.data_ptr(), b.data_ptr(), out.data_ptr()
@@ -285,7 +291,9 @@ class HipOps:
             # want_z="grad": the epilogue stores gelu'(z) as fp16 (what the backward multiplies by) instead of z as bf16
             as_grad = want_z == "grad"
             assert not as_grad or act == 1
-            z = self.empty((M, N), torch.float16 if as_grad else torch.bfloat16)
+            z = self.empty((M, N + z_row_pad), torch.float16 if as_grad else torch.bfloat16)
+            if z_row_pad:                       # (row pitch of the stored by-product: engine.ffn_row_pad)
+                z = z[:, :N]
             g.z_out, g.ldz, g.z_is_gelu_grad = z.data_ptr(), z.stride(0), int(as_grad)
         if zgrad is not None:
             assert zgrad.dtype in (torch.bfloat16, torch.float16) and zgrad.shape == (M, N) and zgrad.stride(1) == 1
@@ -323,31 +331,35 @@ class HipOps:
         self._t1(e0, "decode_step", 0.0)
 
     def layernorm_fwd(self, x, gamma, beta, eps=1e-5, save_stats=True, out=None):
+        """x, out: 2-D with unit column stride; their row pitches may exceed the row length (padded activation buffers)."""
         rows, cols = x.shape
-        assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+        assert x.stride(1) == 1 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
         y = self.empty((rows, cols), torch.bfloat16) if out is None else out
-        assert y.is_contiguous() and y.shape == (rows, cols) and y.dtype == torch.bfloat16
+        assert y.stride(1) == 1 and y.shape == (rows, cols) and y.dtype == torch.bfloat16
         mean = self.empty((rows,), torch.float32) if save_stats else None
         rstd = self.empty((rows,), torch.float32) if save_stats else None
-        self._chk(self.lib.dw_layernorm_fwd(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols,
-                                            float(eps), self._stream()), "layernorm_fwd")
+        self._chk(self.lib.dw_layernorm_fwd_ld(_p(x), _dt(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, cols,
+                                               float(eps), x.stride(0), y.stride(0), self._stream()), "layernorm_fwd")
         return y, mean, rstd
 
     def layernorm_bwd(self, dy, x, mean, rstd, gamma, dres, dgamma, dbeta, out_lowp=None, colsum=None):
         """dres (f32 [rows,cols]) += LN'(dy) if dres is given, else a new tensor is returned.  dgamma/dbeta += ...
-        out_lowp (bf16 [rows,cols]) receives bf16(dres) and colsum (f32 [cols]) += its column sums (fused)."""
+        out_lowp (bf16 [rows,cols]) receives bf16(dres) and colsum (f32 [cols]) += its column sums (fused).
+        Every 2-D argument may have a row pitch larger than cols (unit column stride)."""
         rows, cols = x.shape
-        assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
+        assert dy.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape == (rows, cols)
         acc = dres is not None
         if dres is None:
             dres = self.empty((rows, cols), torch.float32)
-        assert dres.dtype == torch.float32 and dres.is_contiguous()
+        assert dres.dtype == torch.float32 and dres.stride(1) == 1 and dres.shape == (rows, cols)
+        ldl = cols
         if out_lowp is not None:
-            assert out_lowp.dtype == torch.bfloat16 and out_lowp.is_contiguous() and out_lowp.shape == (rows, cols)
+            assert out_lowp.dtype == torch.bfloat16 and out_lowp.stride(1) == 1 and out_lowp.shape == (rows, cols)
+            ldl = out_lowp.stride(0)
         assert colsum is None or out_lowp is not None
-        self._chk(self.lib.dw_layernorm_bwd(_p(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(dres), int(acc),
-                                            _p(dgamma), _p(dbeta), _p(out_lowp), _p(colsum), rows, cols,
-                                            self._stream()), "layernorm_bwd")
+        self._chk(self.lib.dw_layernorm_bwd_ld(_p(dy), _p(x), _dt(x), _p(mean), _p(rstd), _p(gamma), _p(dres), int(acc),
+                                               _p(dgamma), _p(dbeta), _p(out_lowp), _p(colsum), rows, cols,
+                                               dy.stride(0), x.stride(0), dres.stride(0), ldl, self._stream()), "layernorm_bwd")
         return dres
 
     def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None, kv_batch_rows=None):

@@ -113,6 +113,15 @@ int dw_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float
 int dw_layernorm_bwd(const void* dy_bf16, const void* x, int x_dtype, const float* mean, const float* rstd,
                      const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, void* dres_lowp,
                      float* dres_colsum, int rows, int cols, void* stream);
+/* The same two with row pitches in elements (>= cols, multiples of 4; 8 for bf16 x): activation buffers whose rows are padded
+ * by 128 bytes so that the 128-byte pieces a GEMM tile reads from 256-320 consecutive rows do not fall on two of an XCD's sixteen
+ * L2 channels (rows 2 560 / 10 240 bytes apart do; engine.row_pad, tools/gemm_stride_probe.py). */
+int dw_layernorm_fwd_ld(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int rows, int cols, float eps, int64_t ldx, int64_t ldy, void* stream);
+int dw_layernorm_bwd_ld(const void* dy_bf16, const void* x, int x_dtype, const float* mean, const float* rstd,
+                        const float* gamma, float* dres, int accumulate, float* dgamma, float* dbeta, void* dres_lowp,
+                        float* dres_colsum, int rows, int cols, int64_t lddy, int64_t ldx, int64_t lddres,
+                        int64_t ldlowp, void* stream);
 
 /* ---- attention core (TF:modeling_whisper.py:215-238 / integrations/sdpa_attention.py), head_dim 64 --------------
  * q [B*Lq rows], k,v [B*Lk rows]: bf16, head h of a row at element offset h*64, row strides ldq/ldk/ldv/ldo

@@ -62,7 +62,8 @@ class RefOps:
     # nn.Linear under bf16 autocast: bf16 operands, fp32 accumulation (TF:modeling_whisper.py:279-282 etc.)
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
              r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
-             kv_append=None, colsum=None):
+             kv_append=None, colsum=None, z_row_pad=0, out_row_pad=0):
+        # (z_row_pad / out_row_pad: memory layout of the HIP path's buffers, nothing to restate here)
         out_dtype = self.lowp if out_dtype is None else out_dtype
         if ln is not None:                     # operand = bf16(LayerNorm(a)) (decode-step fusion of the HIP kernel)
             a = self.layernorm_fwd(a, ln[0], ln[1], ln[2] if len(ln) > 2 else 1e-5, save_stats=False)[0]

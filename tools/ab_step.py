@@ -52,6 +52,9 @@ for r in range(4):
         type(tr.student).fuse_fc1_bias_grad = bool(c[13]) if len(c) > 13 else True   # fc1.bias gradient in the dX-fc2 GEMM epilogue
         type(tr.student).fuse_attn_bias_grad = bool(c[14]) if len(c) > 14 else False  # q / v bias gradients in the attention backward
         ops.lib.dw_debug_set(20, c[15] if len(c) > 15 else 36)             # v_mfma_f32_16x16x32_bf16 main loops (bit mask NN / NT / TT)
+        type(tr.student).ffn_row_pad = type(tr.teacher).ffn_row_pad = c[16] if len(c) > 16 else 64   # row pitch pad of the FFN-wide buffers
+        type(tr.student).row_pad = type(tr.teacher).row_pad = c[17] if len(c) > 17 else 64
+        type(tr.student).stream_row_pad = type(tr.teacher).stream_row_pad = c[18] if len(c) > 18 else 128
         tr.set_overlap_wgrad(bool(c[7]) if len(c) > 7 else False)          # weight-gradient GEMMs on a second stream
         tr.overlap_teacher = bool(c[8]) if len(c) > 8 else False           # teacher forward on a second stream
         tr.teacher.pad_gemm_rows = bool(c[9]) if len(c) > 9 else False     # teacher decoder GEMMs over M padded to 320 rows
