@@ -278,6 +278,8 @@ class WhisperEngine:
     # ... and of the residual stream the out-proj / fc2 epilogues read and write (fp32 for the student: 5 120-byte rows, four channels
     # per 32-row slab of a wave; 128 bytes = 32 floats / 64 bf16 of pad)
     stream_row_pad = 128
+    # ... and of the dX outputs the backward hands to LayerNorm / attention (dh, dO)
+    dx_row_pad = 64
 
     def act(self, rows, cols, dtype=None, zero_pad=True, pad=0):
         """Activation buffer with rows padded to a multiple of 64 and the pad rows zeroed: the weight-gradient GEMMs
@@ -763,7 +765,7 @@ class WhisperEngine:
         if tr:
             self._wgrad(dy, lc["a"], st.g[f"{p}.fc2.weight"], None, R)
             self._wgrad(dz, lc["h2"], st.g[f"{p}.fc1.weight"], None if fuse_cs else st.g[f"{p}.fc1.bias"], R)
-        dh = ops.gemm(dz[:R], st.s[f"{p}.fc1.weight"], trans_b=True)
+        dh = ops.gemm(dz[:R], st.s[f"{p}.fc1.weight"], trans_b=True, out_row_pad=self.dx_row_pad)
         nb = f"{p}.encoder_attn.out_proj.bias" if cross else f"{p}.self_attn.out_proj.bias"
         dres, dy = self._ln_bwd(f"{p}.final_layer_norm", dh, lc["x2"], lc["mu2"], lc["rs2"], dres, R, emit=True,
                                 colsum_to=self._bias_grad(nb))
@@ -772,7 +774,7 @@ class WhisperEngine:
         if cross:
             cv = st.attn_views(f"{p}.encoder_attn")
             Re = B * Lk
-            do = ops.gemm(dy[:R], cv["wo"], trans_b=True)
+            do = ops.gemm(dy[:R], cv["wo"], trans_b=True, out_row_pad=self.dx_row_pad)
             dq = self.act(R, D, pad=self.row_pad)
             dkv = self.act(Re, 2 * D, pad=self.row_pad)
             fb = tr and self.fuse_attn_bias_grad      # q / v bias gradients from the attention-backward kernels
@@ -786,13 +788,13 @@ class WhisperEngine:
             if denc is not None:
                 ops.gemm(dkv[:Re], cv["wqkv"][D:], trans_b=True, residual=denc, round_res=True,
                          out_dtype=torch.float32, out=denc)
-            dh = ops.gemm(dq[:R], cv["wqkv"][:D], trans_b=True)
+            dh = ops.gemm(dq[:R], cv["wqkv"][:D], trans_b=True, out_row_pad=self.dx_row_pad)
             dres, dy = self._ln_bwd(f"{p}.encoder_attn_layer_norm", dh, lc["x1"], lc["mu1"], lc["rs1"], dres, R,
                                     emit=True, colsum_to=self._bias_grad(f"{p}.self_attn.out_proj.bias"))
             del do, dq, dkv, dh
         # --- self attention
         av = st.attn_views(f"{p}.self_attn")
-        do = ops.gemm(dy[:R], av["wo"], trans_b=True)
+        do = ops.gemm(dy[:R], av["wo"], trans_b=True, out_row_pad=self.dx_row_pad)
         dqkv = self.act(R, 3 * D, pad=self.row_pad)
         qkv = lc["qkv"]
         fb = tr and self.fuse_attn_bias_grad
@@ -802,7 +804,7 @@ class WhisperEngine:
         if tr:
             self._wgrad(dy, lc["o0"], av["g_wo"], None, R)
             self._wgrad(dqkv, lc["h0"], av["g_wqkv"], None if fb else av["g_bqkv"], R, bias_cols=[(0, D), (2 * D, 3 * D)])
-        dh = ops.gemm(dqkv[:R], av["wqkv"], trans_b=True)
+        dh = ops.gemm(dqkv[:R], av["wqkv"], trans_b=True, out_row_pad=self.dx_row_pad)
         return self._ln_bwd(f"{p}.self_attn_layer_norm", dh, lc["x0"], lc["mu0"], lc["rs0"], dres, R, emit=emit_last,
                             colsum_to=colsum_last)
 

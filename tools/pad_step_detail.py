@@ -25,6 +25,7 @@ for pad in pads + pads:
     type(tr.student).ffn_row_pad = type(tr.teacher).ffn_row_pad = pad[0]
     type(tr.student).row_pad = type(tr.teacher).row_pad = pad[1]
     type(tr.student).stream_row_pad = type(tr.teacher).stream_row_pad = pad[2] if len(pad) > 2 else 0
+    type(tr.student).dx_row_pad = type(tr.teacher).dx_row_pad = pad[3] if len(pad) > 3 else 0
     step(); step(); torch.cuda.synchronize()
     ops.profile, ops.profile_detail = {}, True
     step(); torch.cuda.synchronize()
