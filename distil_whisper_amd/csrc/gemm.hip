@@ -157,6 +157,36 @@ extern "C" int dw_reduce_slices(const float* part, int64_t stride, int slices, f
     return DW_OK;
 }
 
+// The same for slabs whose rows are ld_part elements apart (rows padded against L2-channel camping: a [1280 x 5120] fp32 slab has
+// 20 480-byte rows, and the 1 KiB row pieces of a 256-column tile then all land on the same four channels); out rows ld_out apart.
+__global__ __launch_bounds__(256) void reduce_slices_ld_kernel(const float* part, long slice_stride, long ld_part, int slices,
+                                                               float* out, long ld_out, int rows, int cols4, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * cols4) return;
+    const int r = (int)(i / cols4), c = (int)(i - (long)r * cols4) * 4;
+    float* o = out + (long)r * ld_out + c;
+    f32x4 acc = accumulate ? *(const f32x4*)o : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* src = part + (long)r * ld_part + c;
+    for (int s = 0; s < slices; ++s) {
+        const f32x4 v = *(const f32x4*)(src + s * slice_stride);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    *(f32x4*)o = acc;
+}
+extern "C" int dw_reduce_slices_ld(const float* part, int64_t slice_stride, int64_t ld_part, int slices, float* out, int64_t ld_out,
+                                   int rows, int cols, int accumulate, void* stream) {
+    DW_CLEAR_ERR();
+    if (!part || !out || slices < 1 || rows <= 0 || cols <= 0 || (cols & 3) || (ld_part & 3) || (ld_out & 3) || (slice_stride & 3) ||
+        ld_part < cols || ld_out < cols || ((uintptr_t)part & 15) || ((uintptr_t)out & 15))
+        return DW_EINVAL;
+    const long n = (long)rows * (cols / 4);
+    hipLaunchKernelGGL(reduce_slices_ld_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, (long)slice_stride,
+                       (long)ld_part, slices, out, (long)ld_out, rows, cols / 4, accumulate);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
 static inline bool q_split_ok(const GemmP& p) { return p.split_k == 1 && !p.atomic; }
 extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     DW_CLEAR_ERR();

@@ -58,6 +58,7 @@ _SIGS = {
                           C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_layernorm_bwd": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p], C.c_int),
+    "dw_reduce_slices_ld": ([C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
     "dw_layernorm_fwd_ld": ([C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                              C.c_int, C.c_float, C.c_int64, C.c_int64, C.c_void_p], C.c_int),
     "dw_layernorm_bwd_ld": ([C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -186,6 +187,8 @@ class HipOps:
         t256 = ((M + 255) // 256) * ((N + 255) // 256)
         return 256 if t256 >= 512 else 128
 
+    wgrad_slab_pad = 0      # floats of row pad of the split-K partial slabs of the weight-gradient GEMMs (32 measured neutral: the slab stores are not what those launches wait for)
+
     def empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
@@ -266,10 +269,13 @@ class HipOps:
                     if eff > best + 1e-9:
                         best, sk = eff, cand
             sk = max(1, min(sk, nt // 16))
-            if sk > 1 and out.is_contiguous() and (M * N) % 4 == 0:
-                ws = self.empty((sk, M, N), torch.float32)
-                g.c, g.ldc = ws.data_ptr(), N
-                g.split_k, g.slice_stride = sk, M * N
+            if sk > 1 and out.stride(1) == 1 and N % 4 == 0 and out.stride(0) % 4 == 0:
+                # (optional row pad of the slabs, self.wgrad_slab_pad floats: [M x 5120] fp32 slabs have 20 480-byte rows and the
+                # 1 KiB pieces a 256-column tile stores into 256 consecutive rows all land on the same four L2 channels -- measured neutral)
+                ldw = N + self.wgrad_slab_pad
+                ws = self.empty((sk, M, ldw), torch.float32)
+                g.c, g.ldc = ws.data_ptr(), ldw
+                g.split_k, g.slice_stride = sk, M * ldw
             else:
                 g.atomic_acc, g.split_k = 1, 1
         if ln is not None:
@@ -311,8 +317,8 @@ class HipOps:
         e0 = self._t0()
         self._chk(self.lib.dw_gemm_bf16(C.byref(g), self._stream()), f"gemm m={M} n={N} k={K} ta={trans_a} tb={trans_b}")
         if ws is not None:
-            self._chk(self.lib.dw_reduce_slices(ws.data_ptr(), M * N, g.split_k, out.data_ptr(), M * N, 1,
-                                                self._stream()), "reduce_slices")
+            self._chk(self.lib.dw_reduce_slices_ld(ws.data_ptr(), g.slice_stride, g.ldc, g.split_k, out.data_ptr(), out.stride(0),
+                                                   M, N, 1, self._stream()), "reduce_slices")
         key = f"gemm_t{tile_key}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}"
         if self.profile_detail:
             key += (f" m{M} n{N} k{K} c{'f32' if out.dtype == torch.float32 else 'bf16'}"

@@ -101,6 +101,9 @@ typedef struct DwGemm {
 int dw_gemm_bf16(const DwGemm* g, void* stream);
 /* out[i] (+)= sum over slices of part[s*stride + i]; n, stride multiples of 4 (split-K combination, deterministic). */
 int dw_reduce_slices(const float* part, int64_t stride, int slices, float* out, int64_t n, int accumulate, void* stream);
+/* The same over [rows][cols] matrices whose rows are ld_part (slabs, slice_stride elements apart) / ld_out elements apart. */
+int dw_reduce_slices_ld(const float* part, int64_t slice_stride, int64_t ld_part, int slices, float* out, int64_t ld_out,
+                        int rows, int cols, int accumulate, void* stream);
 
 /* ---- LayerNorm (TF:modeling_whisper.py:371,377,434,443,446,573,682), eps 1e-5, statistics in f32 ---------------
  * x [rows][cols] f32 or bf16 (x_dtype), y bf16 [rows][cols]; mean/rstd f32 [rows] (may be NULL for inference). */

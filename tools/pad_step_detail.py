@@ -26,6 +26,7 @@ for pad in pads + pads:
     type(tr.student).row_pad = type(tr.teacher).row_pad = pad[1]
     type(tr.student).stream_row_pad = type(tr.teacher).stream_row_pad = pad[2] if len(pad) > 2 else 0
     type(tr.student).dx_row_pad = type(tr.teacher).dx_row_pad = pad[3] if len(pad) > 3 else 0
+    ops.wgrad_slab_pad = pad[4] if len(pad) > 4 else 0
     step(); step(); torch.cuda.synchronize()
     ops.profile, ops.profile_detail = {}, True
     step(); torch.cuda.synchronize()
