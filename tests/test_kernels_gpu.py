@@ -432,6 +432,40 @@ def test_layernorm(ops, ref, D, x_dtype):
     assert relerr(o3, r3) < 1e-5 and relerr(lo, rlo) < 3e-3 and relerr(cs, rcs) < 1e-3
 
 
+@pytest.mark.parametrize("D,x_dtype,rows", [(1280, torch.float32, 9000), (1280, torch.bfloat16, 517), (384, torch.float32, 517)])
+def test_layernorm_with_padded_row_pitches_is_bit_identical(ops, D, x_dtype, rows):
+    """dw_layernorm_fwd_ld / _bwd_ld: every 2-D argument as a [rows, D] view of a buffer whose rows are D + pad elements apart
+    (the engine's activation buffers, padded by 128 bytes per row) -- same values as with dense rows, bit for bit, and the pad
+    columns untouched.  (rows = 9000 takes the persistent forward / prefetching backward kernels of the encoder shape.)"""
+    def padded(t, pad, fill):
+        buf = torch.full((t.shape[0], t.shape[1] + pad), fill, device="cuda", dtype=t.dtype)
+        buf[:, :t.shape[1]] = t
+        return buf, buf[:, :t.shape[1]]
+    x = rnd((rows, D), 2.0, x_dtype, seed=30) + 0.5
+    gamma, beta = rnd((D,), 1.0, torch.float32, seed=31), rnd((D,), 1.0, torch.float32, seed=32)
+    y, mu, rs = ops.layernorm_fwd(x, gamma, beta)
+    xb, xp = padded(x, 32 if x_dtype == torch.float32 else 64, 7.0)
+    yb, yp = padded(torch.zeros_like(y), 64, 3.0)
+    y2, mu2, rs2 = ops.layernorm_fwd(xp, gamma, beta, out=yp)
+    assert torch.equal(y2, y) and torch.equal(mu2, mu) and torch.equal(rs2, rs)
+    assert bool((yb[:, D:] == 3.0).all())
+    dy = rnd((rows, D), 1.0, seed=33)
+    dres = rnd((rows, D), 1.0, torch.float32, seed=34)
+    lo = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
+    dg, db, cs = (torch.zeros(D, device="cuda") for _ in range(3))
+    out = ops.layernorm_bwd(dy, x, mu, rs, gamma, dres.clone(), dg, db, out_lowp=lo, colsum=cs)
+    dyb, dyp = padded(dy, 64, 5.0)
+    drb, drp = padded(dres, 32, 9.0)
+    lob, lop = padded(torch.zeros_like(lo), 64, 2.0)
+    dg2, db2, cs2 = (torch.zeros(D, device="cuda") for _ in range(3))
+    out2 = ops.layernorm_bwd(dyp, xp, mu, rs, gamma, drp, dg2, db2, out_lowp=lop, colsum=cs2)
+    assert out2.data_ptr() == drp.data_ptr()
+    assert torch.equal(out2, out) and torch.equal(lop, lo)
+    assert bool((drb[:, D:] == 9.0).all()) and bool((lob[:, D:] == 2.0).all())
+    # (dgamma / dbeta / column sums are atomic sums over the same per-workgroup partials: equal up to the order of the atomics)
+    assert relerr(dg2, dg) < 1e-5 and relerr(db2, db) < 1e-5 and relerr(cs2, cs) < 1e-5
+
+
 ATTN_CASES = [
     (2, 3, 1500, 1500, False),   # encoder self
     (2, 3, 447, 447, True),      # decoder self (causal)
