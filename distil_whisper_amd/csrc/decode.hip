@@ -511,6 +511,8 @@ extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
         return DW_EINVAL;
     if (d->stream_dtype != DW_F32 && d->stream_dtype != DW_BF16) return DW_EINVAL;
     const int rows = B * n;
+    const long ldx = d->cross_kv_ld > 0 ? d->cross_kv_ld : 2L * D;        // row pitch of the cross-attention K | V
+    if (ldx < 2L * D || (ldx & 7)) return DW_EINVAL;
     const size_t es = d->stream_dtype == DW_F32 ? 4 : 2;
     int rc = dw_embed_fwd(d->ids, d->tok_emb, (const char*)d->pos_emb + (size_t)t * D * es, d->stream_dtype, d->x,
                           d->stream_dtype, B, n, D, stream);
@@ -580,7 +582,7 @@ extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
             DecAttnP q = {};
             q.x = d->x; q.ldx = D; q.ln_g = L.ln2_g; q.ln_b = L.ln2_b; q.eps = 1e-5f;
             q.w = (const bf16*)L.wq; q.bias = L.bq;
-            q.k = (const bf16*)L.cross_kv; q.v = q.k + D; q.ldkv = 2 * D; q.kv_rows = d->src_len;
+            q.k = (const bf16*)L.cross_kv; q.v = q.k + D; q.ldkv = ldx; q.kv_rows = d->src_len;
             q.o = (bf16*)d->o; q.ldo = D; q.D = D; q.Lk = d->src_len; q.t = 0; q.scale = 0.125f;
             if ((rc = launch_decode_proj(0, d->stream_dtype, q, B, H, (hipStream_t)stream)) != DW_OK) return rc;
         } else {
@@ -592,7 +594,7 @@ extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
         }
         if (rc != DW_OK) return rc;
         const bf16* kx = (const bf16*)L.cross_kv;
-        if ((rc = dw_attn_fwd_ex(d->qkv, kx, kx + D, d->o, nullptr, B, H, n, d->src_len, 3 * D, 2 * D, 2 * D, D, n,
+        if ((rc = dw_attn_fwd_ex(d->qkv, kx, kx + D, d->o, nullptr, B, H, n, d->src_len, 3 * D, ldx, ldx, D, n,
                                  d->src_len, 0, 0.125f, stream)) != DW_OK) return rc;
         }
         if ((rc = gemm(d->o, D, L.wo2, L.bo2, D, D, d->x, D, d->stream_dtype, 0, d->x, nullptr, nullptr, nullptr)) != DW_OK)

@@ -586,7 +586,8 @@ class WhisperEngine:
         cache["t"] = 0
         for i in range(d.dec_layers):
             cv = st.attn_views(f"model.decoder.layers.{i}.encoder_attn")
-            cache["cross"][i] = ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=cache["cross"][i])
+            cache["cross"][i] = ops.gemm(enc_out[:Re], cv["wqkv"][D:], bias=cv["bqkv"][D:], out=cache["cross"][i],
+                                         out_row_pad=self.kv_row_pad)
         return cache
 
     # ---- single-call decoder pass (C entry dw_decode_step) ---------------------------------------------------------
@@ -599,6 +600,9 @@ class WhisperEngine:
     # the two column-sum launches per layer they replace (profiles/r3_gemm_epilogue.md section 5)
     fuse_attn_bias_grad = False
     use_c_decode = True     # HIP path: one library call per decoder pass instead of ~30 per-kernel calls
+    # rows of the static cross-attention K | V padded by 128 bytes: a head's 128-byte pieces of consecutive 5 120-byte rows fall on
+    # four of an XCD's sixteen L2 channels (tools/decode_stride_probe.py: 29.8 -> 26.4 us per layer at batch 16)
+    kv_row_pad = 64
 
     def _decode_desc(self, cache, n):
         """DwDecodeStep for `n` new positions per row over `cache` (built once per (cache, n): weights, caches and the
@@ -637,6 +641,8 @@ class WhisperEngine:
         desc.batch, desc.n_new, desc.d_model, desc.heads, desc.ffn, desc.n_layers = B, n, D, d.heads, F, d.dec_layers
         desc.src_len, desc.max_len, desc.vocab, desc.ldv = d.max_src, cache["max_len"], d.vocab, self.ldv
         desc.stream_dtype = DW_F32 if f32 else DW_BF16
+        desc.cross_kv_ld = cache["cross"][0].stride(0)
+        assert all(c.stride(0) == desc.cross_kv_ld for c in cache["cross"])
         desc.tok_emb = tab["model.decoder.embed_tokens.weight"].data_ptr()
         desc.pos_emb = tab["model.decoder.embed_positions.weight"].data_ptr()
         desc.lnf_g, desc.lnf_b = st.p["model.decoder.layer_norm.weight"].data_ptr(), st.p["model.decoder.layer_norm.bias"].data_ptr()

@@ -44,7 +44,7 @@ class DwDecoderLayer(C.Structure):
 class DwDecodeStep(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "n_new", "d_model", "heads", "ffn", "n_layers", "src_len", "max_len", "t", "vocab", "ldv",
-        "stream_dtype")] + [(n, C.c_void_p) for n in (
+        "stream_dtype", "cross_kv_ld")] + [(n, C.c_void_p) for n in (
             "ids", "tok_emb", "pos_emb", "lnf_g", "lnf_b", "lm_head", "layers", "x", "h", "qkv", "o", "a", "logits")]
 
 
