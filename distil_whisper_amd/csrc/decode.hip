@@ -548,7 +548,7 @@ extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
         const DwDecoderLayer& L = d->layers[l];
         if (!L.wqkv || !L.wo || !L.wq || !L.wo2 || !L.w1 || !L.w2 || !L.self_kv || !L.cross_kv) return DW_EINVAL;
         // ---- self-attention over the cached prefix ----
-        if (proj_self) {
+        if (proj_self && L.bqkv && L.ln1_g && L.ln1_b) {
             DecAttnP q = {};
             q.x = d->x; q.ldx = D; q.ln_g = L.ln1_g; q.ln_b = L.ln1_b; q.eps = 1e-5f;
             q.w = (const bf16*)L.wqkv; q.bias = L.bqkv;
@@ -578,7 +578,7 @@ extern "C" int dw_decode_step(const DwDecodeStep* d, void* stream) {
         if ((rc = gemm(d->o, D, L.wo, L.bo, D, D, d->x, D, d->stream_dtype, 0, d->x, nullptr, nullptr, nullptr)) != DW_OK)
             return rc;
         // ---- cross-attention over the static encoder K/V ----
-        if (proj_cross) {
+        if (proj_cross && L.bq && L.ln2_g && L.ln2_b) {
             DecAttnP q = {};
             q.x = d->x; q.ldx = D; q.ln_g = L.ln2_g; q.ln_b = L.ln2_b; q.eps = 1e-5f;
             q.w = (const bf16*)L.wq; q.bias = L.bq;
