@@ -692,8 +692,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
     };
     if constexpr (CAUSAL) tiles(std::integral_constant<int, 2>{}, qt0, nqt);
     else {
-        // a wave whose 32 keys are not all valid masks every tile; the others only the last, partial query tile
-        const int nfull = wk0 + 31 >= p.Lk ? 0 : (p.Lq >> 6);
+        // a workgroup whose key block is not all valid masks every tile; the others only the last, partial query tile.
+        // The split is WORKGROUP-uniform (derived from the block's last key, not the wave's): the tile loop holds
+        // __syncthreads(), and every wave of a workgroup must reach the same barrier sites -- with a per-wave split the
+        // tail wave of the Lk = 1500 block ran the MODE 1 copy while its siblings ran MODE 0 (round-5 advisor finding).
+        const int nfull = kb0 + 32 * NW - 1 >= p.Lk ? 0 : (p.Lq >> 6);
         tiles(std::integral_constant<int, 0>{}, 0, nfull);
         tiles(std::integral_constant<int, 1>{}, nfull, nqt);
     }

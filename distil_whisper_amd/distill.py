@@ -39,25 +39,49 @@ class BucketWatchdog(threading.Thread):
     bucket and its element range and ends the process (exit code 124) -- the other ranks' own watchdogs then do the same.
     `on_timeout` replaces the exit (tests)."""
 
-    def __init__(self, timeout_s, rank=0, on_timeout=None, poll_s=0.05):
+    def __init__(self, timeout_s, rank=0, on_timeout=None, poll_s=0.05, device=None, first_grace_s=None):
         super().__init__(daemon=True, name="grad-bucket-watchdog")
         self.timeout_s, self.rank, self.on_timeout, self.poll_s = float(timeout_s), rank, on_timeout, poll_s
         self.q = queue.Queue()
         self.fired = None
+        # the device whose events this thread queries: a new thread's current device is 0, and Event.query() from a thread
+        # that never set its device would run against (and create a context on) GPU 0 on every rank with local_rank != 0
+        self.device = device
+        # the very first bucket of a run also pays RCCL's lazy communicator set-up (rings, IPC handles): slow, not stuck
+        self.first_grace_s = 3.0 * self.timeout_s if first_grace_s is None else float(first_grace_s)
+        self._seen = 0
+        self.errors = 0
 
     def submit(self, label, done):
         """done: a zero-argument callable that is True once the bucket has completed (Event.query for device buckets)."""
         self.q.put((time.monotonic(), label, done))
 
+    def _done(self, done, label):
+        """A failing poll must not end the thread silently (the watchdog would be off without anyone noticing): the error is
+        logged once per bucket and the bucket is treated as still pending, so the deadline keeps applying."""
+        try:
+            return bool(done())
+        except Exception as e:      # noqa: BLE001 -- anything the runtime raises from Event.query()
+            self.errors += 1
+            if self.errors <= 3:
+                sys.stderr.write(f"[rank {self.rank}] gradient all-reduce watchdog: polling {label} raised "
+                                 f"{type(e).__name__}: {e}\n")
+                sys.stderr.flush()
+            return False
+
     def run(self):
+        if self.device is not None and torch.cuda.is_available() and torch.device(self.device).type == "cuda":
+            torch.cuda.set_device(self.device)
         while True:
             item = self.q.get()
             if item is None:
                 return
             t0, label, done = item
-            while not done():
-                if time.monotonic() - t0 > self.timeout_s:
-                    msg = (f"[rank {self.rank}] gradient all-reduce watchdog: {label} still pending {self.timeout_s:.0f} s after it "
+            limit = self.first_grace_s if self._seen == 0 else self.timeout_s
+            self._seen += 1
+            while not self._done(done, label):
+                if time.monotonic() - t0 > limit:
+                    msg = (f"[rank {self.rank}] gradient all-reduce watchdog: {label} still pending {limit:.0f} s after it "
                            f"was issued -- a peer rank is gone or the collective is wedged; ending this rank")
                     self.fired = msg
                     sys.stderr.write(msg + "\n")
@@ -94,7 +118,7 @@ class GradReducer:
         self.watchdog = None
         if self.active and watchdog_s and watchdog_s > 0:
             rank = dist.get_rank(group) if self.initialized else 0
-            self.watchdog = BucketWatchdog(watchdog_s, rank, on_timeout)
+            self.watchdog = BucketWatchdog(watchdog_s, rank, on_timeout, device=flat.device if flat.is_cuda else None)
             self.watchdog.start()
 
     def _launch(self, lo, hi):

@@ -665,7 +665,11 @@ class WhisperEngine:
         """The decoder layers of one cached pass over `n` new positions per row (x: [B*n, D] embedded inputs).  With
         few rows (B*n <= 32 / 64) the LayerNorm in front of each projection is computed inside the weight-streaming
         GEMM and the new K/V go straight into the cache (ops.gemm ln= / kv_append=); otherwise they are separate
-        launches.  dw_decode_step issues exactly the same sequence."""
+        launches.  This is the per-kernel PYTHON form of the pass (`use_c_decode = False`; the CPU restatement of the
+        tests runs it).  `dw_decode_step` computes the same pass in fewer launches: since round 5 it runs LayerNorm + q
+        projection + cross-attention in ONE kernel (`attn_decode_proj_kernel`, dw_debug_set key 7, default 4), whose fp32
+        summation order differs from the GEMV's -- q may differ by one bf16 ulp between the two paths.  Tests that
+        compare them either pin `dw_debug_set(7, 12)` (the unfused sequence: exactly this one) or state a tolerance."""
         ops, st, d = self.ops, self.st, self.dims
         B, t, ML = cache["B"], cache["t"], cache["max_len"]
         D, H, Lk = d.d_model, d.heads, d.max_src

@@ -230,6 +230,7 @@ class _Encoder(nn.Module):
         self.embed_positions = nn.Embedding(d.max_src, d.d_model, device="meta")
         self.layers = nn.ModuleList([_EncoderLayer(d.d_model, d.ffn) for _ in range(d.enc_layers)])
         self.layer_norm = nn.LayerNorm(d.d_model, device="meta")
+        self.gradient_checkpointing = False     # read by run_distillation.py:1021 / 1037 before anyone enables it
 
 
 class _Decoder(nn.Module):
@@ -239,6 +240,7 @@ class _Decoder(nn.Module):
         self.embed_positions = nn.Embedding(d.max_tgt, d.d_model, device="meta")
         self.layers = nn.ModuleList([_DecoderLayer(d.d_model, d.ffn) for _ in range(d.dec_layers)])
         self.layer_norm = nn.LayerNorm(d.d_model, device="meta")
+        self.gradient_checkpointing = False
 
 
 class _Model(nn.Module):
@@ -515,6 +517,24 @@ class WhisperForConditionalGeneration(nn.Module):
         self.is_gradient_checkpointing = False
 
     # -- reference surface ------------------------------------------------------------------------------------------
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        """`nn.Module.state_dict()` with INDEPENDENT tensors.  Every parameter of this module is a view of one flat
+        buffer (engine.ParamStore); serializers that look at storages -- safetensors behind `accelerator.save_state`
+        (run_distillation.py:1636) -- take tensors that share a storage for aliases of one another, drop all but one and
+        then refuse the rest ("None is covering the entire storage").  So the entries are copies, and the tied
+        `proj_out.weight` IS `model.decoder.embed_tokens.weight` (one tensor under two names, as `transformers` hands it
+        out).  `keep_vars=True` returns the live parameters (views) unchanged."""
+        sd = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        if keep_vars:
+            return sd
+        mine = [k for k in sd if k.startswith(prefix)]
+        for k in mine:
+            sd[k] = sd[k].clone()
+        tied, emb = prefix + "proj_out.weight", prefix + "model.decoder.embed_tokens.weight"
+        if tied in sd and emb in sd:
+            sd[tied] = sd[emb]
+        return sd
+
     def get_encoder(self):
         return self.model.encoder
 

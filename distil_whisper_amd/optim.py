@@ -12,6 +12,13 @@ re-cast afterwards.  `FusedAdamW` keeps the loop's shape --
     grad_norm = optimizer.clip_grad_norm_(max_grad_norm)      # instead of accelerator.clip_grad_norm_(params, max_grad_norm)
     optimizer.step(); lr_scheduler.step(); optimizer.zero_grad()
 
+(Under `accelerate`, `accelerator.prepare(optimizer)` returns an `AcceleratedOptimizer` wrapper that forwards only the
+`torch.optim.Optimizer` methods -- it has no `__getattr__`, so `optimizer.clip_grad_norm_` does not exist on it
+(run_distillation.py:1449).  Use the module-level `clip_grad_norm_(optimizer, max_grad_norm)` below, which unwraps it, or
+construct `FusedAdamW(..., max_grad_norm=...)` and delete the script's `accelerator.clip_grad_norm_` line: `step()` clips
+by itself then.  Leaving `accelerator.clip_grad_norm_(student_model.parameters(), ...)` in place also works -- it scales
+`p.grad` in place with torch's multi-tensor passes first -- it is merely the slow form.)
+
 -- and runs ONE read of the gradients for the norm (`dw_sumsq_f32`) and ONE pass per parameter group segment
 (`dw_adamw_dev`: clip coefficient from the device-resident norm, AdamW, bf16 shadow refresh) over the model's flat
 parameter / moment buffers.  Same arithmetic as `DistillationTrainer.optimizer_step` (same kernels); `torch.optim.AdamW`
@@ -20,7 +27,28 @@ from the group every step (LR schedulers work unchanged), `state_dict()` / `load
 """
 import torch
 
-__all__ = ["FusedAdamW"]
+__all__ = ["FusedAdamW", "clip_grad_norm_", "unwrap_optimizer"]
+
+
+def unwrap_optimizer(optimizer):
+    """The FusedAdamW behind `accelerate.optimizer.AcceleratedOptimizer` (its `.optimizer`) or a LR-scheduler-style wrapper;
+    the optimizer itself when it is not wrapped."""
+    seen = 0
+    while not isinstance(optimizer, FusedAdamW) and hasattr(optimizer, "optimizer") and seen < 4:
+        optimizer, seen = optimizer.optimizer, seen + 1
+    return optimizer
+
+
+def clip_grad_norm_(optimizer, max_norm, norm_type=2.0):
+    """Line 1611 of run_distillation.py for a FusedAdamW that went through `accelerator.prepare`:
+
+        grad_norm = clip_grad_norm_(optimizer, training_args.max_grad_norm)
+
+    Returns the total gradient norm as a device scalar; the scaling is fused into the next `optimizer.step()`."""
+    opt = unwrap_optimizer(optimizer)
+    if not isinstance(opt, FusedAdamW):
+        raise TypeError("clip_grad_norm_: expected a FusedAdamW (possibly wrapped by accelerate), got " + type(opt).__name__)
+    return opt.clip_grad_norm_(max_norm, norm_type)
 
 
 def _unwrap(model):
@@ -50,8 +78,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 if name is None:
                     raise ValueError("FusedAdamW: every parameter must belong to `model` (a distil_whisper_amd module)")
                 off, shape, _ = st.entries[name]
-                if off < st.train_start:
-                    raise ValueError(f"FusedAdamW: {name} lies in the model's frozen region")
                 n = 1
                 for d in shape:
                     n *= d
@@ -75,6 +101,14 @@ class FusedAdamW(torch.optim.Optimizer):
         key = tuple(id(p) for g in self.param_groups for p in g["params"] if p.grad is not None)
         if key == self._seg_key:
             return
+        # The reference's groups hold EVERY named parameter, also the ones it froze (run_distillation.py:1386-1401 does not
+        # filter on requires_grad; torch.optim.AdamW skips a parameter without a gradient).  Parameters of the store's
+        # frozen region (no gradient / moment storage: the sinusoidal encoder positions, a model built with
+        # frozen_prefixes) are accepted in the groups and must simply never carry a gradient.
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None and self._ranges[id(p)][0] < self.st.train_start:
+                    raise ValueError(f"FusedAdamW: {self._ranges[id(p)][2]} lies in the model's frozen region but has a gradient")
         plan = []
         for gi, group in enumerate(self.param_groups):
             rs = sorted(self._ranges[id(p)][:2] for p in group["params"] if p.grad is not None)
@@ -152,26 +186,93 @@ class FusedAdamW(torch.optim.Optimizer):
         super().zero_grad(set_to_none=set_to_none)
 
     # -- checkpointing (accelerator.save_state / load_state) -------------------------------------------------------------
+    _PRIVATE_KEYS = ("params", "_adam", "_lr_dev")
+
     def state_dict(self):
+        """Flat form: the moments of the whole trainable range in two tensors + the parameter groups (every public key,
+        e.g. LambdaLR's `initial_lr`; `params` holds parameter NAMES).  `torch_state_dict()` is the per-parameter
+        torch.optim.AdamW layout."""
         st = self.st
         lo, hi = st.train_start, st.train_end
-        groups = [{k: v for k, v in g.items() if k not in ("params", "_adam", "_lr_dev")} for g in self.param_groups]
+        groups = [{k: v for k, v in g.items() if k not in self._PRIVATE_KEYS} for g in self.param_groups]
         for g, src in zip(groups, self.param_groups):
             g["params"] = [self._ranges[id(p)][2] for p in src["params"]]
             g["step"] = float(src["_adam"][1].item())
         return {"state": {"exp_avg": st.M[lo:hi].clone(), "exp_avg_sq": st.V[lo:hi].clone(), "range": (lo, hi)},
                 "param_groups": groups}
 
-    def load_state_dict(self, state_dict):
-        st = self.st
-        lo, hi = state_dict["state"]["range"]
-        if (lo, hi) != (st.train_start, st.train_end) or len(state_dict["param_groups"]) != len(self.param_groups):
-            raise ValueError("FusedAdamW.load_state_dict: the checkpoint is for another parameter layout")
-        st.M[lo:hi].copy_(state_dict["state"]["exp_avg"])
-        st.V[lo:hi].copy_(state_dict["state"]["exp_avg_sq"])
-        for g, saved in zip(self.param_groups, state_dict["param_groups"]):
-            for k in ("lr", "betas", "eps", "weight_decay"):
-                g[k] = saved[k]
+    def _restore_groups(self, saved_groups, steps):
+        if len(saved_groups) != len(self.param_groups):
+            raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint has {len(saved_groups)} parameter groups, this "
+                             f"optimizer {len(self.param_groups)}")
+        for g, saved, step in zip(self.param_groups, saved_groups, steps):
+            for k, v in saved.items():                  # every saved key (lr, betas, eps, weight_decay, initial_lr, ...)
+                if k not in self._PRIVATE_KEYS and k != "step":
+                    g[k] = v
             b1, b2 = g["betas"]
-            g["_adam"] = self.ops.adam_state(g["lr"], b1, b2, saved.get("step", 0.0))
+            g["_adam"] = self.ops.adam_state(g["lr"], b1, b2, step)
             g["_lr_dev"] = g["lr"]
+
+    def load_state_dict(self, state_dict):
+        """Accepts this class's flat form and the torch.optim.AdamW layout (`state` keyed by parameter index with
+        `step` / `exp_avg` / `exp_avg_sq`): a checkpoint written by the reference's run with torch.optim.AdamW over the same
+        parameter groups resumes here, and `torch_state_dict()` goes the other way."""
+        state = state_dict["state"]
+        if "range" not in state:
+            return self.load_torch_state_dict(state_dict)
+        st = self.st
+        lo, hi = state["range"]
+        if (lo, hi) != (st.train_start, st.train_end):
+            raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint covers the flat range [{lo}, {hi}), this model's "
+                             f"trainable range is [{st.train_start}, {st.train_end}) -- another frozen layout (freeze_encoder / "
+                             f"requires_grad_ before constructing the model's store); use torch_state_dict() / "
+                             f"load_torch_state_dict() to move moments between layouts by parameter")
+        st.M[lo:hi].copy_(state["exp_avg"])
+        st.V[lo:hi].copy_(state["exp_avg_sq"])
+        self._restore_groups(state_dict["param_groups"], [g.get("step", 0.0) for g in state_dict["param_groups"]])
+
+    def torch_state_dict(self):
+        """The torch.optim.AdamW layout of the same state: {"state": {index: {"step", "exp_avg", "exp_avg_sq"}},
+        "param_groups": [... "params": [indices]]}; indices count the parameters group by group as torch does.  (`step` of a
+        parameter that never had a gradient is still the group's count: this optimizer keeps one count per group.)"""
+        st, state, groups, idx = self.st, {}, [], 0
+        for g in self.param_groups:
+            step = float(g["_adam"][1].item())
+            out = {k: v for k, v in g.items() if k not in self._PRIVATE_KEYS}
+            out["params"] = []
+            for p in g["params"]:
+                a = self._ranges[id(p)][0]
+                if step > 0 and p.requires_grad and a >= st.train_start:     # (torch holds no state for a parameter it never stepped)
+                    state[idx] = {"step": torch.tensor(step), "exp_avg": st.M[a:a + p.numel()].view(p.shape).clone(),
+                                  "exp_avg_sq": st.V[a:a + p.numel()].view(p.shape).clone()}
+                out["params"].append(idx)
+                idx += 1
+            groups.append(out)
+        return {"state": state, "param_groups": groups}
+
+    def load_torch_state_dict(self, state_dict):
+        st = self.st
+        saved = state_dict["param_groups"]
+        if len(saved) != len(self.param_groups) or any(len(a["params"]) != len(b["params"]) for a, b in zip(saved, self.param_groups)):
+            raise ValueError("FusedAdamW.load_torch_state_dict: the checkpoint's parameter groups do not match this optimizer's "
+                             "(same grouping and order as the optimizer that wrote it are required, as for torch.optim)")
+        steps = []
+        for g, sg in zip(self.param_groups, saved):
+            step = 0.0
+            for p, i in zip(g["params"], sg["params"]):
+                ps = state_dict["state"].get(i)
+                a = self._ranges[id(p)][0]
+                if a < st.train_start:
+                    continue
+                if ps is None:
+                    st.M[a:a + p.numel()].zero_()
+                    st.V[a:a + p.numel()].zero_()
+                    continue
+                if tuple(ps["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"FusedAdamW.load_torch_state_dict: moment shape {tuple(ps['exp_avg'].shape)} for "
+                                     f"{self._ranges[id(p)][2]} {tuple(p.shape)}")
+                st.M[a:a + p.numel()].view(p.shape).copy_(ps["exp_avg"])
+                st.V[a:a + p.numel()].view(p.shape).copy_(ps["exp_avg_sq"])
+                step = max(step, float(ps["step"]))
+            steps.append(step)
+        self._restore_groups(saved, steps)

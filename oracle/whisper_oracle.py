@@ -109,6 +109,46 @@ def init_state_dict(cfg: OracleConfig, seed: int, std: float = 0.02, bias_std: f
     return sd
 
 
+def sharpen_state_dict(sd, cfg: OracleConfig, attn_logit_std: float = 4.0, logit_std: float = 5.0,
+                       outlier: float = 30.0):
+    """"Trained-like" statistics on top of init_state_dict (in place, deterministic; no pretrained weights exist
+    offline).  Random-init weights at std 0.02 give near-uniform softmaxes everywhere (CE ~ ln V); a trained Whisper
+    has peaked attention rows, peaked logits and a few residual / LayerNorm channels two orders of magnitude above the
+    rest.  This puts the arithmetic into that regime:
+      * q_proj / k_proj weights rescaled so that q.k/sqrt(64) over LayerNorm outputs has std ~ attn_logit_std
+        (q std = sqrt(D) sigma, 64-term dot product / 8 => D sigma^2);
+      * the decoder's final LayerNorm gain and bias multiplied so that the logits have std ~ logit_std
+        (sqrt(D) x 0.02 x gain; scaling the tied embedding instead would put |E[id]|^2 / std(x) ~ 100 on the INPUT
+        token's own logit and saturate every softmax at exactly 1);
+      * outlier channels: three residual channels receive +-outlier/2 through fc2.bias in the first two layers of each
+        stack (a large-mean residual stream, as Whisper's massive activations), and two LayerNorm gains per fourth
+        layer are multiplied by `outlier`.
+    Used by oracle/gen_golden_sharp.py and the GPU parity tests that consume its fixtures."""
+    D = cfg.d_model
+    s_qk = math.sqrt(attn_logit_std / D) / 0.02
+    s_e = (logit_std / math.sqrt(D)) / 0.02
+    chans = [7 % D, (D // 4 + 3) % D, D - 1]
+    gains = [(D // 2 + 5) % D, (3 * D // 4 + 1) % D]
+    for k in list(sd.keys()):
+        if k.endswith("q_proj.weight") or k.endswith("k_proj.weight"):
+            sd[k] = sd[k] * s_qk
+    sd["model.decoder.layer_norm.weight"] = sd["model.decoder.layer_norm.weight"] * s_e
+    sd["model.decoder.layer_norm.bias"] = sd["model.decoder.layer_norm.bias"] * s_e
+    for part, n in (("encoder", cfg.enc_layers), ("decoder", cfg.dec_layers)):
+        for i in range(n):
+            if i < 2:
+                b = sd[f"model.{part}.layers.{i}.fc2.bias"].clone()
+                for j, c in enumerate(chans):
+                    b[c] += (outlier / 2) * (1.0 if j % 2 == 0 else -1.0)     # two layers add up to +-outlier
+                sd[f"model.{part}.layers.{i}.fc2.bias"] = b
+            if i % 4 == 1:
+                for ln in ("self_attn_layer_norm", "final_layer_norm"):
+                    w = sd[f"model.{part}.layers.{i}.{ln}.weight"].clone()
+                    w[gains] *= outlier
+                    sd[f"model.{part}.layers.{i}.{ln}.weight"] = w
+    return sd
+
+
 def student_layer_map(n_teacher: int, n_student: int):
     """create_student_model.py:129-144: maximally spaced teacher layers, last one forced to the teacher's last."""
     m = np.linspace(0, n_teacher - 1, n_student, dtype=int)

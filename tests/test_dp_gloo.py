@@ -210,6 +210,21 @@ def test_bucket_watchdog_names_the_bucket_that_never_completes():
     wd.stop()
     assert len(fired) == 1
     assert "[rank 3]" in fired[0] and "step 8 bucket 0" in fired[0] and "[100, 200)" in fired[0]
+    # a poll that RAISES must not end the thread silently (round-5 advisor finding): it is logged, the bucket counts as
+    # pending and the deadline still fires; the first bucket of a run gets the longer grace period (RCCL's lazy set-up)
+    fired2 = []
+    wd2 = BucketWatchdog(0.2, rank=1, on_timeout=fired2.append, poll_s=0.01, first_grace_s=0.6)
+
+    def boom():
+        raise RuntimeError("hipErrorInvalidDevice")
+    t1 = time.monotonic()
+    wd2.start()
+    wd2.submit("step 0 bucket 0: elements [0, 10) of the flat gradient (0 MiB)", boom)
+    while not fired2 and time.monotonic() < t1 + 5.0:
+        time.sleep(0.02)
+    wd2.stop()
+    assert len(fired2) == 1 and "step 0 bucket 0" in fired2[0] and wd2.errors > 0
+    assert time.monotonic() - t1 >= 0.6          # the first bucket waited for first_grace_s, not timeout_s
 
 
 def test_grad_reducer_labels_its_buckets_and_counts_steps():

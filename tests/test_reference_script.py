@@ -1,0 +1,245 @@
+"""The reference SCRIPT'S OWN TEXT over the drop-in classes (`-m "not gpu"`; runs where /root/reference exists).
+
+`training/run_distillation.py` cannot be imported or run end to end here (`evaluate`, Hub checkpoints, tokenizer files
+and audio datasets are absent), but everything `main()` does between loading the models and saving them is
+plain Python over the two model objects.  This test cuts those statements out of the file BY SYNTAX TREE -- no retyped
+copy -- and executes them, in the script's order, around (a) the `transformers` classes and (b) the drop-in classes:
+
+  module level   get_parameter_names (760-778)
+  main(), 7      set_trainable_parameters + the freeze_encoder / freeze_decoder / freeze_embed_positions blocks +
+                 share_hidden_states and the tied teacher encoder (1016-1049)
+  main(), 13     forbidden_module, decay_parameters, optimizer_grouped_parameters, torch.optim.AdamW, get_scheduler
+                 (1369-1415)
+  main(), 15     accelerator.prepare(student_model, teacher_model, optimizer, lr_scheduler) (1449-1451) with a real
+                 `accelerate.Accelerator(cpu=True)`
+  nested         kl_divergence, train_step, eval_step (1453-1522)
+  loop body      `with accelerator.accumulate(student_model): ... optimizer.zero_grad()` (1606-1614)
+
+and compares metrics and every parameter after three optimizer steps.  A third run applies INTEGRATION.md's optimizer
+edit to that text (torch.optim.AdamW -> FusedAdamW, accelerator.clip_grad_norm_ -> distil_whisper_amd.optim.clip_grad_norm_)
+and round-trips `accelerator.save_state` / `load_state` -- the accelerate-wrapped optimizer of the round-5 advisor finding.
+"""
+import ast
+import logging
+import os
+import textwrap
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import whisper_oracle as wo
+from oracle.ref_ops import RefOps
+
+REF = "/root/reference/training/run_distillation.py"
+pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="the reference tree is not present on this box")
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+class _Blocks:
+    """Source text of chosen statements of the reference script, located through its syntax tree."""
+
+    def __init__(self):
+        self.src = open(REF).read()
+        self.lines = self.src.splitlines()
+        tree = ast.parse(self.src)
+        self.top = {n.name: n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))}
+        self.main = self.top["main"].body
+
+    def text(self, node_or_nodes):
+        nodes = node_or_nodes if isinstance(node_or_nodes, list) else [node_or_nodes]
+        lo = min(getattr(n, "lineno") - (len(n.decorator_list) if hasattr(n, "decorator_list") else 0) for n in nodes)
+        hi = max(n.end_lineno for n in nodes)
+        return textwrap.dedent("\n".join(self.lines[lo - 1:hi]))
+
+    def nested_def(self, name):
+        return self.text(next(n for n in self.main if isinstance(n, ast.FunctionDef) and n.name == name))
+
+    def assign(self, target):
+        """The top-level statement of main() that assigns `target`."""
+        for n in self.main:
+            if isinstance(n, ast.Assign):
+                for t in n.targets:
+                    names = [t.id] if isinstance(t, ast.Name) else [e.id for e in getattr(t, "elts", []) if isinstance(e, ast.Name)]
+                    if target in names:
+                        return n
+        raise KeyError(target)
+
+    def span(self, first, last):
+        """All top-level statements of main() from `first` to `last` (inclusive), as text."""
+        i, j = self.main.index(first), self.main.index(last)
+        return self.text(self.main[i:j + 1])
+
+    def ifs_testing(self, attr):
+        return next(n for n in self.main if isinstance(n, ast.If) and f"training_args.{attr}" in ast.unparse(n.test))
+
+    def loop_body(self):
+        """The `with accelerator.accumulate(student_model):` block of the training loop."""
+        for n in ast.walk(self.top["main"]):
+            if isinstance(n, ast.With) and "accelerator.accumulate" in ast.unparse(n.items[0].context_expr):
+                return self.text(n)
+        raise KeyError("accumulate block")
+
+
+def _script_namespace(blocks, student_model, teacher_model, BaseModelOutput, accelerator, *, freeze_encoder, fused):
+    """Execute the script's statements in its order inside one namespace; returns the namespace."""
+    from transformers import get_scheduler
+    training_args = types.SimpleNamespace(
+        freeze_encoder=freeze_encoder, freeze_decoder=False, freeze_embed_positions=True, gradient_checkpointing=False,
+        weight_decay=0.1, learning_rate=1e-3, adam_beta1=0.9, adam_beta2=0.999, adam_epsilon=1e-8,
+        lr_scheduler_type="linear", warmup_steps=1, kl_weight=0.7, temperature=2.0, max_grad_norm=0.5)
+    ns = {"torch": torch, "nn": nn, "np": __import__("numpy"), "logger": logging.getLogger("ref"), "training_args": training_args,
+          "student_model": student_model, "teacher_model": teacher_model, "teacher_dtype": torch.float32,
+          "BaseModelOutput": BaseModelOutput, "accelerator": accelerator, "get_scheduler": get_scheduler,
+          "total_train_steps": 8}
+    code = [blocks.text(blocks.top["get_parameter_names"]),
+            blocks.nested_def("set_trainable_parameters"),
+            blocks.text(blocks.ifs_testing("freeze_encoder")),
+            blocks.text(blocks.ifs_testing("freeze_decoder")),
+            blocks.text(blocks.ifs_testing("freeze_embed_positions")),
+            blocks.span(blocks.assign("share_hidden_states"), next(n for n in blocks.main if isinstance(n, ast.If) and
+                        ast.unparse(n.test) == "share_hidden_states")),
+            blocks.span(blocks.assign("forbidden_module"), blocks.assign("lr_scheduler")),
+            blocks.text(blocks.assign("student_model")) if False else "",
+            ]
+    prepare = next(n for n in blocks.main if isinstance(n, ast.Assign) and "accelerator.prepare" in ast.unparse(n.value))
+    code.append(blocks.text(prepare))
+    code += [blocks.nested_def(n) for n in ("kl_divergence", "train_step", "eval_step")]
+    body = blocks.loop_body()
+    code.append("def training_iteration(batch):\n" + textwrap.indent(body, "    ") +
+                "\n    return loss, train_metric\n")
+    text = "\n\n".join(c for c in code if c)
+    assert "torch.optim.AdamW(" in text and "accelerator.clip_grad_norm_(student_model.parameters(), training_args.max_grad_norm)" in text
+    if fused:      # the optimizer edit, applied to the script's text
+        text = text.replace("torch.optim.AdamW(", "FusedAdamW(model=student_model, ")
+        text = text.replace("accelerator.clip_grad_norm_(student_model.parameters(), training_args.max_grad_norm)",
+                            "clip_grad_norm_(optimizer, training_args.max_grad_norm)")
+        from distil_whisper_amd.optim import FusedAdamW, clip_grad_norm_
+        ns.update(FusedAdamW=FusedAdamW, clip_grad_norm_=clip_grad_norm_)
+    exec(compile(text, REF + " (statements selected by tests/test_reference_script.py)", "exec"), ns)
+    ns["_text"] = text
+    return ns
+
+
+def _batches(cfg, n, B, T, seed):
+    out = []
+    for i in range(n):
+        b = wo.synthetic_batch(cfg, B, seed=seed + i, T=T, with_audio=False)
+        feats = torch.randn(B, cfg.n_mels, 3000, generator=torch.Generator().manual_seed(seed + 100 + i)) * 0.5
+        out.append({"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]})
+    return out
+
+
+def _accelerator():
+    from accelerate import Accelerator
+    from accelerate.state import AcceleratorState, GradientState
+    AcceleratorState._reset_state(True)
+    GradientState._reset_state()
+    return Accelerator(cpu=True, gradient_accumulation_steps=1)
+
+
+@pytest.mark.parametrize("freeze_encoder", [False, True])
+def test_script_text_over_drop_in_equals_script_text_over_transformers(freeze_encoder, tmp_path):
+    pytest.importorskip("transformers")
+    pytest.importorskip("accelerate")
+    from transformers.modeling_outputs import BaseModelOutput as HFBaseModelOutput
+    from oracle.gen_golden import hf_model
+    from distil_whisper_amd import modeling as M
+    blocks = _Blocks()
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 71)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    batches = _batches(cfg_t, 3, 2, 29, seed=72)
+
+    def models(kind):
+        if kind == "hf":
+            return hf_model(cfg_s, s_sd), hf_model(cfg_t, t_sd), HFBaseModelOutput
+        ops = RefOps("cpu", lowp=torch.float32)
+        return (M.WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd),
+                M.WhisperForConditionalGeneration(cfg_t, ops=ops, state_dict=t_sd), M.BaseModelOutput)
+
+    def run(kind, fused=False):
+        s, t, bmo = models(kind)
+        ns = _script_namespace(blocks, s, t, bmo, _accelerator(), freeze_encoder=freeze_encoder, fused=fused)
+        assert ns["share_hidden_states"] == freeze_encoder
+        if freeze_encoder:
+            assert ns["teacher_model"].model.encoder is ns["student_model"].model.encoder       # line 1049
+        out = []
+        for b in batches:
+            loss, metric = ns["training_iteration"](b)
+            out.append({k: float(v) for k, v in metric.items()})
+        ev = {k: float(v) for k, v in ns["eval_step"](batches[0]).items()}
+        return ns, s, out, ev
+
+    ns0, s0, out0, ev0 = run("hf")
+    ns1, s1, out1, ev1 = run("drop-in")
+    assert type(ns1["optimizer"]).__name__ == "AcceleratedOptimizer"
+    for m0, m1 in zip(out0, out1):
+        for k in ("loss", "ce_loss", "kl_loss"):
+            assert abs(m1[k] - m0[k]) < 2e-5 * abs(m0[k]) + 1e-7, (k, m0, m1)
+    for k in ev0:
+        assert abs(ev1[k] - ev0[k]) < 2e-5 * abs(ev0[k]) + 1e-7, (k, ev0, ev1)
+    p0 = dict(s0.named_parameters())
+    frozen = 0
+    for n, p in s1.named_parameters():
+        assert p.requires_grad == p0[n].requires_grad, n
+        frozen += not p.requires_grad
+        assert relerr(p, p0[n]) < 2e-5, n
+    # freeze_embed_positions is on in both runs; with freeze_encoder every encoder parameter is off as well
+    assert frozen == (1 + (len([n for n in p0 if n.startswith("model.encoder.")]) if freeze_encoder else 1))
+    assert ns1["lr_scheduler"].get_last_lr()[0] == pytest.approx(ns0["lr_scheduler"].get_last_lr()[0])
+
+    # --- the optimizer edit of INTEGRATION.md on the same text, THROUGH accelerator.prepare (AcceleratedOptimizer has no
+    # __getattr__: optimizer.clip_grad_norm_ does not exist on it; the module-level helper unwraps)
+    ns2, s2, out2, ev2 = run("drop-in", fused=True)
+    from distil_whisper_amd.optim import FusedAdamW, unwrap_optimizer
+    assert type(ns2["optimizer"]).__name__ == "AcceleratedOptimizer" and not hasattr(ns2["optimizer"], "clip_grad_norm_")
+    assert isinstance(unwrap_optimizer(ns2["optimizer"]), FusedAdamW)
+    for m0, m2 in zip(out0, out2):
+        for k in ("loss", "ce_loss", "kl_loss"):
+            assert abs(m2[k] - m0[k]) < 2e-5 * abs(m0[k]) + 1e-7, (k, m0, m2)
+    for n, p in s2.named_parameters():
+        assert relerr(p, p0[n]) < 2e-5, n
+
+    # --- accelerator.save_state / load_state round trip of the wrapped fused optimizer (run_distillation.py:1636, 1560)
+    acc = ns2["accelerator"]
+    ckpt = str(tmp_path / "checkpoint-3-epoch-0")
+    acc.save_state(output_dir=ckpt)
+    ref_P, ref_M = s2.store.P.clone(), s2.store.M.clone()
+    fo = unwrap_optimizer(ns2["optimizer"])
+    step_before = float(fo.param_groups[0]["_adam"][1])
+    loss, _ = ns2["training_iteration"](batches[0])            # move on, then roll back
+    assert not torch.equal(s2.store.P, ref_P)
+    after_4 = s2.store.P.clone()
+    acc.load_state(ckpt)
+    assert torch.equal(s2.store.P, ref_P) and torch.equal(s2.store.M, ref_M)
+    assert float(fo.param_groups[0]["_adam"][1]) == step_before == 3.0
+    assert "initial_lr" in fo.param_groups[0]                  # LambdaLR's key survives the round trip
+    s2.store.refresh_shadow()
+    ns2["training_iteration"](batches[0])                      # the same fourth step again: bit-identical replay
+    assert torch.equal(s2.store.P, after_4)
+
+    # --- a torch.optim.AdamW checkpoint of the reference run resumes in FusedAdamW, and back
+    torch_sd = unwrap_optimizer(ns1["optimizer"]).state_dict()
+    assert 0 in torch_sd["state"] and "exp_avg" in torch_sd["state"][0]
+    s3, t3, bmo = models("drop-in")
+    ns3 = _script_namespace(blocks, s3, t3, bmo, _accelerator(), freeze_encoder=freeze_encoder, fused=True)
+    s3.load_state_dict(s1.state_dict())
+    fo3 = unwrap_optimizer(ns3["optimizer"])
+    fo3.load_state_dict(torch_sd)
+    assert float(fo3.param_groups[0]["_adam"][1]) == 3.0
+    back = fo3.torch_state_dict()
+    for i, ps in torch_sd["state"].items():
+        assert torch.equal(back["state"][i]["exp_avg"], ps["exp_avg"]) and float(back["state"][i]["step"]) == float(ps["step"])
+    for _ in range(3):
+        ns3["lr_scheduler"].step()                              # (the scheduler's own state is accelerate's to restore)
+    ns1["training_iteration"](batches[1])
+    ns3["training_iteration"](batches[1])
+    p1 = dict(s1.named_parameters())
+    for n, p in s3.named_parameters():
+        assert relerr(p, p1[n]) < 2e-5, n
