@@ -156,13 +156,16 @@ def main():
     s_sd, sdims = si.student_from_teacher(t_sd, tdims, le, ld)
     filt = torch.tensor(si.mel_filter_bank(tdims.n_mels), dtype=torch.float32, device=dev).contiguous()
     recipe = args.mode == "recipe"
-    # Side streams (frozen teacher forward, weight-gradient GEMMs): one rank decides by measurement unless told
-    # (mode_selection below: HIP graph on one stream against eager with side streams).  Data-parallel ranks run the eager
-    # step -- the RCCL buckets are issued from the host between the backward's layers -- and run it WITH the side streams:
-    # the same step one rank selects on this pool's boxes, plus the reducer's communication stream (--no-overlap keeps
-    # everything on the main stream).  Over gloo on a shared GPU (--share-device, a plumbing test) the side streams stay
-    # off unless --overlap is given: gloo's host round trips serialise them (12x slower, measured in round 3).
-    side = (args.overlap or (world > 1 and args.backend == "nccl")) and not args.no_overlap
+    # Side streams (frozen teacher forward, weight-gradient GEMMs): decided by measurement unless told.  One rank: HIP graph
+    # on one stream against eager with side streams (mode_selection below).  Data-parallel ranks run the eager step -- the
+    # RCCL buckets are issued from the host between the backward's layers -- and START on the configuration every test
+    # covers: everything on the main stream + the reducer's communication stream.  Then (dp_mode_selection below) a few
+    # untimed steps of that against the same step with the side streams on, max over ranks, and ALL ranks take the faster
+    # one (the choice is all-reduced, so no rank can disagree); a failure of the side-stream probe on any rank falls back to
+    # the single-stream step.  --overlap / --no-overlap skip the probe.  Over gloo on a shared GPU (--share-device, a
+    # plumbing test) the side streams stay off unless --overlap is given: gloo's host round trips serialise them (12x
+    # slower, measured in round 3).
+    side = args.overlap and not args.no_overlap
     tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, temperature=2.0, kl_weight=1.0, lr=1e-4,
                              weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=recipe, share_encoder=recipe,
                              mel_filters=filt, overlap_teacher=side and not args.no_teacher_overlap,
@@ -280,6 +283,8 @@ def main():
         selection = {k: (v if v != float("inf") else None) for k, v in selection.items()}
         log("mode selection (median ms of 6 untimed steps): " + json.dumps(selection) +
             f" -> {'hip_graph_single_stream' if use_graph else 'eager_side_streams'}")
+    if world > 1 and args.backend == "nccl" and not (args.overlap or args.no_overlap):
+        selection = dp_mode_selection(tr, eager_step, dist, dev)
     if use_graph:
         for _ in range(3):            # two eager steps on the capture stream, then the capture (untimed, before the warm-up)
             one_step()
@@ -398,6 +403,12 @@ def main():
 
     step_mode = ("hip_graph" if use_graph else "eager") + \
         ("_side_streams" if (tr.overlap_teacher or tr.student.wgrad_stream is not None) else "_single_stream")
+    red = tr.reducer
+    tr_info = {"bucket_mib": (red.bucket_elems * 4 / 2**20) if red is not None else None,
+               "buckets": getattr(red, "last_buckets", None), "reduced_mib": getattr(red, "last_bytes", 0) / 2**20 if red is not None else None,
+               "streams": ["main"] + (["teacher"] if tr.overlap_teacher else []) +
+                          (["weight-gradient"] if tr.student.wgrad_stream is not None else []) +
+                          (["communication"] if red is not None and red.active and red.stream is not None else [])}
     via_loop = None
     if world == 1 and not args.no_reference_loop:
         # what a maintainer gets from the two-line import change alone: the drop-in modules under the
@@ -431,6 +442,11 @@ def main():
                "step_tflops_per_gpu": step_tflops, "step_mfma_frac": step_tflops / PEAK_BF16_TFLOPS,
                "flops_per_sample": fl, "flops_per_sample_all_positions": sample_flops(T), "step_mode": step_mode, "cu_hog": args.cu_hog or None,
                "mode_selection": selection, "step_stats": step_stats,
+               "collective": None if world == 1 else {
+                   "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "ranks": world,
+                   "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "NCCL_MIN_NCHANNELS": os.environ.get("NCCL_MIN_NCHANNELS"),
+                   "bucket_mib": tr_info["bucket_mib"], "buckets_per_step": tr_info["buckets"],
+                   "all_reduced_mib_per_step": tr_info["reduced_mib"], "streams": tr_info["streams"]},
                "kernels_sha16": _kernels_sha16(),
                "ab": ab, "via_reference_loop": via_loop, "roofline": roofline, "cpu_baseline": cpu_baseline}
         if ab and "hip_graph_all_447_decoder_positions" in ab and "error" not in ab:
@@ -499,6 +515,51 @@ def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_hos
     # (shared encoder: the one-call loss takes the student's rows out of the teacher's full logits)
     out["with_valid_len_fused_kd_loss_and_fused_optimizer"] = leg(True, True, True)
     return out
+
+
+def dp_mode_selection(tr, eager_step, dist, dev, pre=2, n=5):
+    """Data-parallel ranks choose between two ways to issue the same eager step -- everything on the main stream (plus the
+    reducer's communication stream), or with the frozen teacher forward and the weight-gradient GEMMs on their own streams
+    -- by measurement, a few untimed steps of each WITH the bucketed all-reduce in them.  Per leg the slowest rank counts
+    (all-reduce MAX of the medians), the side-stream leg is only eligible if it ran on EVERY rank (all-reduce MIN of an ok
+    flag), and because every rank reads the same reduced numbers every rank takes the same decision.  The run starts on the
+    single-stream step: the configuration the test-suite executes on a GPU (tests/test_dp_gpu.py) -- an 8-GPU run can not
+    land on a configuration nobody has run without having measured it against that one first."""
+    def probe():
+        for _ in range(pre):
+            eager_step()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            eager_step()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))[n // 2]
+
+    tr.overlap_teacher = False
+    tr.set_overlap_wgrad(False)
+    single = probe()
+    ok, sidet = 1.0, float("inf")
+    try:
+        tr.overlap_teacher = True
+        tr.set_overlap_wgrad(True)
+        sidet = probe()
+    except Exception as e:      # noqa: BLE001 -- whatever the side-stream step raises, the run continues on the other one
+        ok = 0.0
+        log(f"side-stream probe failed on this rank ({type(e).__name__}: {e}); single-stream step")
+        torch.cuda.synchronize()
+    t = torch.tensor([single, sidet if ok else 1e30], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    okt = torch.tensor([ok], device=dev, dtype=torch.float64)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    single_max, side_max, all_ok = float(t[0]), float(t[1]), bool(okt.item() == 1.0)
+    use_side = all_ok and side_max < single_max
+    tr.overlap_teacher = use_side
+    tr.set_overlap_wgrad(use_side)
+    sel = {"eager_single_stream": single_max, "eager_side_streams": side_max if all_ok else None,
+           "side_streams_ran_on_every_rank": all_ok, "statistic": f"max over ranks of the median of {n} untimed steps, ms"}
+    log("data-parallel mode selection: " + json.dumps(sel) + f" -> {'eager_side_streams' if use_side else 'eager_single_stream'}")
+    return sel
 
 
 def spawn_ranks(n):

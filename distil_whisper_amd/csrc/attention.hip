@@ -31,6 +31,7 @@ struct AttnP {
     float* dq_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dq (q_proj.bias gradient), or null
     float* dv_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dv (v_proj.bias gradient), or null
     int plain_order;       // 1 = workgroups take (tile, head, batch) in launch order (A/B switch of attn_workgroup)
+    float defer;           // deferred-maximum threshold of the forward softmax in log2 units (g_attn_defer; 0 = the exact rule)
     int coff;              // causal mask: key <= query + coff (0 = top-left aligned, Lk - Lq = bottom-right aligned)
     float scale;
 };
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
         // than 2^DW_ATTN_DEFER (probabilities then stay below 2^8 -- nothing for fp32 sums or the bf16 P operand, whose relative
         // precision does not depend on the scale); with the exact rule some row of the wave's 32 sees a new maximum in three tiles
         // out of four at 1500 keys, and every such tile pays the 32-register rescale of O.  -DDW_ATTN_DEFER=0 is the exact rule.
-        const bool move = __any((mx - m_run) * c > (float)DW_ATTN_DEFER);
+        const bool move = __any((mx - m_run) * c > p.defer);
         const float m_new = move ? fmaxf(m_run, mx) : m_run;
         const float mc = m_new * c;
         // two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32): the softmax's vector
@@ -726,6 +727,8 @@ int g_attn_bwd_waves = 4;  // dw_debug_set key 17: 4 / 12 waves per workgroup of
 int g_attn_fwd_waves = 4;  // dw_debug_set key 16: 4 / 8 waves (x 32 queries) per workgroup of the non-causal forward kernel (8: half
                            // the K/V staging per query -- measured neutral: the kernel is not bound by the staging traffic)
 int g_attn_plain_order = 0; // dw_debug_set key 18
+int g_attn_defer = DW_ATTN_DEFER;  // dw_debug_set key 23: the forward's deferred-maximum threshold (0 = exact running maximum; the
+                                   // A/B of tests/test_sharp_parity_gpu.py prices this deviation on peaked attention rows)
 int g_attn_ablate = 0;     // dw_debug_set key 15 (DW_ABLATE builds)
 int g_attn_decode = 1;     // dw_debug_set key 4: 1 = single-query attention runs the streaming decode kernel
 static int check_ld(int64_t ld) { return (ld & 7) ? DW_EINVAL : DW_OK; }
@@ -774,6 +777,7 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     const int g4 = (Lq + 127) / 128;
     dim3 grid(g4 * H * B), block(256);
     p.plain_order = g_attn_plain_order;
+    p.defer = (float)g_attn_defer;
 #ifdef DW_ABLATE
     if (!causal && g_attn_ablate) {
         switch (g_attn_ablate) {
@@ -836,6 +840,7 @@ extern "C" int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const
     const int q4 = (Lq + 127) / 128, k4 = (Lk + 127) / 128;
     dim3 gq(q4 * H * B), gk(k4 * H * B), block(256);
     p.plain_order = g_attn_plain_order;
+    p.defer = (float)g_attn_defer;
     const int fs = g_attn_bwd_stage;
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), gq, block, 0, s, p);

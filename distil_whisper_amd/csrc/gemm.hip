@@ -47,6 +47,7 @@ extern int g_attn_decode;
 extern int g_attn_ablate;
 extern int g_attn_fwd_waves;
 extern int g_attn_plain_order;
+extern int g_attn_defer;
 extern int g_attn_bwd_waves;
 extern int g_logmel_mfma;     // logmel.hip
 extern int g_decode_fuse_off; // decode.hip
@@ -125,6 +126,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 21) { g_ln_variant = value; return DW_OK; }
     if (key == 22) { g_gemm_row_tail = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
+    if (key == 23) { if (value < 0 || value > 64) return DW_EINVAL; g_attn_defer = value; return DW_OK; }
     if (key == 16) { g_attn_fwd_waves = value; return DW_OK; }
     if (key == 15) { g_attn_ablate = value; return DW_OK; }
     if (key == 9) { if (value < 8 || value > 256 || (value & 7)) return DW_EINVAL; g_gemm_cus = value; return DW_OK; }

@@ -116,6 +116,8 @@ class GradReducer:
         self.labels = []
         self.step = 0
         self.watchdog = None
+        self._bytes = self._buckets = 0                  # of the step being issued
+        self.last_bytes = self.last_buckets = 0          # of the last completed step (what bench.py reports)
         if self.active and watchdog_s and watchdog_s > 0:
             rank = dist.get_rank(group) if self.initialized else 0
             self.watchdog = BucketWatchdog(watchdog_s, rank, on_timeout, device=flat.device if flat.is_cuda else None)
@@ -123,6 +125,8 @@ class GradReducer:
 
     def _launch(self, lo, hi):
         view = self.flat[lo:hi]
+        self._bytes += (hi - lo) * 4
+        self._buckets += 1
         self.labels.append(f"step {self.step} bucket {len(self.handles)}: elements [{lo}, {hi}) of the flat gradient "
                            f"({(hi - lo) * 4 / 2**20:.0f} MiB)")
         if self.stream is not None:
@@ -183,6 +187,7 @@ class GradReducer:
                 h.wait()
         self.handles, self.labels = [], []
         self.step += 1
+        self.last_bytes, self.last_buckets, self._bytes, self._buckets = self._bytes, self._buckets, 0, 0
         if self.stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
 

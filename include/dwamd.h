@@ -313,7 +313,10 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *   key 21  LayerNorm kernels: bit 0 persistent fp32-input forward with next-row prefetch (bits 8-11: workgroups per CU),
  *           bit 1 backward with next-row / residual-gradient prefetch at two waves per SIMD (default 3; tools/ln_ab.py)
  *   key 22  wide row-major 256-row launches hand a partial last row block (<= 128 rows) to the 128-tile kernel when the full
- *           row blocks alone need one round of the CUs less (default 1; bit-identical) */
+ *           row blocks alone need one round of the CUs less (default 1; bit-identical)
+ *   key 23  attention forward: threshold (in powers of two) by which a tile maximum must exceed the running reference of
+ *           the online softmax before the reference moves (default 8; 0 = the exact running maximum, the A/B leg of
+ *           tests/test_sharp_parity_gpu.py) */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus

@@ -195,9 +195,29 @@ def test_trainer_over_rccl_with_one_rank_equals_plain_trainer(ops):
         lo = min(a for a, _ in launched)
         hi = max(b_ for _, b_ in launched)
         assert lo == tr.student_store.train_start and hi == tr.student_store.train_end
+        assert tr.reducer.last_buckets == len(launched) // 2 and tr.reducer.last_bytes == 4 * (hi - lo)
+        # Every stream bench.py can put under a data-parallel step at once (dp_mode_selection's second leg): teacher forward
+        # on its stream, weight-gradient GEMMs on theirs, the reducer's communication stream waiting for both, the bucket
+        # watchdog polling behind it, the teacher decoder over padded rows -- and the switch between the two modes on a live
+        # trainer, as the probe does it.
+        tr3 = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, always_reduce=True, bucket_bytes=64 << 10, overlap_wgrad=True,
+                           overlap_teacher=True, pad_teacher_rows=True, comm_watchdog_s=30.0)
+        assert tr3.overlap_teacher and tr3.student.wgrad_stream is not None and tr3.reducer.watchdog is not None
+        p_all, gn_all = run(tr3)
+        assert tr3.reducer.watchdog.fired is None and tr3.reducer.watchdog.errors == 0
+        tr4 = make_trainer(ops, cfg_t, cfg_s, t_sd, s_sd, always_reduce=True, bucket_bytes=64 << 10, comm_watchdog_s=30.0)
+        tr4.train_step(feats, ids, labels)                         # single-stream step ...
+        tr4.overlap_teacher = True                                 # ... then the side streams switched on between steps
+        tr4.set_overlap_wgrad(True)
+        assert tr4.reducer.also_wait == [tr4.student.wgrad_stream]
+        tr4.train_step(feats, ids, labels)
+        torch.cuda.synchronize()
+        p_sw = tr4.student_store.P.clone()
     finally:
         dist.destroy_process_group()
     assert relerr(p_dp, p_plain) < 1e-6 and abs(gn_dp - gn_plain) < 1e-4 * gn_plain
+    assert relerr(p_all, p_plain) < 1e-6 and abs(gn_all - gn_plain) < 1e-4 * gn_plain
+    assert relerr(p_sw, p_plain) < 1e-6
 
 
 def test_weight_gradient_stream_equals_single_stream(ops):
