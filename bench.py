@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--no-reference-loop", action="store_true",
                     help="skip the `via_reference_loop` leg (the reference's loop body -- model(**batch), its own fp32 softmax / "
                          "KL lines, loss.backward(), clip_grad_norm_, torch.optim.AdamW -- over the drop-in modules)")
+    ap.add_argument("--dp-probe", action="store_true",
+                    help="run the data-parallel mode selection (dp_mode_selection) also over gloo (with --share-device: exercises "
+                         "the selection and the all-reduced decision on a one-GPU box; over nccl it runs by default)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
@@ -283,7 +286,7 @@ def main():
         selection = {k: (v if v != float("inf") else None) for k, v in selection.items()}
         log("mode selection (median ms of 6 untimed steps): " + json.dumps(selection) +
             f" -> {'hip_graph_single_stream' if use_graph else 'eager_side_streams'}")
-    if world > 1 and args.backend == "nccl" and not (args.overlap or args.no_overlap):
+    if world > 1 and (args.backend == "nccl" or args.dp_probe) and not (args.overlap or args.no_overlap):
         selection = dp_mode_selection(tr, eager_step, dist, dev)
     if use_graph:
         for _ in range(3):            # two eager steps on the capture stream, then the capture (untimed, before the warm-up)

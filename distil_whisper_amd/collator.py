@@ -2,8 +2,10 @@
 
 `DataCollatorSpeechSeq2SeqWithPadding` mirrors run_distillation.py:405-478 (same constructor fields and the same
 returned keys): labels padded to `max_target_length`, `decoder_input_ids = labels[:, :-1]`, `labels = labels[:, 1:]`,
-padding -> -100, prompt tokens up to and including <|startoftranscript|> -> -100.  The integer work is vectorised
-torch on the target device (a few KB per batch; not a kernel-worthy hot spot).
+padding -> -100, prompt tokens up to and including <|startoftranscript|> -> -100.  The ragged id lists become one
+rectangle by a single numpy scatter into a pinned staging buffer, cross to the device in one copy together with their
+lengths, and every mask is derived there (a few KB per batch: not a kernel-worthy hot spot; timed
+with the rest of the input side by tools/bench_input_pipeline.py).
 `linear_schedule_lr` restates `get_scheduler("linear", ...)` as the reference configures it (1409-1415: warm-up and
 total steps are multiplied by the number of processes because every process steps the scheduler).
 """
@@ -33,15 +35,22 @@ class DataCollatorSpeechSeq2SeqWithPadding:
     def __call__(self, features):
         B = len(features)
         L = self.max_target_length
-        ids = torch.full((B, L), self.pad_token_id, dtype=torch.long)
-        att = torch.zeros((B, L), dtype=torch.bool)
-        for i, f in enumerate(features):
-            lab = torch.as_tensor(np.asarray(f["labels"], dtype=np.int64))
-            if lab.numel() > L:
-                raise ValueError(f"labels of length {lab.numel()} exceed max_target_length={L}")
-            ids[i, : lab.numel()] = lab
-            att[i, : lab.numel()] = True
-        ids, att = ids.to(self.device), att.to(self.device)
+        # ONE ragged -> rectangular scatter on the host (no per-sample tensor ops), ONE pinned staging buffer, ONE copy to
+        # the device carrying the ids and the row lengths; every mask below is derived on the device from the lengths
+        lens = np.fromiter((np.asarray(f["labels"]).size for f in features), dtype=np.int64, count=B)
+        if B and int(lens.max()) > L:
+            raise ValueError(f"labels of length {int(lens.max())} exceed max_target_length={L}")
+        stage = torch.empty((B, L + 1), dtype=torch.long, pin_memory=str(self.device).startswith("cuda") and torch.cuda.is_available())
+        host = stage.numpy()
+        host[:, :L] = self.pad_token_id
+        host[:, L] = lens
+        if B and int(lens.sum()):
+            flat = np.concatenate([np.asarray(f["labels"], dtype=np.int64).reshape(-1) for f in features])
+            starts = np.cumsum(lens) - lens
+            host[np.repeat(np.arange(B), lens), np.arange(flat.size) - np.repeat(starts, lens)] = flat
+        stage = stage.to(self.device, non_blocking=True)
+        ids = stage[:, :L]
+        att = torch.arange(L, device=stage.device)[None, :] < stage[:, L:]
         decoder_input_ids = ids[:, :-1].contiguous()
         labels = ids[:, 1:].masked_fill(~att[:, 1:], -100)
         bos_index = torch.argmax((labels == self.decoder_start_token_id).long(), dim=1)
@@ -50,7 +59,7 @@ class DataCollatorSpeechSeq2SeqWithPadding:
         labels = torch.where(prompt_mask, torch.full_like(labels, -100), labels).contiguous()
         batch = {"labels": labels, "decoder_input_ids": decoder_input_ids}
         if self.report_valid_len:
-            per_row = [max(1, int(np.asarray(f["labels"]).size) - 1) for f in features]
+            per_row = [max(1, int(n) - 1) for n in lens]
             batch["valid_len"] = per_row if self.report_valid_len == "per_sequence" else max(per_row, default=1)
         if "input_features" in features[0]:
             feats = np.stack([np.asarray(f["input_features"], dtype=np.float32) for f in features])
