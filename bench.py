@@ -508,7 +508,12 @@ def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_hos
         torch.cuda.synchronize()
         t = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
         return {"median_ms": t[len(t) // 2], "audio_s_per_s": B * 30e3 / t[len(t) // 2], "loss": float(m["loss"].item())}
+    from distil_whisper_amd import lazy_logits
+    before = dict(lazy_logits.STATS)
     out["verbatim"] = leg(False, False)
+    # (the loop's own softmax / log_softmax / KLDivLoss lines run over the drop-in's lazy `.logits`: answered by the fused loss
+    # kernel, no fp32 [B, T, V] temporaries -- distil_whisper_amd/lazy_logits.py; the counters say whether that happened)
+    out["verbatim"]["lazy_logits"] = {k: lazy_logits.STATS[k] - before[k] for k in before}
     # the same loop body with distil_whisper_amd.optim.FusedAdamW in place of torch.optim.AdamW and its clip_grad_norm_ in
     # place of accelerator.clip_grad_norm_ (two changed lines of the script; same parameter groups, same LambdaLR)
     out["verbatim_with_fused_optimizer"] = leg(False, False, True)

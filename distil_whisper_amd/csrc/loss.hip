@@ -32,7 +32,8 @@ __global__ __launch_bounds__(LOSS_NT) void loss_count_kernel(const int64_t* labe
 __global__ __launch_bounds__(LOSS_NT) void loss_row_kernel(const bf16* s_logits, const bf16* t_logits,
                                                            const int64_t* labels, int V, long ld, float T,
                                                            float ce_w, float kl_w, float grad_scale, bf16* dlogits,
-                                                           float* row_ce, float* row_kl, const int32_t* counts) {
+                                                           float* row_ce, float* row_kl, const int32_t* counts,
+                                                           const float* weights) {
     __shared__ float red[LOSS_NT / 64];
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(LOSS_NT) void loss_row_kernel(const bf16* s_logits,
     if (!dlogits) return;
 
     // pass C: gradient w.r.t. the student logits (written in place of / next to them)
+    if (weights) { ce_w = weights[0]; kl_w = weights[1]; }      // device-resident mix (dw_distill_loss_w)
     const float n_ce = (float)max(counts[0], 1), n_kl = (float)max(counts[1], 1);
     const float gce = ce_ok ? grad_scale * ce_w / n_ce : 0.f;
     const float gkl = kl_ok ? grad_scale * kl_w * T / n_kl : 0.f;  // T^2 * (1/T)
@@ -122,12 +124,13 @@ __global__ __launch_bounds__(LOSS_NT) void loss_row_kernel(const bf16* s_logits,
 
 __global__ __launch_bounds__(LOSS_NT) void loss_final_kernel(const float* row_ce, const float* row_kl, int rows,
                                                              const int32_t* counts, float T, float ce_w, float kl_w,
-                                                             float* losses) {
+                                                             float* losses, const float* weights) {
     __shared__ float red[LOSS_NT / 64];
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x; i < rows; i += LOSS_NT) { a += row_ce[i]; b += row_kl[i]; }
     a = block_sum<LOSS_NT>(a, red);
     b = block_sum<LOSS_NT>(b, red);
+    if (weights) { ce_w = weights[0]; kl_w = weights[1]; }
     if (threadIdx.x == 0) {
         // no valid label in the batch: the reference's means are 0/0 = NaN (CrossEntropyLoss over zero tokens,
         // kl.sum() / padding_mask.sum()); report NaN as well so that the empty batch is visible (the gradient written
@@ -142,10 +145,10 @@ __global__ __launch_bounds__(LOSS_NT) void loss_final_kernel(const float* row_ce
     }
 }
 
-extern "C" int dw_distill_loss(const void* s_logits, const void* t_logits, const int64_t* labels, int rows, int V,
-                               int64_t ld, float temperature, float ce_weight, float kl_weight, float grad_scale,
-                               float* losses, void* dlogits, float* row_ce, float* row_kl, int32_t* counts,
-                               void* stream) {
+static int distill_loss_launch(const void* s_logits, const void* t_logits, const int64_t* labels, int rows, int V,
+                               int64_t ld, float temperature, float ce_weight, float kl_weight, const float* weights,
+                               float grad_scale, float* losses, void* dlogits, float* row_ce, float* row_kl,
+                               int32_t* counts, void* stream) {
     DW_CLEAR_ERR();
     if (!s_logits || !t_logits || !labels || !losses || !row_ce || !row_kl || !counts) return DW_EINVAL;
     if (rows <= 0 || V <= 0 || ld < V || (ld & 7) || temperature <= 0.f) return DW_EINVAL;
@@ -154,9 +157,28 @@ extern "C" int dw_distill_loss(const void* s_logits, const void* t_logits, const
     hipLaunchKernelGGL(loss_count_kernel, dim3(1), dim3(LOSS_NT), 0, s, labels, rows, counts);
     hipLaunchKernelGGL(loss_row_kernel, dim3(rows), dim3(LOSS_NT), 0, s, (const bf16*)s_logits, (const bf16*)t_logits,
                        labels, V, (long)ld, temperature, ce_weight, kl_weight, grad_scale, (bf16*)dlogits, row_ce,
-                       row_kl, counts);
+                       row_kl, counts, weights);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(LOSS_NT), 0, s, row_ce, row_kl, rows, counts, temperature,
-                       ce_weight, kl_weight, losses);
+                       ce_weight, kl_weight, losses, weights);
     DW_CHECK_LAUNCH();
     return DW_OK;
+}
+
+extern "C" int dw_distill_loss(const void* s_logits, const void* t_logits, const int64_t* labels, int rows, int V,
+                               int64_t ld, float temperature, float ce_weight, float kl_weight, float grad_scale,
+                               float* losses, void* dlogits, float* row_ce, float* row_kl, int32_t* counts,
+                               void* stream) {
+    return distill_loss_launch(s_logits, t_logits, labels, rows, V, ld, temperature, ce_weight, kl_weight, nullptr, grad_scale,
+                               losses, dlogits, row_ce, row_kl, counts, stream);
+}
+
+// The same with the loss mix (ce_weight, kl_weight) read from DEVICE memory (f32[2]): the weights of a caller whose mix is the
+// result of device arithmetic -- autograd's upstream gradients of the reference's own loss lines (run_distillation.py:1486-1493
+// over distil_whisper_amd.modeling.LazyLogits) -- without a host round trip.
+extern "C" int dw_distill_loss_w(const void* s_logits, const void* t_logits, const int64_t* labels, int rows, int V,
+                                 int64_t ld, float temperature, const float* weights, float grad_scale, float* losses,
+                                 void* dlogits, float* row_ce, float* row_kl, int32_t* counts, void* stream) {
+    if (!weights || ((uintptr_t)weights & 3)) return DW_EINVAL;
+    return distill_loss_launch(s_logits, t_logits, labels, rows, V, ld, temperature, 0.f, 0.f, weights, grad_scale, losses,
+                               dlogits, row_ce, row_kl, counts, stream);
 }

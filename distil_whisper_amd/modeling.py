@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .engine import ParamStore, WhisperDims, WhisperEngine
+from .lazy_logits import LazyLogits, LazyState, _CEFn, _FusedFn, lazy_backward
 from .student_init import mel_filter_bank, random_state_dict
 
 
@@ -39,6 +40,7 @@ class Seq2SeqLMOutput:
     _logits_lowp: Optional[torch.Tensor] = None
     _model: Optional[object] = None
     _rows: Optional[object] = None      # _RowSel of a forward called with valid_len (rows of _logits_lowp), else None
+    _lazy: Optional[object] = None      # lazy_logits.LazyState shared by `.logits`, `.loss` and the engine node's backward
 
 
 @dataclass
@@ -381,14 +383,20 @@ class _EngineFn(torch.autograd.Function):
         V = eng.dims.vocab
         if sel is None:
             logits, dctx = eng.decode(decoder_input_ids.contiguous(), enc, save=train)
-            out_logits = logits[: B * T, :V].float().view(B, T, V)       # accelerate upcasts model outputs to fp32
         else:
             # the dead decoder positions are left out (same loss, same gradients: distill.trim_dead_positions)
             logits, dctx = eng.decode(decoder_input_ids[:, :sel.Te].contiguous(), enc, save=train, live=sel.live)
-            out_logits = sel.expand(logits, V)
+        # `.logits` keeps the reference's type and shape -- fp32 [B, T, V], accelerate upcasts model outputs to fp32 -- but the
+        # allocation is left UNFILLED: the values stay in the engine's bf16 buffer until something other than the reference's
+        # own loss expression reads them (lazy_logits.LazyLogits; the wrapper is put on by `forward`, which owns the state)
+        out_logits = torch.empty((B, T, V), dtype=torch.float32, device=logits.device)
+        state = LazyState(model, logits, sel, (B, T, V), train)
+        ctx.set_materialize_grads(False)
         ctx.model, ctx.ectx, ctx.dctx, ctx.shape, ctx.sel = model, ectx, dctx, (B, T, V), sel
         ctx.logits_buf = logits if train else None
+        ctx.lazy = state
         model._last_logits_lowp = logits
+        model._last_lazy_state = state
         Re = B * eng.dims.max_src
         enc_out = enc[:Re].float().view(B, eng.dims.max_src, -1)
         ctx.mark_non_differentiable(enc_out)
@@ -400,11 +408,14 @@ class _EngineFn(torch.autograd.Function):
         B, T, V = ctx.shape
         st = eng.st
         buf = ctx.logits_buf
-        buf.zero_()
-        if ctx.sel is None:
-            buf[: B * T, :V].copy_(g_logits.reshape(B * T, V))
-        else:
-            buf[: ctx.sel.n, :V].copy_(ctx.sel.select(g_logits.reshape(B * T, V)))
+        if not lazy_backward(ctx.lazy, buf, g_logits):
+            # no loss node left its upstream gradient behind: the caller differentiated through the materialised tensor
+            buf.zero_()
+            if g_logits is not None:
+                if ctx.sel is None:
+                    buf[: B * T, :V].copy_(g_logits.reshape(B * T, V))
+                else:
+                    buf[: ctx.sel.n, :V].copy_(ctx.sel.select(g_logits.reshape(B * T, V)))
         eng.zero_small_grads()
         denc = eng.backward_decoder(ctx.dctx, buf, want_denc=ctx.ectx is not None)
         if ctx.ectx is not None:
@@ -417,36 +428,6 @@ class _EngineFn(torch.autograd.Function):
         for name, p in zip(model._param_names, model._param_list):
             grads.append(st.g[name].clone() if (p.requires_grad and name in st.g) else None)
         return (None, None, None, None, None, *grads)
-
-
-class _FusedLossFn(torch.autograd.Function):
-    """CE (+ optionally the KL distillation term against teacher logits) of the engine's low-precision logits in ONE
-    pass of the fused loss kernel (dw_distill_loss) instead of log_softmax / softmax / KLDivLoss over three fp32
-    [B, T, V] temporaries (run_distillation.py:1486-1493, TF:modeling_whisper.py:1083-1087).  `logits` (the fp32 output
-    of the model, same values) only ties the node into the autograd graph; the kernel reads the bf16 buffer.  Backward
-    returns d(loss)/d(logits) -- computed by the same kernel pass -- as an fp32 [B, T, V] tensor, which is what
-    autograd would hand to the model's backward anyway."""
-
-    @staticmethod
-    def forward(ctx, logits, ops, s_buf, t_buf, labels, V, temperature, ce_weight, kl_weight, sel=None):
-        B, T = labels.shape
-        R = B * T if sel is None else sel.n
-        lab = (labels.reshape(-1) if sel is None else sel.select(labels.reshape(-1, 1)).reshape(-1)).contiguous()
-        need = ctx.needs_input_grad[0]      # (grad mode is off inside Function.forward; this is the real signal)
-        grad = ops.empty(tuple(s_buf[:R].shape), s_buf.dtype) if need else None
-        t_rows = s_buf[:R] if t_buf is None else t_buf[:R]
-        losses = ops.distill_loss(s_buf[:R], t_rows, lab, V, temperature, ce_weight, kl_weight if t_buf is not None else 0.0,
-                                  1.0, need, grad_out=grad)
-        ctx.grad, ctx.shape, ctx.sel = grad, (B, T, V), sel
-        ctx.mark_non_differentiable(losses)
-        total = losses[2] if t_buf is not None else losses[0]
-        return total.clone(), losses
-
-    @staticmethod
-    def backward(ctx, g_total, _g_losses):
-        B, T, V = ctx.shape
-        g = ctx.grad[:, :V].float().view(B, T, V) if ctx.sel is None else ctx.sel.expand(ctx.grad, V)
-        return (g * g_total, None, None, None, None, None, None, None, None, None)
 
 
 def fused_distillation_loss(student_outputs, teacher_outputs, labels, temperature=2.0, kl_weight=1.0, ce_weight=0.8):
@@ -471,8 +452,13 @@ def fused_distillation_loss(student_outputs, teacher_outputs, labels, temperatur
     elif (sel is None) != (t_sel is None) or (sel is not None and not sel.same_as(t_sel)):
         raise ValueError("fused_distillation_loss: student and teacher outputs were computed over different decoder "
                          "positions (pass the same valid_len to both forwards, or none to the teacher)")
-    loss, losses = _FusedLossFn.apply(student_outputs.logits, model.ops, s_buf, t_buf, labels, model.dims.vocab,
-                                      float(temperature), float(ce_weight), float(kl_weight), sel)
+    state = student_outputs._lazy
+    B, T = labels.shape
+    R = state.rows
+    lab = state.select_rows(labels.reshape(B * T, 1)).reshape(-1).contiguous()
+    t_rows = t_buf[:R]
+    loss, losses = _FusedFn.apply(student_outputs.logits.as_subclass(torch.Tensor), state, t_rows, lab, float(temperature),
+                                  float(ce_weight), float(kl_weight))
     return loss, {"loss": losses[2], "ce_loss": losses[0], "kl_loss": losses[1]}
 
 
@@ -665,12 +651,18 @@ class WhisperForConditionalGeneration(nn.Module):
         sel = _RowSel.make(valid_len, decoder_input_ids.shape[0], decoder_input_ids.shape[1], decoder_input_ids.device)
         logits, enc = _EngineFn.apply(self, input_features, enc_in, decoder_input_ids, sel, *self._param_list)
         lowp, self._last_logits_lowp = self._last_logits_lowp, None
+        state, self._last_lazy_state = self._last_lazy_state, None
         loss = None
         if labels is not None:
-            # token-mean CE over labels != -100 (TF:modeling_whisper.py:1083-1087) by the fused loss kernel
-            loss, _ = _FusedLossFn.apply(logits, self.ops, lowp, None, labels, d.vocab, 1.0, 1.0, 0.0, sel)
-        return Seq2SeqLMOutput(loss=loss, logits=logits, encoder_last_hidden_state=enc, _logits_lowp=lowp, _model=self,
-                               _rows=sel)
+            # token-mean CE over labels != -100 (TF:modeling_whisper.py:1083-1087) by a forward-only pass of the fused loss
+            # kernel; its gradient is produced -- together with the KD term's, if the caller adds one -- by the engine
+            # node's backward (lazy_logits.lazy_backward)
+            state.labels = labels
+            B, T = labels.shape
+            lab = state.select_rows(labels.reshape(B * T, 1)).reshape(-1).contiguous()
+            loss = _CEFn.apply(logits, state, lab)
+        return Seq2SeqLMOutput(loss=loss, logits=LazyLogits.wrap(logits, state), encoder_last_hidden_state=enc,
+                               _logits_lowp=lowp, _model=self, _rows=sel, _lazy=state)
 
     @torch.no_grad()
     def generate(self, input_features=None, generation_config=None, logits_processor=None, stopping_criteria=None,

@@ -70,6 +70,8 @@ _SIGS = {
     "dw_distill_loss": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float,
                          C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                          C.c_void_p], C.c_int),
+    "dw_distill_loss_w": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p,
+                           C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
     "dw_embed_fwd": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_void_p], C.c_int),
     "dw_embed_bwd": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p], C.c_int),
@@ -420,9 +422,10 @@ class HipOps:
         return dq, dk, dv
 
     def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad,
-                     grad_out=None):
+                     grad_out=None, weights_dev=None):
         """Returns losses f32[4] = (ce, kl, total, n_valid).  With want_grad the gradient w.r.t. the student logits
-        overwrites s_logits in place (bf16), or goes to `grad_out` (same shape and dtype) when that is given."""
+        overwrites s_logits in place (bf16), or goes to `grad_out` (same shape and dtype) when that is given.
+        `weights_dev` (f32[2] on the device) replaces (ce_weight, kl_weight): dw_distill_loss_w."""
         rows, ld = s_logits.shape
         if grad_out is not None:
             assert want_grad and grad_out.shape == s_logits.shape and grad_out.dtype == torch.bfloat16 and grad_out.is_contiguous()
@@ -433,9 +436,15 @@ class HipOps:
         row_ce = self.empty((rows,), torch.float32)
         row_kl = self.empty((rows,), torch.float32)
         counts = self.empty((2,), torch.int32)
+        dl = (_p(s_logits) if grad_out is None else _p(grad_out)) if want_grad else None
+        if weights_dev is not None:
+            assert weights_dev.dtype == torch.float32 and weights_dev.numel() == 2 and weights_dev.is_contiguous()
+            self._chk(self.lib.dw_distill_loss_w(_p(s_logits), _p(t_logits), _p(labels), rows, V, ld, float(temperature),
+                                                 _p(weights_dev), float(grad_scale), _p(losses), dl, _p(row_ce), _p(row_kl),
+                                                 _p(counts), self._stream()), "distill_loss_w")
+            return losses
         self._chk(self.lib.dw_distill_loss(_p(s_logits), _p(t_logits), _p(labels), rows, V, ld, float(temperature),
-                                           float(ce_weight), float(kl_weight), float(grad_scale), _p(losses),
-                                           (_p(s_logits) if grad_out is None else _p(grad_out)) if want_grad else None,
+                                           float(ce_weight), float(kl_weight), float(grad_scale), _p(losses), dl,
                                            _p(row_ce), _p(row_kl), _p(counts),
                                            self._stream()), "distill_loss")
         return losses

@@ -166,6 +166,13 @@ int dw_attn_bwd_ex(const void* q, const void* k, const void* v, const void* o, c
 int dw_distill_loss(const void* s_logits, const void* t_logits, const int64_t* labels, int rows, int V, int64_t ld,
                     float temperature, float ce_weight, float kl_weight, float grad_scale, float* losses,
                     void* dlogits, float* row_ce, float* row_kl, int32_t* counts, void* stream);
+/* The same with the mix {ce_weight, kl_weight} read from DEVICE memory (`weights`: f32[2]) by the gradient pass and the
+ * total: for a caller whose weights are device scalars -- the upstream gradients autograd hands to the reference's own loss
+ * lines `0.8 * ce_loss + kl_weight * kl_loss` (run_distillation.py:1486-1493) when they run over the drop-in modules' lazy
+ * logits (distil_whisper_amd.modeling.LazyLogits) -- no host round trip, graph-capturable. */
+int dw_distill_loss_w(const void* s_logits, const void* t_logits, const int64_t* labels, int rows, int V, int64_t ld,
+                      float temperature, const float* weights, float grad_scale, float* losses, void* dlogits,
+                      float* row_ce, float* row_kl, int32_t* counts, void* stream);
 
 /* ---- embeddings (TF:modeling_whisper.py:675-676, 736-762) ------------------------------------------------------
  * out[b*T+t][:] = tok[ids[b*T+t]][:] + pos[t][:]; tables f32 or bf16 (tab_dtype); out f32 or bf16. */

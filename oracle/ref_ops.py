@@ -197,7 +197,9 @@ class RefOps:
 
     # run_distillation.py:1453-1462, 1486-1493 + CrossEntropyLoss (TF:modeling_whisper.py:1083-1087), verbatim math
     def distill_loss(self, s_logits, t_logits, labels, V, temperature, ce_weight, kl_weight, grad_scale, want_grad,
-                     grad_out=None):
+                     grad_out=None, weights_dev=None):
+        if weights_dev is not None:        # dw_distill_loss_w: the mix comes from device memory
+            ce_weight, kl_weight = weights_dev[0].detach(), weights_dev[1].detach()
         with torch.enable_grad():      # (callers may sit inside an autograd.Function.forward, where grad mode is off)
             zs = s_logits[:, :V].float().detach().requires_grad_(want_grad)
             zt = t_logits[:, :V].float().detach()

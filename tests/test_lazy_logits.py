@@ -1,0 +1,211 @@
+"""distil_whisper_amd.lazy_logits: `.logits` of the drop-in model is a tensor whose fp32 [B, T, V] storage stays unfilled while
+the reference's own loss lines (run_distillation.py:1453-1462, 1486-1493) run over it -- they are answered by the fused
+loss kernel -- and is filled from the engine's bf16 buffer the moment anything else reads it.  CPU (`-m "not gpu"`, the torch
+restatement of the kernels): the lazy answers and gradients equal the ones obtained by materialising first and running the
+same lines on plain tensors; every "anything else" path is exact; misuse is loud."""
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import whisper_oracle as wo
+from oracle.ref_ops import RefOps
+from distil_whisper_amd import lazy_logits
+from distil_whisper_amd import modeling as M
+
+
+def relerr(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def kl_divergence(target_distribution, log_predicted_distribution, labels):
+    """run_distillation.py:1453-1462"""
+    kl_loss = nn.KLDivLoss(reduction="none")
+    divergence = kl_loss(log_predicted_distribution, target_distribution)
+    padding_mask = labels >= 0
+    padding_mask = padding_mask.unsqueeze(-1)
+    divergence = divergence * padding_mask
+    divergence = divergence.sum() / padding_mask.sum()
+    return divergence
+
+
+def reference_lines(student_outputs, teacher_outputs, labels, temperature=2.0, kl_weight=0.7, s_logits=None, t_logits=None):
+    """run_distillation.py:1486-1493 (over `.logits`, or over the given plain tensors)"""
+    s = student_outputs.logits if s_logits is None else s_logits
+    t = teacher_outputs.logits if t_logits is None else t_logits
+    ce_loss = student_outputs.loss
+    teacher_distribution = nn.functional.softmax(t / temperature, dim=-1)
+    student_distribution = nn.functional.log_softmax(s / temperature, dim=-1)
+    kl_loss = kl_divergence(teacher_distribution, student_distribution, labels) * temperature ** 2
+    loss = 0.8 * ce_loss + kl_weight * kl_loss
+    return loss, ce_loss, kl_loss
+
+
+@pytest.fixture()
+def setup():
+    cfg_t = wo.CONFIGS["micro"]
+    t_sd = wo.init_state_dict(cfg_t, 31)
+    s_sd, cfg_s = wo.student_from_teacher(t_sd, cfg_t, 2, 1)
+    b = wo.synthetic_batch(cfg_t, 3, seed=32, T=21, with_audio=False)
+    feats = torch.randn(3, cfg_t.n_mels, 3000, generator=torch.Generator().manual_seed(33)) * 0.5
+    batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"], "labels": b["labels"]}
+
+    def models():
+        ops = RefOps("cpu", lowp=torch.float32)
+        return (M.WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd),
+                M.WhisperForConditionalGeneration(cfg_t, ops=ops, state_dict=t_sd))
+    return models, batch, cfg_t
+
+
+def grads(model):
+    return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_reference_lines_on_lazy_logits_equal_the_same_lines_on_materialised_tensors(setup):
+    models, batch, _ = setup
+    labels = batch["labels"]
+    # (a) lazy: the lines as the script has them
+    s, t = models()
+    before = dict(lazy_logits.STATS)
+    so = s(**batch)
+    with torch.no_grad():
+        to = t(**batch)
+    assert isinstance(so.logits, lazy_logits.LazyLogits) and so.logits.shape == (3, 21, s.dims.vocab) and so.logits.dtype == torch.float32
+    assert so.logits.requires_grad and not to.logits.requires_grad
+    loss, ce, kl = reference_lines(so, to, labels)
+    loss.backward()
+    d = {k: lazy_logits.STATS[k] - before[k] for k in before}
+    assert d == {"lazy_sums": 1, "fills": 0, "lazy_backwards": 1}, d
+    assert not so._lazy.filled and not to._lazy.filled
+    g_lazy = grads(s)
+    # (b) eager: materialise both first, the same lines on the plain tensors
+    s2, t2 = models()
+    so2 = s2(**batch)
+    with torch.no_grad():
+        to2 = t2(**batch)
+    sl, tl = so2.logits.materialize(), to2.logits.materialize()
+    assert type(sl) is torch.Tensor and so2._lazy.filled
+    loss2, ce2, kl2 = reference_lines(so2, to2, labels, s_logits=sl, t_logits=tl)
+    loss2.backward()
+    g_eager = grads(s2)
+    assert abs(loss.item() - loss2.item()) < 1e-5 * abs(loss2.item())
+    assert abs(kl.item() - kl2.item()) < 1e-5 * abs(kl2.item()) and ce.item() == ce2.item()
+    assert set(g_lazy) == set(g_eager)
+    for n in g_eager:
+        assert relerr(g_lazy[n], g_eager[n]) < 2e-5, n
+
+
+def test_every_other_use_reads_exactly_the_eager_values(setup):
+    models, batch, cfg = setup
+    s, _ = models()
+    with torch.no_grad():
+        out = s(**batch)
+    V = s.dims.vocab
+    ref = out._logits_lowp[: 3 * 21, :V].float().view(3, 21, V)
+    lz = out.logits
+    before = lazy_logits.STATS["fills"]
+    assert lz.shape == ref.shape and lz.dim() == 3 and lz.size(-1) == V and lz.numel() == ref.numel() and not lz.is_cuda
+    assert lz.float() is lz and lz.to(torch.float32) is lz           # already fp32: still lazy
+    assert lazy_logits.STATS["fills"] == before and not out._lazy.filled
+    assert torch.equal(lz.argmax(-1), ref.argmax(-1))
+    assert lazy_logits.STATS["fills"] == before + 1 and out._lazy.filled
+    assert torch.equal(lz[:, 0], ref[:, 0]) and torch.equal(lz[1, 2:5, ::7], ref[1, 2:5, ::7])
+    assert torch.equal(torch.cat([lz, lz], 0), torch.cat([ref, ref], 0))
+    assert torch.equal(lz + 1.0, ref + 1.0) and torch.equal(2.0 * lz, 2.0 * ref) and torch.equal(lz / 3.0, ref / 3.0)
+    assert torch.equal(lz.sum(-1), ref.sum(-1)) and lz.mean().item() == ref.mean().item()
+    assert torch.equal(lz.detach().clone(), ref) and torch.equal(lz.to(torch.float64), ref.double())
+    assert torch.equal(torch.softmax(lz, 1), torch.softmax(ref, 1))                       # another dim: eager
+    assert torch.equal(nn.functional.log_softmax(lz, dim=-1).exp(), nn.functional.log_softmax(ref, dim=-1).exp())
+    assert type(lz + 1.0) is torch.Tensor and "tensor" in repr(lz)
+    assert lazy_logits.STATS["fills"] == before + 1                  # one fill serves all of them
+
+
+@pytest.mark.parametrize("variant", ["tensor_temperature", "batchmean", "mask_2d", "dim_first", "extra_term"])
+def test_expressions_outside_the_recognised_one_fall_back_exactly(setup, variant):
+    """Anything that is not the reference's expression is computed by torch on the filled tensors: same numbers and
+    gradients as on plain tensors."""
+    models, batch, _ = setup
+    labels = batch["labels"]
+
+    def lines(s, t, ce):
+        T = 2.0
+        if variant == "tensor_temperature":
+            Tt = torch.tensor(2.0)
+            return 0.8 * ce + (nn.functional.kl_div(nn.functional.log_softmax(s / Tt, -1), nn.functional.softmax(t / Tt, -1),
+                                                    reduction="none") * (labels >= 0).unsqueeze(-1)).sum()
+        if variant == "batchmean":
+            return 0.8 * ce + nn.functional.kl_div(nn.functional.log_softmax(s / T, -1), nn.functional.softmax(t / T, -1), reduction="batchmean")
+        if variant == "mask_2d":
+            d = nn.functional.kl_div(nn.functional.log_softmax(s / T, -1), nn.functional.softmax(t / T, -1), reduction="none")
+            return 0.8 * ce + (d.sum(-1) * (labels >= 0)).sum()
+        if variant == "dim_first":
+            return 0.8 * ce + nn.functional.kl_div(nn.functional.log_softmax(s / T, 1), nn.functional.softmax(t / T, 1), reduction="none").sum()
+        d = nn.functional.kl_div(nn.functional.log_softmax(s / T, -1), nn.functional.softmax(t / T, -1), reduction="none")
+        return 0.8 * ce + (d * (labels >= 0).unsqueeze(-1)).sum() / (labels >= 0).sum() + 1e-3 * (s * s).mean()     # lazy sum + a real use
+
+    res = []
+    for mat in (False, True):
+        s, t = models()
+        so = s(**batch)
+        with torch.no_grad():
+            to = t(**batch)
+        sl, tl = (so.logits.materialize(), to.logits.materialize()) if mat else (so.logits, to.logits)
+        loss = lines(sl, tl, so.loss)
+        loss.backward()
+        res.append((loss.item(), grads(s)))
+    (l0, g0), (l1, g1) = res
+    assert abs(l0 - l1) < 1e-5 * abs(l1), (variant, l0, l1)
+    for n in g1:
+        assert relerr(g0[n], g1[n]) < 2e-5, (variant, n)
+
+
+def test_ce_only_eval_mode_valid_len_and_a_mask_that_is_not_the_labels(setup):
+    models, batch, _ = setup
+    labels = batch["labels"]
+    # CE alone: `.loss.backward()` -- the engine node gets no [B, T, V] gradient, the kernel produces it
+    s, t = models()
+    before = dict(lazy_logits.STATS)
+    so = s(**batch)
+    so.loss.backward()
+    assert lazy_logits.STATS["lazy_backwards"] == before["lazy_backwards"] + 1 and lazy_logits.STATS["fills"] == before["fills"]
+    g_ce = grads(s)
+    s2, _ = models()
+    so2 = s2(**batch)
+    ce2 = nn.functional.cross_entropy(so2.logits.materialize().view(-1, s2.dims.vocab), labels.view(-1), ignore_index=-100)
+    ce2.backward()
+    assert abs(so.loss.item() - ce2.item()) < 1e-5 * ce2.item()
+    for n, g in grads(s2).items():
+        assert relerr(g_ce[n], g) < 2e-5, n
+    # eval_step's lines under no_grad, temperature 1 (run_distillation.py:1498-1522)
+    with torch.no_grad():
+        so, to = s(**batch), t(**batch)
+        kl = kl_divergence(nn.functional.softmax(to.logits, dim=-1), nn.functional.log_softmax(so.logits, dim=-1), labels)
+        kl_ref = kl_divergence(nn.functional.softmax(to.logits.materialize(), dim=-1),
+                               nn.functional.log_softmax(so.logits.materialize(), dim=-1), labels)
+    assert abs(kl.item() - kl_ref.item()) < 1e-5 * abs(kl_ref.item())
+    # dead decoder positions left out (valid_len per sequence): the lazy lines see the same loss as the full forward
+    lens = [int((row != -100).nonzero().max()) + 1 for row in labels]
+    s3, t3 = models()
+    so3 = s3(**batch, valid_len=lens)
+    with torch.no_grad():
+        to3 = t3(**batch, valid_len=lens)
+    l3, _, _ = reference_lines(so3, to3, labels)
+    s4, t4 = models()
+    so4 = s4(**batch)
+    with torch.no_grad():
+        to4 = t4(**batch)
+    l4, _, _ = reference_lines(so4, to4, labels)
+    assert abs(l3.item() - l4.item()) < 1e-5 * abs(l4.item())
+    l3.backward()
+    l4.backward()
+    g3, g4 = grads(s3), grads(s4)
+    for n in g4:
+        assert relerr(g3[n], g4[n]) < 2e-5, n
+    # a mask that is not `labels >= 0`: the fused pass is keyed on the labels, so the answer is NaN, never silently wrong
+    s5, t5 = models()
+    so5 = s5(**batch)
+    with torch.no_grad():
+        to5 = t5(**batch)
+    other = torch.ones_like(labels, dtype=torch.bool).unsqueeze(-1)
+    d = nn.KLDivLoss(reduction="none")(nn.functional.log_softmax(so5.logits / 2.0, dim=-1), nn.functional.softmax(to5.logits / 2.0, dim=-1))
+    assert torch.isnan((d * other).sum())

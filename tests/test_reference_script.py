@@ -176,8 +176,15 @@ def test_script_text_over_drop_in_equals_script_text_over_transformers(freeze_en
         ev = {k: float(v) for k, v in ns["eval_step"](batches[0]).items()}
         return ns, s, out, ev
 
+    from distil_whisper_amd import lazy_logits
     ns0, s0, out0, ev0 = run("hf")
+    before = dict(lazy_logits.STATS)
     ns1, s1, out1, ev1 = run("drop-in")
+    # The script's five loss lines (1486-1493) ran UNEDITED over the drop-in's lazy `.logits`: every `divergence.sum()` (three
+    # train steps + one eval step) was answered by the fused kernel, no fp32 [B, T, V] tensor was ever filled, and every
+    # backward took d(loss)/d(logits) from the kernel instead of autograd's passes over the temporaries.
+    d = {k: lazy_logits.STATS[k] - before[k] for k in before}
+    assert d == {"lazy_sums": 4, "fills": 0, "lazy_backwards": 3}, d
     assert type(ns1["optimizer"]).__name__ == "AcceleratedOptimizer"
     for m0, m1 in zip(out0, out1):
         for k in ("loss", "ce_loss", "kl_loss"):
