@@ -485,8 +485,10 @@ def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_hos
         student.freeze_encoder()
     out = {"steps": steps, "warmup": warm, "optimizer": "torch.optim.AdamW (two groups) + clip_grad_norm_", "unit": "ms/step"}
 
-    def leg(with_len, fused, fused_opt=False):
+    def leg(with_len, fused, fused_opt=False, skip_dead=False):
         import functools
+        # (DW_SKIP_DEAD_POSITIONS=1 in the environment of the unedited script sets this class attribute at import)
+        student.skip_dead_positions = teacher.skip_dead_positions = bool(skip_dead)
         from distil_whisper_amd.optim import FusedAdamW
         loop = ReferenceLoop(student, teacher, M.BaseModelOutput, share_hidden_states=recipe, teacher_dtype=torch.bfloat16,
                              fused_loss=M.fused_distillation_loss if fused else None,
@@ -514,6 +516,9 @@ def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_hos
     # (the loop's own softmax / log_softmax / KLDivLoss lines run over the drop-in's lazy `.logits`: answered by the fused loss
     # kernel, no fp32 [B, T, V] temporaries -- distil_whisper_amd/lazy_logits.py; the counters say whether that happened)
     out["verbatim"]["lazy_logits"] = {k: lazy_logits.STATS[k] - before[k] for k in before}
+    # the unedited loop again with DW_SKIP_DEAD_POSITIONS=1: the models read the label lengths back from `labels` themselves
+    # (behind the encoder's launches) and leave the dead decoder positions out -- no collator change, no `valid_len` in the batch
+    out["verbatim_env_DW_SKIP_DEAD_POSITIONS"] = leg(False, False, skip_dead=True)
     # the same loop body with distil_whisper_amd.optim.FusedAdamW in place of torch.optim.AdamW and its clip_grad_norm_ in
     # place of accelerator.clip_grad_norm_ (two changed lines of the script; same parameter groups, same LambdaLR)
     out["verbatim_with_fused_optimizer"] = leg(False, False, True)

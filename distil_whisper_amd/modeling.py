@@ -12,6 +12,7 @@ them) and error behaviour, but every tensor operation runs in the HIP kernels th
 Parameters are views into the engine's flat fp32 master buffer, so `optimizer.step()`, `save_pretrained`-style
 `state_dict()`, `load_state_dict()` and DistributedDataParallel all work on them unchanged.
 """
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -363,6 +364,48 @@ class _RowSel:
         return out
 
 
+class _PendingLens:
+    """The label lengths of a batch on their way to the host (`WhisperForConditionalGeneration.skip_dead_positions`).
+
+    The reference hands the model `labels` padded to 448 with -100 (run_distillation.py:405-478) and computes all 447
+    decoder positions of every row; positions behind a row's last label are dead (distill.trim_dead_positions: same loss,
+    same gradients without them -- 71 % of the benchmark's decoder positions).  Leaving them out needs the lengths ON THE
+    HOST (they size the launches), and the drop-in collator can put them into the batch (`report_valid_len`) -- but that is
+    an edit of the script.  Without it the lengths are read back from the device tensor the model is given: a tiny reduction
+    and a non-blocking copy into pinned memory are enqueued FIRST, the whole encoder forward (which does not depend on them)
+    is enqueued next, and only then the host waits for the copy's event -- by which time the device has >= 100 ms of encoder
+    work queued, so the wait costs the host its run-ahead over the previous step and the device nothing.  The second model
+    called with the same `labels` tensor (the teacher: `teacher_model(**batch)` / `(encoder_outputs=..., labels=...)`) finds
+    the lengths in a one-entry cache keyed by the tensor's address, shape and version: no second round trip."""
+
+    _cache = {}
+
+    def __init__(self, labels):
+        self.key = (labels.data_ptr(), tuple(labels.shape), labels._version, str(labels.device))
+        self.lens = _PendingLens._cache.get(self.key)
+        self.event = None
+        if self.lens is None:
+            T = labels.shape[1]
+            pos = torch.arange(1, T + 1, device=labels.device)
+            lens_dev = ((labels != -100) * pos).amax(dim=1)
+            if labels.is_cuda:
+                self.host = torch.empty(labels.shape[0], dtype=torch.int64, pin_memory=True)
+                self.host.copy_(lens_dev, non_blocking=True)
+                self.event = torch.cuda.Event()
+                self.event.record()
+            else:
+                self.host = lens_dev
+
+    def resolve(self):
+        if self.lens is None:
+            if self.event is not None:
+                self.event.synchronize()
+            self.lens = [max(1, int(x)) for x in self.host.tolist()]
+            _PendingLens._cache.clear()
+            _PendingLens._cache[self.key] = self.lens
+        return self.lens
+
+
 class _EngineFn(torch.autograd.Function):
     """forward: engine encode+decode with activations kept; backward: engine backward from d(loss)/d(logits) (and
     optionally d/d(encoder_last_hidden_state)); parameter gradients are returned as views of the flat buffer."""
@@ -381,6 +424,9 @@ class _EngineFn(torch.autograd.Function):
             enc[:rows].copy_(enc_in.reshape(rows, -1))
         B, T = decoder_input_ids.shape
         V = eng.dims.vocab
+        if isinstance(sel, _PendingLens):       # label lengths read back from the device: the encoder is queued, now wait
+            sel = _RowSel.make(sel.resolve(), B, T, decoder_input_ids.device)
+        model._last_sel = sel
         if sel is None:
             logits, dctx = eng.decode(decoder_input_ids.contiguous(), enc, save=train)
         else:
@@ -467,6 +513,13 @@ class WhisperForConditionalGeneration(nn.Module):
     student under `accelerate` bf16 autocast (SURVEY.md section 8a').  dtype=torch.bfloat16: weights rounded to bf16
     and a bf16 residual stream -- a model loaded with `torch_dtype=torch.bfloat16` (the teacher of
     run_distillation.py:986-1004, every model of run_eval.py / run_pseudo_labelling.py); inference only."""
+
+    # `forward(..., labels=...)` without `valid_len`: read the label lengths back from `labels` and leave the dead decoder
+    # positions out (_PendingLens).  Same loss and gradients under the reference's loss lines (CE ignores -100, the KL term is
+    # masked by labels >= 0); `.logits` then has ZERO rows behind each row's last label, which a caller that looks at padded
+    # positions would see -- so it is OFF unless asked for: `DW_SKIP_DEAD_POSITIONS=1` in the environment of the unedited
+    # script, or `model.skip_dead_positions = True`.
+    skip_dead_positions = os.environ.get("DW_SKIP_DEAD_POSITIONS", "0") not in ("", "0", "false", "False")
 
     def __init__(self, config, ops=None, device="cuda:0", state_dict=None, seed=0, frozen_prefixes=(),
                  dtype=torch.float32):
@@ -648,8 +701,14 @@ class WhisperForConditionalGeneration(nn.Module):
             raise ValueError(f"Whisper expects the mel input features to be of length {2 * d.max_src}, but found "
                              f"{input_features.shape[-1]}. Make sure to pad the input mel features to {2 * d.max_src}.")
         self._sync_shadow()
-        sel = _RowSel.make(valid_len, decoder_input_ids.shape[0], decoder_input_ids.shape[1], decoder_input_ids.device)
+        if valid_len is None and labels is not None and self.skip_dead_positions and labels.shape == decoder_input_ids.shape:
+            sel = _PendingLens(labels)           # (resolved inside _EngineFn.forward, behind the encoder's launches)
+            if sel.lens is not None:             # the other model already fetched them for this very tensor
+                sel = _RowSel.make(sel.lens, decoder_input_ids.shape[0], decoder_input_ids.shape[1], decoder_input_ids.device)
+        else:
+            sel = _RowSel.make(valid_len, decoder_input_ids.shape[0], decoder_input_ids.shape[1], decoder_input_ids.device)
         logits, enc = _EngineFn.apply(self, input_features, enc_in, decoder_input_ids, sel, *self._param_list)
+        sel, self._last_sel = self._last_sel, None
         lowp, self._last_logits_lowp = self._last_logits_lowp, None
         state, self._last_lazy_state = self._last_lazy_state, None
         loss = None

@@ -101,7 +101,7 @@ def test_every_other_use_reads_exactly_the_eager_values(setup):
     with torch.no_grad():
         out = s(**batch)
     V = s.dims.vocab
-    ref = out._logits_lowp[: 3 * 21, :V].float().view(3, 21, V)
+    ref = out._logits_lowp[: 3 * 21, :V].float().view(3, 21, V) if out._rows is None else out._rows.expand(out._logits_lowp, V)
     lz = out.logits
     before = lazy_logits.STATS["fills"]
     assert lz.shape == ref.shape and lz.dim() == 3 and lz.size(-1) == V and lz.numel() == ref.numel() and not lz.is_cuda
@@ -209,3 +209,42 @@ def test_ce_only_eval_mode_valid_len_and_a_mask_that_is_not_the_labels(setup):
     other = torch.ones_like(labels, dtype=torch.bool).unsqueeze(-1)
     d = nn.KLDivLoss(reduction="none")(nn.functional.log_softmax(so5.logits / 2.0, dim=-1), nn.functional.softmax(to5.logits / 2.0, dim=-1))
     assert torch.isnan((d * other).sum())
+
+
+def test_label_lengths_are_read_back_from_the_labels_when_the_batch_carries_none(setup):
+    """`skip_dead_positions` (DW_SKIP_DEAD_POSITIONS=1 or the attribute): `model(**batch)` with the reference's batch -- labels padded with -100, no
+    `valid_len` -- leaves the dead decoder positions out on its own.  Same loss and gradients as with the lengths given by
+    the collator and as with every position computed; `.logits` equals the full forward's at the live positions and is zero
+    behind each row's last label; the second model called with the same labels tensor takes the lengths from the cache."""
+    models, batch, _ = setup
+    labels = batch["labels"]
+    lens = [int((row != -100).nonzero().max()) + 1 for row in labels]
+    runs = {}
+    for mode in ("auto", "given", "off"):
+        s, t = models()
+        s.skip_dead_positions = t.skip_dead_positions = mode != "off"
+        M._PendingLens._cache.clear()
+        so = s(**batch, **({"valid_len": lens} if mode == "given" else {}))
+        if mode == "auto":
+            assert list(M._PendingLens._cache.values()) == [lens]
+        with torch.no_grad():
+            to = t(**batch, **({"valid_len": lens} if mode == "given" else {}))
+        assert (so._rows is None) == (mode == "off") and (to._rows is None) == (mode == "off")
+        loss, ce, kl = reference_lines(so, to, labels)
+        loss.backward()
+        runs[mode] = (loss.item(), grads(s), so.logits.materialize().detach().clone())
+    for mode in ("auto", "given"):
+        assert abs(runs[mode][0] - runs["off"][0]) < 1e-5 * abs(runs["off"][0]), mode
+        for n, g in runs["off"][1].items():
+            assert relerr(runs[mode][1][n], g) < 2e-5, (mode, n)
+    live = torch.arange(labels.shape[1])[None, :] < torch.tensor(lens)[:, None]
+    assert torch.equal(runs["auto"][2], runs["given"][2])
+    assert relerr(runs["auto"][2][live], runs["off"][2][live]) < 1e-6 and float(runs["auto"][2][~live].abs().max()) == 0.0
+    # a labels tensor modified in place is a new key (its version counter moved): no stale lengths
+    s, _ = models()
+    s.skip_dead_positions = True
+    lab2 = labels.clone()
+    s(input_features=batch["input_features"], decoder_input_ids=batch["decoder_input_ids"], labels=lab2)
+    lab2[:, 5:] = -100
+    out = s(input_features=batch["input_features"], decoder_input_ids=batch["decoder_input_ids"], labels=lab2)
+    assert out._rows.Te == 5

@@ -257,11 +257,14 @@ def test_fused_loss_with_shared_encoder_teacher_that_saw_no_valid_len(per_sequen
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_len", [False, True])
+@pytest.mark.parametrize("with_len", [False, True, "auto"])
 def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fixtures(with_len):
     """with_len: the batch also carries the per-sequence label lengths (`valid_len`, what the drop-in collator reports) and
     travels through `student_model(**batch)` / `teacher_model(**batch)` unchanged: the dead decoder positions are left out
-    and the fixture losses, gradient norm and parameters must come out all the same."""
+    and the fixture losses, gradient norm and parameters must come out all the same.  "auto": the reference's batch as it is,
+    the models read the lengths back from `labels` themselves (`skip_dead_positions`, what DW_SKIP_DEAD_POSITIONS=1 switches
+    on).  In every mode the loop's own softmax / log_softmax / KLDivLoss lines are answered by the fused loss kernel
+    (lazy `.logits`): no fp32 [B, T, V] tensor is filled."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     from distil_whisper_amd import modeling as M
     from distil_whisper_amd.ops_hip import HipOps
@@ -277,7 +280,7 @@ def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fix
     feats = fe([a for a in b["audio"]], sampling_rate=16000, return_tensors="pt").input_features
     assert feats.is_cuda and np.abs(feats[:, ::9, ::97].cpu().numpy() - g32["mel_slice"]).max() < 1e-4
     batch = {"input_features": feats, "decoder_input_ids": b["decoder_input_ids"].cuda(), "labels": b["labels"].cuda()}
-    if with_len:
+    if with_len is True:
         lab = b["labels"]
         batch["valid_len"] = [1 + int((row != -100).nonzero().max()) for row in lab]
         assert max(batch["valid_len"]) < lab.shape[1]          # (the fixture batch does have a dead tail)
@@ -293,6 +296,9 @@ def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fix
         for fused in (False, True):
             student = M.WhisperForConditionalGeneration(cfg_s, ops=ops, state_dict=s_sd)                    # fp32 master, bf16 compute
             teacher = M.WhisperForConditionalGeneration(cfg_t, ops=ops, state_dict=t_sd, dtype=torch.bfloat16)   # teacher_dtype
+            student.skip_dead_positions = teacher.skip_dead_positions = with_len == "auto"
+            from distil_whisper_amd import lazy_logits
+            stats0 = dict(lazy_logits.STATS)
             loop = ReferenceLoop(student, teacher, M.BaseModelOutput, teacher_dtype=torch.bfloat16,
                                  wrap=lambda m: DDP(m, device_ids=[0]),
                                  fused_loss=M.fused_distillation_loss if fused else None)
@@ -313,6 +319,10 @@ def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fix
             # the optimizer wrote the fp32 master weights; the next forward must see them (shadow refresh)
             m2, _ = loop.training_iteration(batch, temperature=2.0)
             assert m2["loss"].item() < metrics["loss"].item()
+            d = {k: lazy_logits.STATS[k] - stats0[k] for k in stats0}
+            assert d["fills"] == 0 and d["lazy_backwards"] == 2 and d["lazy_sums"] == (0 if fused else 3), (fused, d)
+            if with_len == "auto":
+                assert student._param_list and M._PendingLens._cache      # (the lengths came back from the device)
             results[fused] = (metrics, student.state_dict())
     (ma, sa), (mb, sb) = results[False], results[True]
     for k in ("loss", "ce_loss", "kl_loss"):
