@@ -320,7 +320,8 @@ def test_reference_loop_over_drop_in_classes_under_ddp_matches_the_reference_fix
             m2, _ = loop.training_iteration(batch, temperature=2.0)
             assert m2["loss"].item() < metrics["loss"].item()
             d = {k: lazy_logits.STATS[k] - stats0[k] for k in stats0}
-            assert d["fills"] == 0 and d["lazy_backwards"] == 2 and d["lazy_sums"] == (0 if fused else 3), (fused, d)
+            # (eval_step always runs the loop's own lines; the two training iterations do unless the one-call fused loss replaces them)
+            assert d["fills"] == 0 and d["lazy_backwards"] == 2 and d["lazy_sums"] == (1 if fused else 3), (fused, d)
             if with_len == "auto":
                 assert student._param_list and M._PendingLens._cache      # (the lengths came back from the device)
             results[fused] = (metrics, student.state_dict())
