@@ -25,6 +25,8 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_phased_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_phased.hip
 int dw_gemm_tile256_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile256.hip: 16 waves, 4 x 4
 int dw_gemm_tile128_launch(const GemmP& p, int ta, int tb, hipStream_t s);  // gemm_tile128.hip: 8 waves, 2 x 4
+int dw_gemm_tile128w4_launch(const GemmP& p, int ta, int tb, int var, hipStream_t s);  // gemm_tile128w4.hip: 4 waves, 2 x 2
+static int g_gemm_t128_w4 = 0;   // dw_debug_set key 24: 128-tile launches on the four-wave tile (1: plain K loop, 2: register double buffer)
 int dw_gemm_wp8_nn_ref_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_nn_ref.hip (builtin DMA; A/B only)
 int dw_gemm_wp8_nn320_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_m320.hip (320 x 256 block tile)
 int dw_gemm_wp8_nt320_launch(const GemmP& p, hipStream_t s);
@@ -126,6 +128,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 21) { g_ln_variant = value; return DW_OK; }
     if (key == 22) { g_gemm_row_tail = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
+    if (key == 24) { if (value < 0 || value > 2) return DW_EINVAL; g_gemm_t128_w4 = value; return DW_OK; }
     if (key == 23) { if (value < 0 || value > 64) return DW_EINVAL; g_attn_defer = value; return DW_OK; }
     if (key == 16) { g_attn_fwd_waves = value; return DW_OK; }
     if (key == 15) { g_attn_ablate = value; return DW_OK; }
@@ -368,5 +371,6 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         // second launch cannot start before the slowest workgroup of the first one has drained.)
         return launch256(p);
     }
+    if (g_gemm_t128_w4) return dw_gemm_tile128w4_launch(p, g->trans_a, g->trans_b, g_gemm_t128_w4, s);
     return dw_gemm_tile128_launch(p, g->trans_a, g->trans_b, s);
 }

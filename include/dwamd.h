@@ -323,7 +323,9 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *           row blocks alone need one round of the CUs less (default 1; bit-identical)
  *   key 23  attention forward: threshold (in powers of two) by which a tile maximum must exceed the running reference of
  *           the online softmax before the reference moves (default 8; 0 = the exact running maximum, the A/B leg of
- *           tests/test_sharp_parity_gpu.py) */
+ *           tests/test_sharp_parity_gpu.py)
+ *   key 24  128-tile launches on the four-wave tile (2 x 2 waves of 64 x 64; 1 plain K loop, 2 register double buffer;
+ *           default 0 = eight waves of 64 x 32; bit-identical) */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus

@@ -7,15 +7,16 @@ from distil_whisper_amd.distill import DistillationTrainer
 from distil_whisper_amd import student_init as si
 dev = "cuda:0"
 ops = HipOps(dev)
-tdims = si.PRESETS["large-v3"]
+MODEL = os.environ.get("MODEL", "large-v3")            # large-v3 | small.en | tiny.en (BASELINE configs 3 / 2 / 1)
+tdims = si.PRESETS[MODEL]
 t_sd = si.random_state_dict(tdims, 0, dev)
-s_sd, sdims = si.student_from_teacher(t_sd, tdims, 32, 2)
-filt = torch.tensor(si.mel_filter_bank(128), dtype=torch.float32, device=dev).contiguous()
+s_sd, sdims = si.student_from_teacher(t_sd, tdims, *si.STUDENT_LAYERS[MODEL])
+filt = torch.tensor(si.mel_filter_bank(tdims.n_mels), dtype=torch.float32, device=dev).contiguous()
 tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, mel_filters=filt)
 del t_sd, s_sd
 B, T = int(os.environ.get("B", 32)), 447
 audio = 0.1 * torch.randn(B, 480000, device=dev)
-ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
+ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = tdims.decoder_start_token_id
 dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
 def step():
     return tr.train_step(tr.features(audio), dec_in, labels)
@@ -33,7 +34,7 @@ for _ in range(2):
 ops.profile = None
 rows = sorted(acc.items(), key=lambda kv: -kv[1]["ms"])
 tot = sum(d["ms"] for _, d in rows) / 2
-print(f"# per-flavour launch times of one step (B={B}); instrumented step = {tot:.1f} ms\n")
+print(f"# per-flavour launch times of one {MODEL} step (B={B}); instrumented step = {tot:.1f} ms\n")
 print("| launch | calls/step | ms/step | avg us | TFLOP/s |\n|---|---|---|---|---|")
 for k, d in rows:
     tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
