@@ -56,9 +56,54 @@ def apply_timestamp_rules(scores, tokens, n, begin_index, no_timestamps_token_id
     return out
 
 
+def apply_repetition_penalty(scores, input_ids, penalty):
+    """`RepetitionPenaltyLogitsProcessor` (TF:generation/logits_process.py): the scores of every token already in the row's
+    sequence (prompt included) are divided by `penalty` when positive and multiplied when negative."""
+    sc = torch.gather(scores, 1, input_ids)
+    sc = torch.where(sc < 0, sc * penalty, sc / penalty)
+    return scores.scatter(1, input_ids, sc)
+
+
+def apply_no_repeat_ngram(scores, input_ids, n):
+    """`NoRepeatNGramLogitsProcessor`: a token that would complete an n-gram the row's sequence already contains is banned.
+    Vectorised: every window of n-1 tokens equal to the sequence's last n-1 tokens bans the token that followed it."""
+    B, L = input_ids.shape
+    if n <= 0 or L + 1 < n:
+        return scores
+    if n == 1:
+        return scores.scatter(1, input_ids, float("-inf"))
+    tail = input_ids[:, L - (n - 1):]                                     # [B, n-1]
+    win = input_ids.unfold(1, n - 1, 1)[:, : L - (n - 1)]                  # [B, L-n+1, n-1]: windows that HAVE a follower
+    hit = (win == tail[:, None, :]).all(-1)                               # [B, L-n+1]
+    follow = input_ids[:, n - 1:]                                          # [B, L-n+1]
+    # (several windows may name the same token: any hit bans it)
+    ban_any = torch.zeros_like(scores, dtype=torch.int32).scatter_add_(1, follow, hit.to(torch.int32)) > 0
+    return scores.masked_fill(ban_any, float("-inf"))
+
+
+def warp_and_sample(scores, temperature=None, top_k=None, top_p=None, generator=None):
+    """The sampling tail of `GenerationMixin._sample`: TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper (in
+    that order, TF `_get_logits_processor`), softmax, one `torch.multinomial` draw per row."""
+    sc = scores
+    if temperature is not None and float(temperature) != 1.0:
+        sc = sc / float(temperature)
+    if top_k is not None and int(top_k) > 0:
+        k = min(int(top_k), sc.shape[-1])
+        kth = torch.topk(sc, k)[0][..., -1, None]
+        sc = sc.masked_fill(sc < kth, float("-inf"))
+    if top_p is not None and float(top_p) < 1.0:
+        srt, idx = torch.sort(sc, descending=False)
+        cum = srt.softmax(-1).cumsum(-1)
+        remove = cum <= (1.0 - float(top_p))
+        remove[..., -1:] = False                                          # min_tokens_to_keep = 1
+        sc = sc.masked_fill(remove.scatter(1, idx, remove), float("-inf"))
+    probs = torch.softmax(sc, dim=-1)
+    return torch.multinomial(probs, num_samples=1, generator=generator)[:, 0]
+
+
 class GreedyDecoder:
     def __init__(self, engine, batch, max_len, eos_token_id=None, suppress_tokens=None, begin_suppress_tokens=None,
-                 use_graphs=None, check_every=16, timestamp_rules=None, pad_token_id=None):
+                 use_graphs=None, check_every=16, timestamp_rules=None, pad_token_id=None, soft=None):
         self.eng, self.B, self.max_len = engine, int(batch), int(max_len)
         d = engine.dims
         if self.max_len > d.max_tgt:
@@ -85,6 +130,14 @@ class GreedyDecoder:
         if timestamp_rules is not None and eos_token_id is None:
             raise ValueError("timestamp rules need eos_token_id")
         self.fill = -1 if eos_token_id is None else (eos_token_id if pad_token_id is None else pad_token_id)
+        # soft = dict(do_sample=, temperature=, top_k=, top_p=, repetition_penalty=, no_repeat_ngram_size=, generator=):
+        # history-dependent processors and sampling of `GenerationMixin` (TF `_get_logits_processor` order: repetition
+        # penalty, no-repeat n-gram, min-new-tokens, Whisper's suppress / begin-suppress / timestamp rules, then the
+        # temperature / top-k / top-p warpers and the multinomial draw).  The selection then runs as torch ops on the
+        # step's logits instead of dw_greedy_select, eagerly (no HIP-graph replay: the history grows every step).
+        self.soft = soft
+        if soft is not None:
+            self.use_graphs = False
         self.cache = None
         self.graphs = {}
         self.pool = None
@@ -96,6 +149,9 @@ class GreedyDecoder:
         self.cache["t"] = t
         logits = eng.decode_step(self.cur, self.cache)
         r = self.timestamp_rules
+        if self.soft is not None and mode != 0:
+            self._select_soft(logits, t + 1, mode, no_eos)
+            return
         # logits processors of the reference (min-new-tokens, begin-suppress, suppress, timestamp rules), argmax and the
         # EOS bookkeeping in one launch (csrc/decode.hip); the next token lands in tokens[:, t+1] and in cur
         eng.ops.greedy_select(
@@ -106,6 +162,37 @@ class GreedyDecoder:
             else r["max_initial_timestamp_index"],
             begin_index=1 if r is None else r["begin_index"], eos=-1 if self.eos is None else self.eos,
             fill=self.fill, done=self.done)
+
+    def _select_soft(self, logits, n, mode, no_eos):
+        """Token n of every row from `logits` with the history-dependent processors / sampling of `self.soft`."""
+        d, so, r = self.eng.dims, self.soft, self.timestamp_rules
+        B = self.B
+        neg = float("-inf")
+        sc = logits[:B, :d.vocab].float()
+        hist = self.tokens[:, :n]
+        rp = so.get("repetition_penalty")
+        if rp is not None and float(rp) != 1.0:
+            sc = apply_repetition_penalty(sc, hist, float(rp))
+        if so.get("no_repeat_ngram_size"):
+            sc = apply_no_repeat_ngram(sc, hist, int(so["no_repeat_ngram_size"]))
+        if no_eos and self.eos is not None:
+            sc[:, self.eos] = neg
+        if self.suppress is not None:
+            sc = sc.masked_fill(self.suppress[:d.vocab].bool()[None, :], neg)
+        if mode == 1 and self.begin_suppress is not None:
+            sc = sc.masked_fill(self.begin_suppress[:d.vocab].bool()[None, :], neg)
+        if r is not None:
+            sc = apply_timestamp_rules(sc, self.tokens, n, int(r["begin_index"]), int(r["no_timestamps_token_id"]), self.eos,
+                                       r.get("max_initial_timestamp_index"))
+        if so.get("do_sample"):
+            nxt = warp_and_sample(sc, so.get("temperature"), so.get("top_k"), so.get("top_p"), so.get("generator"))
+        else:
+            nxt = sc.argmax(-1)
+        if self.eos is not None:
+            nxt = torch.where(self.done, torch.full_like(nxt, self.fill), nxt)
+            self.done.logical_or_(nxt == self.eos)
+        self.tokens[:, n].copy_(nxt)
+        self.cur.copy_(nxt.view(B, 1))
 
     def _run_step(self, t, mode, no_eos=False):
         if not self.use_graphs:

@@ -741,8 +741,12 @@ class WhisperForConditionalGeneration(nn.Module):
         `force_unique_generate_call`) and inputs longer than 30 s run the reference's timestamp seek loop
         (`seek_decode`, TF:784-903) with `condition_on_prev_tokens`, the fallback thresholds (`temperature` tuple,
         `compression_ratio_threshold`, `logprob_threshold`) and the `no_speech_threshold` skip.
-        Arguments this path does not implement RAISE (nothing is silently ignored): group beam search, plain sampling,
-        the fallback heuristics outside the seek loop, token-level timestamps, custom logits processors.
+        Single-window greedy decoding also takes GenerationMixin's `repetition_penalty`, `no_repeat_ngram_size` and plain
+        sampling (a positive `temperature`, as in the reference's generate_with_fallback, with `top_k` / `top_p`):
+        decoding.GreedyDecoder `soft` -- token for token the reference's on the same device and seed.
+        Arguments this path does not implement RAISE (nothing is silently ignored): group beam search, those three options
+        combined with beams / an assistant / the seek loop, the fallback heuristics outside the seek loop, token-level
+        timestamps, custom logits processors.
         Returns what the reference returns: the generated tokens only (decoder prompt and EOS stripped, right-padded
         with pad_token_id), or with `return_dict_in_generate=True` / `force_unique_generate_call=True` the full
         sequences (prompt + generated, as GenerationMixin emits them)."""
@@ -762,8 +766,9 @@ class WhisperForConditionalGeneration(nn.Module):
                              condition_on_prev_tokens=bool(condition_on_prev_tokens))
         uses_fallback = bool(condition_on_prev_tokens) or compression_ratio_threshold is not None or \
             logprob_threshold is not None or no_speech_threshold is not None or len(temps) > 1
-        if not uses_fallback and temps[0] is not None and temps[0] > 0.0:
-            raise NotImplementedError("sampling (temperature > 0) is not implemented on the MI355X path")
+        # plain sampling: as in the reference's generate_with_fallback (TF:generation_whisper.py `do_sample = temperature is not
+        # None and temperature > 0.0`), a positive `temperature` IS the switch -- `do_sample=True` alone decodes greedily
+        sample_temp = float(temps[0]) if (not uses_fallback and temps[0] is not None and temps[0] > 0.0) else None
         engine_keys = ("encoder_outputs", "assistant_model", "decoder_input_ids", "use_cache")
         unknown = [k for k in kwargs if k not in G._CONFIG_KEYS and k not in engine_keys]
         if unknown:
@@ -776,16 +781,22 @@ class WhisperForConditionalGeneration(nn.Module):
         num_beams = int(getattr(gc, "num_beams", 1) or 1)
         if num_beams > 1 and (getattr(gc, "num_beam_groups", 1) or 1) != 1:
             raise NotImplementedError("group beam search is not implemented on the MI355X path")
-        if getattr(gc, "do_sample", False):
-            raise NotImplementedError("do_sample=True is not implemented on the MI355X path")
         if (getattr(gc, "num_return_sequences", 1) or 1) != 1:
             raise NotImplementedError("num_return_sequences > 1 is not implemented on the MI355X path")
-        if getattr(gc, "repetition_penalty", None) not in (None, 1.0):
-            raise NotImplementedError("repetition_penalty is not implemented on the MI355X path")
         if num_beams == 1 and getattr(gc, "length_penalty", None) not in (None, 1.0):
             raise NotImplementedError("length_penalty without beam search is not implemented on the MI355X path")
-        if getattr(gc, "no_repeat_ngram_size", 0):
-            raise NotImplementedError("no_repeat_ngram_size is not implemented on the MI355X path")
+        # history-dependent processors / sampling (GenerationMixin's repetition penalty, no-repeat n-gram, temperature / top-k /
+        # top-p sampling): on the single-call KV-cache decoder (decoding.GreedyDecoder `soft`); elsewhere they raise below
+        soft = None
+        rp, nrn = getattr(gc, "repetition_penalty", None), int(getattr(gc, "no_repeat_ngram_size", 0) or 0)
+        if sample_temp is not None or rp not in (None, 1.0) or nrn:
+            # (an unset top_k is GenerationMixin's global default of 50 when sampling; run_eval.py:739 passes top_k=0 = off)
+            tk = getattr(gc, "top_k", None)
+            soft = dict(do_sample=sample_temp is not None, temperature=sample_temp, top_k=50 if tk is None else tk,
+                        top_p=getattr(gc, "top_p", None), repetition_penalty=rp, no_repeat_ngram_size=nrn)
+            if num_beams > 1 or kwargs.get("assistant_model") is not None or kwargs.get("use_cache", True) is False:
+                raise NotImplementedError("sampling / repetition_penalty / no_repeat_ngram_size are implemented for greedy "
+                                          "single-window decoding with the KV cache (not with beams, an assistant or use_cache=False)")
         if gc.decoder_start_token_id is None:
             gc.decoder_start_token_id = d.decoder_start_token_id
         # ---- encoder
@@ -819,6 +830,9 @@ class WhisperForConditionalGeneration(nn.Module):
             if frames > 2 * d.max_src or (rt and not force_unique_generate_call):
                 # the reference's seek loop (TF:784-903): with timestamps every window is decoded until its audio is
                 # consumed, also when the input is a single 30 s window (run_pseudo_labelling.py:861-996 calls it so)
+                if soft is not None:
+                    raise NotImplementedError("sampling / repetition_penalty / no_repeat_ngram_size are implemented for "
+                                              "single-window decoding, not inside the timestamp seek loop, on the MI355X path")
                 return self._generate_seek_loop(input_features, attention_mask, gc, language, task, is_multilingual,
                                                 prompt_ids, kwargs, use_graphs, return_dict_in_generate, num_beams,
                                                 fallback_args, return_segments)
@@ -925,12 +939,13 @@ class WhisperForConditionalGeneration(nn.Module):
                                 max_initial_timestamp_index=getattr(gc, "max_initial_timestamp_index", None))
             total = P + max_new
             key = (B, total, eos, pad, bool(use_graphs), tuple(suppress or ()), tuple(begin_suppress or ()),
-                   None if ts_rules is None else tuple(sorted(ts_rules.items())))
+                   None if ts_rules is None else tuple(sorted(ts_rules.items())),
+                   None if soft is None else tuple(sorted((k, v) for k, v in soft.items())))
             dec = self._decoders.get(key)
             if dec is None:
                 dec = GreedyDecoder(eng, B, total, eos_token_id=eos, suppress_tokens=suppress,
                                     begin_suppress_tokens=begin_suppress, use_graphs=use_graphs,
-                                    check_every=16 if use_graphs else 1, timestamp_rules=ts_rules, pad_token_id=pad)
+                                    check_every=16 if use_graphs else 1, timestamp_rules=ts_rules, pad_token_id=pad, soft=soft)
                 self._decoders = {key: dec}        # one live decoder (its graphs pin the K/V cache buffers)
             seqs = dec.run(enc, ids, max_new, min_new)
         else:

@@ -231,7 +231,37 @@ def test_generate_matches_transformers_live_and_rejects_unsupported_arguments():
         got = model.generate(feats, return_dict_in_generate=True, **kw).sequences
         assert got.tolist() == ref.tolist(), (kw, got.tolist(), ref.tolist())
         assert model.generate(feats, **kw).tolist() == ref_plain.tolist(), kw
-    for bad, exc in ((dict(num_beams=4, num_beam_groups=2), NotImplementedError), (dict(do_sample=True), NotImplementedError),
+    # GenerationMixin's history-dependent processors and plain sampling on the single-window KV-cache decoder (round 6):
+    # repetition_penalty / no_repeat_ngram_size under greedy search are deterministic -> token for token; sampling draws
+    # from torch's global generator exactly as `_sample` does (one multinomial per step over the warped fp32 scores), so
+    # on the same device under the same seed the sampled tokens are the reference's too.  A positive `temperature` IS the
+    # sampling switch in the reference's Whisper generate (`do_sample = temperature is not None and temperature > 0.0`):
+    # `do_sample=True` alone decodes greedily there, and here.
+    for kw in (dict(max_new_tokens=9, language="en", repetition_penalty=1.8),
+               dict(max_new_tokens=9, language="en", no_repeat_ngram_size=2, eos_token_id=frequent),
+               dict(max_new_tokens=8, language="de", repetition_penalty=1.3, no_repeat_ngram_size=3),
+               dict(max_new_tokens=6, language="en", do_sample=True)):
+        with torch.no_grad():
+            ref = gd.hf_model(gd.CFG_T, sd_t, **fields).generate(feats, return_dict_in_generate=True, **kw).sequences
+        got = model.generate(feats, return_dict_in_generate=True, **kw).sequences
+        assert got.tolist() == ref.tolist(), (kw, got.tolist(), ref.tolist())
+    for kw in (dict(max_new_tokens=8, language="en", temperature=0.8),
+               dict(max_new_tokens=8, language="en", temperature=1.3, top_k=5),
+               dict(max_new_tokens=8, language="fr", temperature=0.7, top_p=0.6, repetition_penalty=1.2),
+               dict(max_new_tokens=7, language="en", temperature=1.0, top_k=20, top_p=0.9, no_repeat_ngram_size=2)):
+        hf_s = gd.hf_model(gd.CFG_T, sd_t, **fields)       # (built BEFORE seeding: its random initialisation draws from the generator)
+        torch.manual_seed(1234)
+        with torch.no_grad():
+            ref = hf_s.generate(feats, return_dict_in_generate=True, **kw).sequences
+        torch.manual_seed(1234)
+        got = model.generate(feats, return_dict_in_generate=True, **kw).sequences
+        assert got.tolist() == ref.tolist(), (kw, got.tolist(), ref.tolist())
+        torch.manual_seed(99)
+        other = model.generate(feats, return_dict_in_generate=True, **kw).sequences
+        assert other.shape == got.shape
+    for bad, exc in ((dict(num_beams=4, num_beam_groups=2), NotImplementedError),
+                     (dict(num_beams=2, repetition_penalty=1.2), NotImplementedError),
+                     (dict(temperature=0.5, return_timestamps=True), NotImplementedError),
                      (dict(temperature=(0.2, 0.4)), NotImplementedError),
                      (dict(condition_on_prev_tokens=True), NotImplementedError),
                      (dict(no_speech_threshold=0.6, logprob_threshold=-1.0), NotImplementedError),
