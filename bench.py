@@ -530,15 +530,17 @@ def reference_loop_leg(ops, args, tdims, le, ld, audio, dec_in, labels, lens_hos
     return out
 
 
-def dp_mode_selection(tr, eager_step, dist, dev, pre=2, n=5):
+def dp_mode_selection(tr, eager_step, dist, dev, pre=2, n=5, probe=None):
     """Data-parallel ranks choose between two ways to issue the same eager step -- everything on the main stream (plus the
     reducer's communication stream), or with the frozen teacher forward and the weight-gradient GEMMs on their own streams
     -- by measurement, a few untimed steps of each WITH the bucketed all-reduce in them.  Per leg the slowest rank counts
     (all-reduce MAX of the medians), the side-stream leg is only eligible if it ran on EVERY rank (all-reduce MIN of an ok
     flag), and because every rank reads the same reduced numbers every rank takes the same decision.  The run starts on the
     single-stream step: the configuration the test-suite executes on a GPU (tests/test_dp_gpu.py) -- an 8-GPU run can not
-    land on a configuration nobody has run without having measured it against that one first."""
-    def probe():
+    land on a configuration nobody has run without having measured it against that one first.
+    `probe`: the timing function (median ms of n steps after `pre` untimed ones); the default brackets the steps with HIP
+    events; tests/test_dp_gloo.py injects per-rank numbers to check the agreement logic on CPU over gloo."""
+    def hip_probe():
         for _ in range(pre):
             eager_step()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
@@ -549,6 +551,7 @@ def dp_mode_selection(tr, eager_step, dist, dev, pre=2, n=5):
         torch.cuda.synchronize()
         return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))[n // 2]
 
+    probe = probe or hip_probe
     tr.overlap_teacher = False
     tr.set_overlap_wgrad(False)
     single = probe()
@@ -560,7 +563,8 @@ def dp_mode_selection(tr, eager_step, dist, dev, pre=2, n=5):
     except Exception as e:      # noqa: BLE001 -- whatever the side-stream step raises, the run continues on the other one
         ok = 0.0
         log(f"side-stream probe failed on this rank ({type(e).__name__}: {e}); single-stream step")
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
     t = torch.tensor([single, sidet if ok else 1e30], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     okt = torch.tensor([ok], device=dev, dtype=torch.float64)

@@ -470,9 +470,17 @@ class _EngineFn(torch.autograd.Function):
         # returned view would change under torch.autograd.grad results, tensor hooks or DDP bucket views that keep it.
         # (AccumulateGrad takes ownership of a fresh non-view gradient without copying it again: still one copy.)
         # Parameters frozen after construction (`requires_grad_(False)`, run_distillation.py:1018-1040) get None.
+        # ONE copy of the trainable range (a single launch, not ~600 five-microsecond ones on a host that is the bottleneck of the
+        # eager loop); every returned gradient is a contiguous view of that fresh buffer, which nothing else writes.
+        lo, hi = st.train_start, st.train_end
+        Gc = st.G[lo:hi].clone() if hi > lo else None
         grads = []
         for name, p in zip(model._param_names, model._param_list):
-            grads.append(st.g[name].clone() if (p.requires_grad and name in st.g) else None)
+            if p.requires_grad and name in st.g:
+                off = st.entries[name][0]
+                grads.append(Gc[off - lo: off - lo + p.numel()].view(p.shape))
+            else:
+                grads.append(None)
         return (None, None, None, None, None, *grads)
 
 

@@ -248,3 +248,64 @@ def test_grad_reducer_labels_its_buckets_and_counts_steps():
         r.watchdog.stop()
     finally:
         dist.destroy_process_group()
+
+
+def _mode_selection_worker(rank, world, port, out_dir):
+    """bench.dp_mode_selection over gloo with per-rank timings injected: rank 0 measures the side-stream step FASTER than the
+    single-stream one, rank 1 measures it SLOWER (or fails it, third scenario) -- the decision must be the same on both ranks
+    and follow the slowest rank."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeTrainer:
+        overlap_teacher = False
+        wgrad = False
+
+        def set_overlap_wgrad(self, on):
+            self.wgrad = bool(on)
+
+    out = {}
+    # (single-stream ms, side-stream ms or an exception) per rank
+    scenarios = {"side_wins_on_both": [(100.0, 90.0), (101.0, 95.0)],
+                 "side_loses_on_one": [(100.0, 90.0), (100.0, 130.0)],
+                 "side_fails_on_one": [(100.0, 90.0), (100.0, RuntimeError("side-stream launch failed"))],
+                 "single_slow_on_one": [(100.0, 99.0), (140.0, 120.0)]}
+    for name, per_rank in scenarios.items():
+        tr = FakeTrainer()
+        single, side = per_rank[rank]
+
+        def probe():
+            v = side if tr.overlap_teacher else single
+            if isinstance(v, Exception):
+                raise v
+            return v
+        sel = bench.dp_mode_selection(tr, None, dist, "cpu", probe=probe)
+        out[name] = {"sel": sel, "overlap_teacher": tr.overlap_teacher, "wgrad": tr.wgrad}
+    with open(os.path.join(out_dir, f"sel{rank}.json"), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_data_parallel_mode_selection_is_the_same_on_every_rank(tmp_path):
+    """bench.py's data-parallel ranks start single-stream and take the side streams only if the slowest rank measures them
+    faster and they ran on every rank (round-5 review item 5: an N-GPU run must not land on an unmeasured configuration)."""
+    import json
+    port = _free_port()
+    mp.spawn(_mode_selection_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (json.load(open(os.path.join(str(tmp_path), f"sel{r}.json"))) for r in (0, 1))
+    assert r0 == r1                                            # same reduced numbers, same decision, on both ranks
+    want = {"side_wins_on_both": (True, 101.0, 95.0), "side_loses_on_one": (False, 100.0, 130.0),
+            "side_fails_on_one": (False, 100.0, None), "single_slow_on_one": (True, 140.0, 120.0)}
+    for name, (use_side, single_max, side_max) in want.items():
+        got = r0[name]
+        assert got["overlap_teacher"] == got["wgrad"] == use_side, name
+        assert got["sel"]["eager_single_stream"] == single_max and got["sel"]["eager_side_streams"] == side_max, (name, got)
+        assert got["sel"]["side_streams_ran_on_every_rank"] == (name != "side_fails_on_one")
