@@ -161,7 +161,8 @@ class LongFormTranscriber:
     def __init__(self, model, feature_extractor, batch_size=16, chunk_length_s=30.0, stride_length_s=None,
                  max_new_tokens=128, prompt_ids=None, eos_token_id=None, first_special_id=None, suppress_tokens=None,
                  begin_suppress_tokens=None, use_graphs=None, rank=0, world=1, return_timestamps=False,
-                 no_timestamps_token_id=None, max_initial_timestamp_index=50, special_ids=None):
+                 no_timestamps_token_id=None, max_initial_timestamp_index=50, special_ids=None, overlap=False,
+                 decode_cus=64):
         """return_timestamps=True: the windows are decoded under the timestamp rules (`prompt_ids` must then not end in
         <|notimestamps|>; `no_timestamps_token_id` is required) and stitched by their timestamp tokens; the call returns
         per utterance a list of {"timestamp": (start, end), "tokens": [...]} (`stitch_timestamped`)."""
@@ -213,6 +214,13 @@ class LongFormTranscriber:
                                      suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens,
                                      use_graphs=use_graphs, timestamp_rules=rules)
         self._wave = torch.zeros((self.B, feature_extractor.n_samples), dtype=torch.float32, device=dev)
+        # overlap=True (GPU only): the encoder of batch i+1 runs on one HIP stream while the token loop of batch i runs on
+        # another.  A batch of 16 windows is ~41 ms of encoder (MFMA-bound, persistent GEMM grids on every CU) followed by ~32 ms
+        # of token steps (128 x 18 dependent few-microsecond launches that leave the matrix pipe idle): back to back they add up,
+        # side by side the token steps fit under the encoder.  The persistent GEMM grids hold a CU for a whole launch, so
+        # `decode_cus` CUs are kept out of their grids (dw_debug_set key 9) for the token-step kernels to land on at once.
+        self.overlap = bool(overlap) and torch.device(dev).type == "cuda"
+        self.decode_cus = int(decode_cus)
 
     def plan(self, lengths):
         """[(utterance, start, length)] for all windows of all utterances, in pipeline order."""
@@ -247,19 +255,64 @@ class LongFormTranscriber:
             return rows
         return [None] * lo + mine + [None] * (n_all - hi)
 
-    def _transcribe(self, audios):
+    def _encode_batch(self, audios, batch):
         model = self.model
+        self._wave.zero_()
+        for r, (u, start, length, _, _) in enumerate(batch):
+            self._wave[r, :length].copy_(audios[u][start:start + length])
+        feats = model.ops.logmel(self._wave, self.fe._filt)
+        enc, _ = model.engine.encode(feats, save=False)
+        return enc
+
+    def _decoded_batches(self, audios, jobs, prompt):
+        """Yields (batch, ids as a numpy array) in order.  overlap: two-stage pipeline over two HIP streams (see __init__)."""
+        batches = [jobs[b0:b0 + self.B] for b0 in range(0, len(jobs), self.B)]
+        if not self.overlap or len(batches) < 2:
+            for batch in batches:
+                enc = self._encode_batch(audios, batch)
+                yield batch, self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
+            return
+        ops = self.model.ops
+        main = torch.cuda.current_stream(self.dev)
+        if not hasattr(self, "_streams"):
+            self._streams = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+        s_enc, s_dec = self._streams
+        s_enc.wait_stream(main)
+        s_dec.wait_stream(main)
+        cus = 256 - self.decode_cus
+        if self.decode_cus > 0:
+            ops.lib.dw_debug_set(9, cus - cus % 8)
+        try:
+            with torch.cuda.stream(s_enc):
+                enc = self._encode_batch(audios, batches[0])
+                ready = torch.cuda.Event()
+                ready.record(s_enc)
+            for i, batch in enumerate(batches):
+                cur_enc, cur_ready = enc, ready
+                if i + 1 < len(batches):
+                    with torch.cuda.stream(s_enc):            # the NEXT batch's encoder is queued before this batch's token loop
+                        enc = self._encode_batch(audios, batches[i + 1])
+                        ready = torch.cuda.Event()
+                        ready.record(s_enc)
+                with torch.cuda.stream(s_dec):
+                    s_dec.wait_event(cur_ready)
+                    ids_dev = self.decoder.run(cur_enc, prompt, self.max_new)
+                    done = torch.cuda.Event()
+                    done.record(s_dec)
+                done.synchronize()                             # (cur_enc stays referenced until its last reader has finished)
+                yield batch, ids_dev.cpu().numpy()
+                del cur_enc
+        finally:
+            if self.decode_cus > 0:
+                ops.lib.dw_debug_set(9, 256)
+            main.wait_stream(s_enc)
+            main.wait_stream(s_dec)
+
+    def _transcribe(self, audios):
         jobs = self.plan([a.numel() for a in audios])
         per_utt = [[] for _ in audios]
         prompt = self.prompt[None, :].expand(self.B, -1).contiguous()
-        for b0 in range(0, len(jobs), self.B):
-            batch = jobs[b0:b0 + self.B]
-            self._wave.zero_()
-            for r, (u, start, length, _, _) in enumerate(batch):
-                self._wave[r, :length].copy_(audios[u][start:start + length])
-            feats = model.ops.logmel(self._wave, self.fe._filt)
-            enc, _ = model.engine.encode(feats, save=False)
-            ids = self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
+        for batch, ids in self._decoded_batches(audios, jobs, prompt):
             sr_hz = float(self.fe.sampling_rate)
             for r, (u, _, length, sl, sr) in enumerate(batch):
                 row = ids[r, self.prompt.numel():]

@@ -58,6 +58,20 @@ for graphs in (False, True):
     t0 = time.perf_counter(); tr.decoder.run(enc, prompt, NEW); torch.cuda.synchronize(); td = time.perf_counter() - t0
     res["graphs" if graphs else "eager"] = {"windows": windows, "wall_s": dt, "audio_s_per_s": CLIPS * 300 / dt,
                                             "ms_per_decode_step": td / NEW * 1e3, "decode_tokens_per_s": B * NEW / td}
+# the encoder of batch i+1 on one stream beside the token loop of batch i on another (LongFormTranscriber(overlap=True)), with
+# `decode_cus` CUs kept out of the persistent GEMM grids; the transcripts must equal the sequential run's
+CLIPS_OV = max(CLIPS, 8)
+audio_ov = audio + [0.1 * torch.randn(4_800_000, device=dev) for _ in range(CLIPS_OV - CLIPS)]
+seq = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True)
+seq(audio_ov[:1]); torch.cuda.synchronize()
+t0 = time.perf_counter(); ref_out = seq(audio_ov); torch.cuda.synchronize(); dt_seq = time.perf_counter() - t0
+res["overlap"] = {"clips": CLIPS_OV, "sequential": {"wall_s": dt_seq, "audio_s_per_s": CLIPS_OV * 300 / dt_seq}}
+for dc in eval(os.environ.get("DECODE_CUS", "(0, 32, 64, 96)")):
+    tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True, overlap=True, decode_cus=dc)
+    tr(audio_ov[:1]); torch.cuda.synchronize()
+    t0 = time.perf_counter(); out = tr(audio_ov); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    res["overlap"][f"decode_cus_{dc}"] = {"wall_s": dt, "audio_s_per_s": CLIPS_OV * 300 / dt, "same_transcripts": out == ref_out}
+del seq
 # per-launch-class breakdown of the decode step (eager, HIP events around every launch; 32 steps)
 tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=33, use_graphs=False)
 feats = torch.randn(B, 128, 3000, device=dev) * 0.5
