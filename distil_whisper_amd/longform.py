@@ -221,6 +221,7 @@ class LongFormTranscriber:
         # `decode_cus` CUs are kept out of their grids (dw_debug_set key 9) for the token-step kernels to land on at once.
         self.overlap = bool(overlap) and torch.device(dev).type == "cuda"
         self.decode_cus = int(decode_cus)
+        self.decode_priority = -1
 
     def plan(self, lengths):
         """[(utterance, start, length)] for all windows of all utterances, in pipeline order."""
@@ -275,7 +276,9 @@ class LongFormTranscriber:
         ops = self.model.ops
         main = torch.cuda.current_stream(self.dev)
         if not hasattr(self, "_streams"):
-            self._streams = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev))
+            # (the token loop's stream has the higher priority: its few-microsecond kernels are dispatched ahead of the
+            # encoder's queued workgroups whenever a CU frees up)
+            self._streams = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev, priority=self.decode_priority))
         s_enc, s_dec = self._streams
         s_enc.wait_stream(main)
         s_dec.wait_stream(main)
