@@ -238,6 +238,16 @@ def test_graph_replayed_greedy_decode_and_longform_scheduler(ops):
                 seqs.append(text)
         want.append(merge_sequences(seqs))
     assert got[True] == want
+    # the encoder of batch i+1 on one HIP stream beside the token loop of batch i on another (CUs reserved for the token-step
+    # kernels, EOS checks syncing the host inside the loop): the same transcripts, twice (second call: streams / graphs reused)
+    for dc in (0, 64):
+        tr = LongFormTranscriber(model, fe, batch_size=3, max_new_tokens=10, first_special_id=first_special, use_graphs=True,
+                                 overlap=True, decode_cus=dc, eos_token_id=eos)
+        ref = LongFormTranscriber(model, fe, batch_size=3, max_new_tokens=10, first_special_id=first_special, use_graphs=True,
+                                  eos_token_id=eos)
+        assert tr.overlap and tr(audios) == ref(audios) and tr(audios[::-1]) == ref(audios[::-1]), dc
+    assert ops.gemm(torch.zeros(512, 64, device="cuda", dtype=torch.bfloat16),
+                    torch.zeros(512, 64, device="cuda", dtype=torch.bfloat16)).shape == (512, 512)       # (key 9 restored: launches fine)
 
 
 def test_device_resident_input_pipeline(ops):
