@@ -155,6 +155,51 @@ def stitch_timestamped(windows, timestamp_begin, special_ids=(), prompt_token_id
     return segments
 
 
+def two_stage_pipeline(owner, ops, dev, batches, encode_fn, decode_fn, overlap, decode_cus, priority=-1):
+    """Yields (batch, decode_fn(encode_fn(batch)) as a numpy array) in order.  overlap: the encoder stage of batch i+1 runs on one
+    HIP stream while the token loop of batch i runs on another, with `decode_cus` CUs kept out of the persistent GEMM grids
+    (dw_debug_set key 9) so that the token-step kernels find a CU at once; the streams live on `owner`.  Used by the long-form
+    and the pseudo-labelling schedulers (run_eval.py:566-576, run_pseudo_labelling.py:861-996): same tokens either way."""
+    if not overlap or len(batches) < 2:
+        for batch in batches:
+            yield batch, decode_fn(encode_fn(batch)).cpu().numpy()
+        return
+    main = torch.cuda.current_stream(dev)
+    if not hasattr(owner, "_streams"):
+        owner._streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=priority))
+    s_enc, s_dec = owner._streams
+    s_enc.wait_stream(main)
+    s_dec.wait_stream(main)
+    cus = 256 - int(decode_cus)
+    if decode_cus > 0:
+        ops.lib.dw_debug_set(9, cus - cus % 8)
+    try:
+        with torch.cuda.stream(s_enc):
+            enc = encode_fn(batches[0])
+            ready = torch.cuda.Event()
+            ready.record(s_enc)
+        for i, batch in enumerate(batches):
+            cur_enc, cur_ready = enc, ready
+            if i + 1 < len(batches):
+                with torch.cuda.stream(s_enc):            # the NEXT batch's encoder is queued before this batch's token loop
+                    enc = encode_fn(batches[i + 1])
+                    ready = torch.cuda.Event()
+                    ready.record(s_enc)
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(cur_ready)
+                ids_dev = decode_fn(cur_enc)
+                done = torch.cuda.Event()
+                done.record(s_dec)
+            done.synchronize()                             # (cur_enc stays referenced until its last reader has finished)
+            yield batch, ids_dev.cpu().numpy()
+            del cur_enc
+    finally:
+        if decode_cus > 0:
+            ops.lib.dw_debug_set(9, 256)
+        main.wait_stream(s_enc)
+        main.wait_stream(s_dec)
+
+
 class LongFormTranscriber:
     """audio (list of 1-D float tensors/arrays at 16 kHz, any length) -> list of stitched text-token id lists."""
 
@@ -221,7 +266,6 @@ class LongFormTranscriber:
         # `decode_cus` CUs are kept out of their grids (dw_debug_set key 9) for the token-step kernels to land on at once.
         self.overlap = bool(overlap) and torch.device(dev).type == "cuda"
         self.decode_cus = int(decode_cus)
-        self.decode_priority = -1
 
     def plan(self, lengths):
         """[(utterance, start, length)] for all windows of all utterances, in pipeline order."""
@@ -268,48 +312,8 @@ class LongFormTranscriber:
     def _decoded_batches(self, audios, jobs, prompt):
         """Yields (batch, ids as a numpy array) in order.  overlap: two-stage pipeline over two HIP streams (see __init__)."""
         batches = [jobs[b0:b0 + self.B] for b0 in range(0, len(jobs), self.B)]
-        if not self.overlap or len(batches) < 2:
-            for batch in batches:
-                enc = self._encode_batch(audios, batch)
-                yield batch, self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
-            return
-        ops = self.model.ops
-        main = torch.cuda.current_stream(self.dev)
-        if not hasattr(self, "_streams"):
-            # (the token loop's stream has the higher priority: its few-microsecond kernels are dispatched ahead of the
-            # encoder's queued workgroups whenever a CU frees up)
-            self._streams = (torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev, priority=self.decode_priority))
-        s_enc, s_dec = self._streams
-        s_enc.wait_stream(main)
-        s_dec.wait_stream(main)
-        cus = 256 - self.decode_cus
-        if self.decode_cus > 0:
-            ops.lib.dw_debug_set(9, cus - cus % 8)
-        try:
-            with torch.cuda.stream(s_enc):
-                enc = self._encode_batch(audios, batches[0])
-                ready = torch.cuda.Event()
-                ready.record(s_enc)
-            for i, batch in enumerate(batches):
-                cur_enc, cur_ready = enc, ready
-                if i + 1 < len(batches):
-                    with torch.cuda.stream(s_enc):            # the NEXT batch's encoder is queued before this batch's token loop
-                        enc = self._encode_batch(audios, batches[i + 1])
-                        ready = torch.cuda.Event()
-                        ready.record(s_enc)
-                with torch.cuda.stream(s_dec):
-                    s_dec.wait_event(cur_ready)
-                    ids_dev = self.decoder.run(cur_enc, prompt, self.max_new)
-                    done = torch.cuda.Event()
-                    done.record(s_dec)
-                done.synchronize()                             # (cur_enc stays referenced until its last reader has finished)
-                yield batch, ids_dev.cpu().numpy()
-                del cur_enc
-        finally:
-            if self.decode_cus > 0:
-                ops.lib.dw_debug_set(9, 256)
-            main.wait_stream(s_enc)
-            main.wait_stream(s_dec)
+        yield from two_stage_pipeline(self, self.model.ops, self.dev, batches, lambda batch: self._encode_batch(audios, batch),
+                                      lambda enc: self.decoder.run(enc, prompt, self.max_new), self.overlap, self.decode_cus)
 
     def _transcribe(self, audios):
         jobs = self.plan([a.numel() for a in audios])

@@ -45,7 +45,7 @@ class PseudoLabeller:
 
     def __init__(self, model, feature_extractor, batch_size=16, max_new_tokens=255, prompt_ids=None, eos_token_id=None,
                  timestamp_rules=None, use_graphs=None, rank=0, world=1, suppress_tokens=None,
-                 begin_suppress_tokens=None, num_beams=1):
+                 begin_suppress_tokens=None, num_beams=1, overlap=False, decode_cus=64):
         self.model, self.fe = model, feature_extractor
         self.B, self.max_new = int(batch_size), int(max_new_tokens)
         self.rank, self.world = rank, world
@@ -64,6 +64,10 @@ class PseudoLabeller:
                                      suppress_tokens=suppress_tokens, begin_suppress_tokens=begin_suppress_tokens,
                                      use_graphs=use_graphs, timestamp_rules=timestamp_rules)
         self._wave = torch.zeros((self.B, feature_extractor.n_samples), dtype=torch.float32, device=dev)
+        # overlap=True: the encoder of the next batch of packs beside the token loop of the current one (longform.two_stage_pipeline;
+        # plain greedy decoding only -- the seek loop and beam search encode / decode in their own order)
+        self.overlap = bool(overlap) and torch.device(dev).type == "cuda"
+        self.decode_cus = int(decode_cus)
 
     def __call__(self, audios, speaker_ids=None, gather=False, group=None):
         """`gather=True`: every rank returns the labels of ALL packs (rank-ordered exchange of the id lists, the
@@ -77,8 +81,7 @@ class PseudoLabeller:
         mine = shard(list(range(len(packs))), self.rank, self.world)
         prompt = self.prompt[None, :].expand(self.B, -1).contiguous()
         out = {}
-        for b0 in range(0, len(mine), self.B):
-            batch = mine[b0:b0 + self.B]
+        def wave_to_features(batch):
             self._wave.zero_()
             for r, pi in enumerate(batch):
                 pos = 0
@@ -86,7 +89,24 @@ class PseudoLabeller:
                     n = audios[si].numel()
                     self._wave[r, pos:pos + n].copy_(audios[si])
                     pos += n
-            feats = model.ops.logmel(self._wave, self.fe._filt)
+            return model.ops.logmel(self._wave, self.fe._filt)
+
+        batches = [mine[b0:b0 + self.B] for b0 in range(0, len(mine), self.B)]
+        plain = not (self._ts_rules is not None and self.num_beams == 1) and self.num_beams == 1
+        if plain:
+            from .longform import two_stage_pipeline
+            for batch, ids in two_stage_pipeline(self, model.ops, self.dev, batches,
+                                                 lambda b: model.engine.encode(wave_to_features(b), save=False)[0],
+                                                 lambda enc: self.decoder.run(enc, prompt, self.max_new), self.overlap,
+                                                 self.decode_cus):
+                for r, pi in enumerate(batch):
+                    row = ids[r, self.prompt.numel():].tolist()
+                    if self.eos is not None and self.eos in row:
+                        row = row[:row.index(self.eos)]
+                    out[pi] = [int(x) for x in row]
+            batches = []
+        for batch in batches:
+            feats = wave_to_features(batch)
             if self._ts_rules is not None and self.num_beams == 1:
                 # generate(..., return_timestamps=True) of the reference is a seek loop (TF:784-903): a pack is decoded
                 # in as many passes as its predicted end-of-segment timestamps require
@@ -99,12 +119,9 @@ class PseudoLabeller:
                     out[pi] = [int(t) for sg in segs[r] for t in sg["tokens"]]
                 continue
             enc, _ = model.engine.encode(feats, save=False)
-            if self.num_beams > 1:
-                from .decoding import beam_search_decode
-                ids = beam_search_decode(model.engine, enc, prompt, self.max_new, self.num_beams, self.eos,
-                                         timestamp_rules=self._ts_rules, **self._beam_kw).cpu().numpy()
-            else:
-                ids = self.decoder.run(enc, prompt, self.max_new).cpu().numpy()
+            from .decoding import beam_search_decode
+            ids = beam_search_decode(model.engine, enc, prompt, self.max_new, self.num_beams, self.eos,
+                                     timestamp_rules=self._ts_rules, **self._beam_kw).cpu().numpy()
             for r, pi in enumerate(batch):
                 row = ids[r, self.prompt.numel():].tolist()
                 if self.eos is not None and self.eos in row:

@@ -68,7 +68,6 @@ t0 = time.perf_counter(); ref_out = seq(audio_ov); torch.cuda.synchronize(); dt_
 res["overlap"] = {"clips": CLIPS_OV, "sequential": {"wall_s": dt_seq, "audio_s_per_s": CLIPS_OV * 300 / dt_seq}}
 for dc in eval(os.environ.get("DECODE_CUS", "(0, 32, 64, 96)")):
     tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True, overlap=True, decode_cus=dc)
-    tr.decode_priority = int(os.environ.get("DECODE_PRIO", "-1"))
     tr(audio_ov[:1]); torch.cuda.synchronize()
     t0 = time.perf_counter(); out = tr(audio_ov); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     res["overlap"][f"decode_cus_{dc}"] = {"wall_s": dt, "audio_s_per_s": CLIPS_OV * 300 / dt, "same_transcripts": out == ref_out}

@@ -72,4 +72,15 @@ for graphs in (False, True):
         "decode_step_TBps_on_algorithmic_bytes": step_bytes / (td / NEW) / 1e12,
         "decode_step_frac_of_8TBps": step_bytes / (td / NEW) / 8e12,
         "encoder_ms_per_batch": e0.elapsed_time(e1) / 3}
+# the encoder of the next batch of packs beside the token loop of the current one (PseudoLabeller(overlap=True)); same labels
+ref = PseudoLabeller(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True)
+ref(audios[:B * 2], spk[:B * 2]); torch.cuda.synchronize()
+t0 = time.perf_counter(); rows_ref, _, _ = ref(audios, spk); torch.cuda.synchronize(); dt_ref = time.perf_counter() - t0
+secs = sum(a.numel() for a in audios) / 16000.0
+res["overlap"] = {"sequential": {"wall_s": dt_ref, "audio_s_per_s": secs / dt_ref}}
+for dc in (0, 32, 64):
+    pl = PseudoLabeller(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=True, overlap=True, decode_cus=dc)
+    pl(audios[:B * 2], spk[:B * 2]); torch.cuda.synchronize()
+    t0 = time.perf_counter(); rows, _, _ = pl(audios, spk); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    res["overlap"][f"decode_cus_{dc}"] = {"wall_s": dt, "audio_s_per_s": secs / dt, "same_labels": rows == rows_ref}
 print(json.dumps(res))
