@@ -315,13 +315,13 @@ __global__ __launch_bounds__(64 * NW) void attn_decode_kernel(const AttnP p) {
         for (int it = 0; it < NIT; ++it) {
             int k = wave * 8 + it * (NW * 8) + sub;
             k = k < p.Lk ? k : p.Lk - 1;
-            kr[it] = *(const bf16x8*)(K + (long)k * p.ldk);
+            kr[it] = ld_stream<2>((const bf16x8*)(K + (long)k * p.ldk));
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int k = wave * 8 + it * (NW * 8) + sub;
             k = k < p.Lk ? k : p.Lk - 1;
-            vr[it] = *(const bf16x8*)(V + (long)k * p.ldv);
+            vr[it] = ld_stream<2>((const bf16x8*)(V + (long)k * p.ldv));
         }
     }
     // ---- pass 1: scores (in log2 units) and their maximum ----

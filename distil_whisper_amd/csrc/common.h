@@ -283,3 +283,19 @@ __device__ __forceinline__ float block_max(float v, float* red) {
         hipError_t e__ = hipGetLastError();                \
         if (e__ != hipSuccess) return (int)e__;            \
     } while (0)
+
+// Streamed-once loads of the token step (-DDW_DECODE_NT=<mask>): bit 0 the weight-streaming GEMVs' W, bit 1 the K / V rows of the
+// single-query attention kernels.  Round 6, measured in one process against variant builds (tools/decode_nt_ab.py): the cross-
+// attention K / V are 246 MB per token step at batch 16, read once by one workgroup each; with the non-temporal hint on them
+// (mask 2, the default) they no longer push the step's RE-READ bytes -- 92 MB of layer weights + the 133 MB LM head, which fit
+// the 256 MB Infinity Cache -- out of it between steps: 0.2490 -> 0.2288 ms per step of the 2-layer student (-8.1 %), 3.069 -> 3.022 ms
+// for the 32-layer teacher (whose 1.7 GB of weights cannot be resident anyway).  The hint on the WEIGHT loads is the wrong way
+// round for the same reason (mask 1: -1 % / +3.6 %; mask 3 cancels the gain).
+#ifndef DW_DECODE_NT
+#define DW_DECODE_NT 2
+#endif
+template <int BIT, class T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+    if constexpr ((DW_DECODE_NT & BIT) != 0) return __builtin_nontemporal_load(p);
+    else return *p;
+}

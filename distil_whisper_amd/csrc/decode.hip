@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * DEC_NW, 4) void attn_decode_proj_kernel(const 
         for (int u = 0; u < UN; ++u) {
             int k = k0 + u * DEC_NW * 8 + sub;
             k = k < nold ? k : (nold > 0 ? nold - 1 : 0);
-            kr[u] = nold > 0 ? *(const bf16x8*)(K + (long)k * p.ldkv) : bf16x8{};
+            kr[u] = nold > 0 ? ld_stream<2>((const bf16x8*)(K + (long)k * p.ldkv)) : bf16x8{};
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * DEC_NW, 4) void attn_decode_proj_kernel(const 
         for (int u = 0; u < UN; ++u) {
             int k = k0 + u * DEC_NW * 8 + sub;
             k = k < nold ? k : (nold > 0 ? nold - 1 : 0);
-            vr[u] = nold > 0 ? *(const bf16x8*)(V + (long)k * p.ldkv) : bf16x8{};
+            vr[u] = nold > 0 ? ld_stream<2>((const bf16x8*)(V + (long)k * p.ldkv)) : bf16x8{};
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {

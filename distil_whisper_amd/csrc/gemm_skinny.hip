@@ -63,7 +63,7 @@ __global__ __launch_bounds__(LN ? 256 : 64 * SK_MAXW) void gemm_skinny_kernel(co
     bf16x8 wf[SK_MAXS];
 #pragma unroll
     for (int s = 0; s < SK_MAXS; ++s)
-        if (s < ns) wf[s] = *(const bf16x8*)(wp + s * 32);
+        if (s < ns) wf[s] = ld_stream<1>((const bf16x8*)(wp + s * 32));
 
     f32x4_t acc[MB];
 #pragma unroll
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_wide_kernel(const GemmP p, in
         const bf16* wp = p.b + (long)wrow * p.ldb + (long)s0 * 32 + g * 8;
 #pragma unroll
         for (int s = 0; s < SK_MAXS; ++s)
-            if (s < ns) wf[nb][s] = *(const bf16x8*)(wp + s * 32);
+            if (s < ns) wf[nb][s] = ld_stream<1>((const bf16x8*)(wp + s * 32));
     }
     f32x4_t acc[NB][MB];
 #pragma unroll
