@@ -30,6 +30,8 @@ static int g_gemm_t128_w4 = 0;   // dw_debug_set key 24: 128-tile launches on th
 int dw_gemm_wp8_nn_ref_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_nn_ref.hip (builtin DMA; A/B only)
 int dw_gemm_wp8_nn320_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_m320.hip (320 x 256 block tile)
 int dw_gemm_wp8_nt320_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp8_nn128_launch(const GemmP& p, hipStream_t s);               // gemm_wp8_m128.hip (128 x 256 block tile)
+int dw_gemm_wp8_nt128_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp8_nn_dbg_launch(const GemmP& p, int dbg, hipStream_t s);         // gemm_wp8_dbg.hip (main-loop ablations; profiling only)
 int dw_gemm_wp8_nn_launch(const GemmP& p, hipStream_t s);                   // gemm_wp8_*.hip: software-pipelined loop, 8 waves
 int dw_gemm_wp8_nt_launch(const GemmP& p, hipStream_t s);
@@ -85,6 +87,7 @@ static unsigned g_gemm_trace_lo = 0, g_gemm_trace_hi = 0;   // dw_debug_set keys
 static int g_gemm_mi16 = 36;
 static int g_gemm_dbg = 0;       // dw_debug_set key 19: row-major 256-row GEMMs run the ablation / experiment kernel `value` of gemm_wp8_dbg.hip
 static int g_gemm_dynamic = 1;   // dw_debug_set key 10: dynamic job hand-out in the persistent kernels (gemm_common.h)
+static int g_gemm_small_m = 1;   // dw_debug_set key 25: kernel choice by rounds of the CUs for outputs with fewer than two rounds of 256-row tiles (0: the 128 x 128 lock-step kernel)
 static int g_gemm_row_tail = 1;  // dw_debug_set key 22: the partial last row block of a wide 256-row launch goes to the 128-tile kernel when that saves a round
 
 // Nine device counters per stream for the dynamic job hand-out of the persistent kernels (kernels of one stream never
@@ -127,6 +130,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 20) { g_gemm_mi16 = value; return DW_OK; }
     if (key == 21) { g_ln_variant = value; return DW_OK; }
     if (key == 22) { g_gemm_row_tail = value; return DW_OK; }
+    if (key == 25) { g_gemm_small_m = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
     if (key == 24) { if (value < 0 || value > 2) return DW_EINVAL; g_gemm_t128_w4 = value; return DW_OK; }
     if (key == 23) { if (value < 0 || value > 64) return DW_EINVAL; g_attn_defer = value; return DW_OK; }
@@ -260,18 +264,36 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
         return dw_gemm_skinny_launch(p, s);
     }
     if (fused) return DW_EINVAL;                  // the fusions exist in the skinny-M kernel only
+    if (tile == 129 && (g->trans_a || p.split_k != 1 || p.atomic)) return DW_EINVAL;   // (tile 129: force the software-pipelined 128 x 256 tile)
     bool one_round_320 = false;
+    bool small_m_256 = false;       // a 256-row kernel chosen by the small-M rule below: runs on the 16x16x32 loop
     if (tile != 128 && tile != 256) {
-        const long t256 = (long)((g->m + 255) / 256) * ((g->n + 255) / 256);
+        const long tn = (g->n + 255) / 256;
+        const long t256 = (long)((g->m + 255) / 256) * tn;
         tile = t256 >= 512 ? 256 : 128;
-        // A grid too small for two rounds of 256-tiles that is ONE round of 320-row tiles filling at least half the
-        // CUs (the teacher decoder's padded M = 14400, N = 1280: 225 workgroups) runs that round instead of 4-5 rounds
-        // of 128-tiles.
-        if (tile == 128 && (g_gemm_variant & 2048) && !g->trans_a && p.split_k == 1 && !p.atomic && g->m % 320 == 0 &&
-            g->n % 256 == 0) {
-            const long t320 = (long)(g->m / 320) * (g->n / 256);
-            if (t320 <= g_gemm_cus && 2 * t320 >= g_gemm_cus) { tile = 256; one_round_320 = true; }
+        if (tile == 128 && g_gemm_small_m && (g_gemm_variant & 16) && !g->trans_a && p.split_k == 1 && !p.atomic) {
+            // Fewer than two rounds of 256-row tiles (the decoders: M = 32 x live positions).  Three software-pipelined kernels can
+            // take the launch -- 128 x 256 tiles in a three-stage ring (gemm_wp8_m128.hip), 256 x 256 on 16x16x32, 320 x 256 -- and
+            // what decides is how many rounds of the 256 CUs each needs: a 256-row tile costs ~1.65 and a 320-row tile ~2.05 of a
+            // 128-row tile's time (tools/gemm_m128_probe.py: M = 4 480 / 4 258 / 7 136 at the step's N and K; e.g. N = K = 1280 at
+            // M = 4 480: 21.3 us on 175 128-row tiles against 31.7 on 90 256-row tiles and 26.6 for the lock-step 128 x 128 kernel
+            // this rule replaces; N = 1280, K = 5120 at M = 7 136: 108 us on 140 256-row tiles against 123 / 136).  Every kernel
+            // computes the same fp32 chain over k per element: the choice never changes a result.
+            const long cus = g_gemm_cus;
+            const long r128 = (((long)(g->m + 127) / 128) * tn + cus - 1) / cus;
+            const long r256 = (t256 + cus - 1) / cus;
+            const bool ok320 = (g_gemm_variant & 2048) && g->m % 320 == 0 && g->n % 256 == 0;
+            const long r320 = ok320 ? ((long)(g->m / 320) * tn + cus - 1) / cus : 0;
+            const long c128 = r128 * 100, c256 = r256 * 165, c320 = ok320 ? r320 * 205 : (1L << 40);
+            if (c320 <= c128 && c320 <= c256) { tile = 256; one_round_320 = true; }
+            else if (c256 <= c128) { tile = 256; small_m_256 = true; }
+            else tile = 129;
         }
+    }
+    if (tile == 129) {
+        p.strip = g_gemm_strip;
+        if (g_gemm_dynamic) p.sched = gemm_sched_slot(s);
+        return g->trans_b ? dw_gemm_wp8_nt128_launch(p, s) : dw_gemm_wp8_nn128_launch(p, s);
     }
     if (tile == 256 && g->tile != 256 && !g->trans_a && !g->trans_b && g->r && g->r_dtype == DW_F32 && g->c_dtype == DW_F32 &&
         g->k <= 1024 && p.split_k == 1 && !p.atomic) {
@@ -317,6 +339,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
                               !g->r && !g->z_out && !g->zgrad_in && g->c_dtype != DW_F32 &&    // (the flavours of the accumulator-side walk)
                               !one_round_320 && !(v & 4096) && !g_gemm_dbg;   // (a forced / single-round 320-row tile and the ablation path keep their kernel)
         auto launch256 = [&](const GemmP& q) -> int {
+            if (small_m_256 && wp_ok && !g_gemm_dbg) return g->trans_b ? dw_gemm_wp16_nt_launch(q, s) : dw_gemm_wp16_nn_launch(q, s);
             if (nn16_256) {
                 // Row tail (round 5; dw_debug_set key 22, default on): M = 48 000 is 187.5 row tiles -- 2 820 tiles = 11.02 rounds of the
                 // CUs, and with the per-XCD job ranges four XCDs run a TWELFTH round for four tiles (8 % of the launch).  The last,

@@ -109,14 +109,20 @@ __device__ __forceinline__ void wp_dma16i(const i32x4_t& rsrc, unsigned lds_base
 // where 256-row tiles give 940 / 1880 / 2820 = 3.67 / 7.34 / 11.02 (the last round a third full); per MFMA the wave
 // reads 7 % fewer fragment bytes and the workgroup stages 10 % fewer operand bytes -- on a chip whose GEMM rate is set
 // by the socket power limit (tools/gemm_power_probe.py) bytes moved per flop are what the clock is paid with.
-template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true, int DBG = 0, int BM = 256>
+// NST = 3 (128-row tile): a THREE-stage operand ring.  A sub-step of the 64 x 64 wave tile is four MFMAs, so the 2.5-3.5 sub-steps
+// a DMA piece gets in the two-stage schedule are ~0.4 us -- less than its latency, and the wave sits out the rest at the K-tile
+// boundary (measured: 1.1 us per K tile, the same as the lock-step 128 x 128 kernel).  With three stages the pieces of K tile
+// t + 2 are requested during tile t and the boundary waits with a COUNTED vmcnt (the newest NH0 + NH1 loads may stay in flight:
+// the counter retires in order), one barrier per K tile as before.
+template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true, int DBG = 0, int BM = 256, int NST = 2>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(const GemmP p) {
     constexpr int BN = 256, NW = WM * WN, FM = BM / WM / 32, FN = BN / WN / 32, TN = BN / WN;
+    static_assert(NST == 2 || (NST == 3 && DBG == 0 && ASMDMA && BM < 256), "three stages: the 128-row tile");
     static_assert(NW * 32 * (TN + 4) * 4 <= 2 * (BM + BN) * 128, "epilogue patches must fit the operand buffers");
     static_assert(BM == 256 || !TA, "the k-major A image is built for 256-row tiles");
     constexpr int CPA = BM / 8 / NW, CPB = BN / 8 / NW;   // DMA pieces (1 KiB) per wave per operand per K tile
     constexpr int CP = CPB;
-    constexpr bool UNI = BM != 256;
+    constexpr bool UNI = BM == 320;                     // (BM = 128 keeps one clamped offset per piece like BM = 256: any M)
 #ifndef DW_EPF
 #define DW_EPF 4
 #endif
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     constexpr int NA0 = (CPA + 1) / 2, NB0 = CPB / 2;          // pieces of half 0
     constexpr int NH0 = NA0 + NB0, NH1 = CPA + CPB - NH0;      // loads a wave issues per half
     constexpr int STAGE = (BM + BN) * 128;            // one K tile: A [256][64] | B [256][64] (or their k-major images)
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
     __shared__ __attribute__((aligned(1024))) float bias_lds[BN];     // this tile's bias slice (see gemm_epilogue lds_bias)
 
     const int tid = threadIdx.x;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
             constexpr int RG = VH ? NMF / 4 : NMF / 2;                   // gaps that carry fragment reads
             constexpr int PER = (DSI + RG - 1) / RG;
             constexpr int NLD = VH == 1 ? NH0 : NH1;                       // operand loads of the half this sub-step issues
-            static_assert(RG + (NH0 > NH1 ? NH0 : NH1) <= NMF, "not enough MFMA gaps for the operand loads");
+            static_assert(VH == 0 || RG + NLD <= NMF, "not enough MFMA gaps for the operand loads");
             static_for<0, RG>([&](auto qc) __attribute__((always_inline)) { mfma1(sc, qc); });
 #pragma unroll
             for (int q = 0; q < RG; ++q) {
@@ -343,13 +349,62 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         const bool tile_in = m0 + BM <= p.m && n0 + BN <= p.n;
         // (issued first: lands with tile 0; scalar base + 32-bit lane offset, see gemm_wp16.h)
         if (p.bias && tile_in && wave == 0) glds16_so(p.bias + n0, (unsigned)lane_k * 16u, lds_addr_of(bias_lds));
+        if constexpr (NST == 3) {
+            // ---- three-stage ring: tiles 0 and 1 whole, first half of tile 2; tile 0 has landed when only those are outstanding ----
+            dma(I0{}, 0); dma(I1{}, 0);
+            kA += stepA; kB += stepB;
+            if (nt > 1) { dma(I0{}, 1); dma(I1{}, 1); kA += stepA; kB += stepB; }
+            if (nt > 2) dma(I0{}, 2);
+            if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NH0 + NH1) : "memory");
+            else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NH0 + NH1) : "memory");
+            else wait_vm0();
+            __syncthreads();
+            DW_TRACE(1);
+            frags(I0{}, I0{}, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // one K tile out of buffer b0; b1 / b2: the buffers of tiles t+1 / t+2.  M1..M3: tile t+1 / t+2 / t+3 exists.
+            // (kA, kB) point at tile t+2 on entry (its first half is in flight, its second half is issued in sub-step 0).
+            auto body3 = [&](auto m1c, auto m2c, auto m3c, int b0, int b1, int b2) {
+                constexpr bool M1 = decltype(m1c)::value, M2 = decltype(m2c)::value, M3 = decltype(m3c)::value;
+                PIN_SET(0);
+                frags(I1{}, I1{}, b0);
+                if constexpr (M2) { substep(I0{}, I1{}, I2{}, b2); kA += stepA; kB += stepB; }
+                else substep(I0{}, I1{}, I0{}, 0);
+                PIN_SET(1);
+                frags(I0{}, I2{}, b0);
+                substep(I1{}, I1{}, I0{}, 0);
+                PIN_SET(0);
+                frags(I1{}, I3{}, b0);
+                substep(I0{}, I1{}, I0{}, 0);
+                PIN_SET(1);
+                if constexpr (M1) {
+                    // tile t+1 has landed once only tile t+2's pieces (requested after it) are outstanding
+                    if constexpr (M2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NH0 + NH1) : "memory");
+                    else wait_vm0();
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // sub-step 3: fragments of (t+1, 0); first half of tile t+3 into b0 (every wave is past its last read of it)
+                if constexpr (M1) frags(I0{}, I0{}, b1);
+                if constexpr (M3) substep(I1{}, I1{}, I1{}, b0);
+                else if constexpr (M1) substep(I1{}, I1{}, I0{}, 0);
+                else substep(I1{}, I0{}, I0{}, 0);
+            };
+            int t = 0, b0 = 0, b1 = 1, b2 = 2;
+            auto rot = [&]() { const int x = b0; b0 = b1; b1 = b2; b2 = x; ++t; };
+            for (; t + 3 < nt; rot()) body3(std::true_type{}, std::true_type{}, std::true_type{}, b0, b1, b2);
+            if (nt >= 3) { body3(std::true_type{}, std::true_type{}, std::false_type{}, b0, b1, b2); rot(); }
+            if (nt >= 2) { body3(std::true_type{}, std::false_type{}, std::false_type{}, b0, b1, b2); rot(); }
+            body3(std::false_type{}, std::false_type{}, std::false_type{}, b0, b1, b2);
+        } else {
         if (!prefetched) { dma(I0{}, (DBG & 2) ? 8 : 0); dma(I1{}, (DBG & 2) ? 8 : 0); }
         kA += stepA; kB += stepB;
         if (nt > 1) dma(I0{}, (DBG & 2) ? 9 : 1);
         if (nt > 1) {      // tile 0 has landed when only the NH0 loads of tile 1's first half are outstanding
             if constexpr (NH0 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if constexpr (NH0 == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else { static_assert(NH0 == 4 || NH0 == 8 || NH0 == 5, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if constexpr (NH0 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else { static_assert(NH0 == 4 || NH0 == 8 || NH0 == 5 || NH0 == 3, "vmcnt immediate"); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         } else wait_vm0();
         __syncthreads();
         DW_TRACE(1);
@@ -391,6 +446,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         for (; t + 2 < nt; ++t) body(std::true_type{}, std::true_type{}, t);
         if (nt >= 2) { body(std::true_type{}, std::false_type{}, t); ++t; }
         body(std::false_type{}, std::false_type{}, t);
+        }   // NST == 2
 
         DW_TRACE(2);
         // ---- optional (dw_debug_set key 11 bit 128, OFF by default): the NEXT tile's first operand tile, requested before
@@ -403,7 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
         // comes first after the epilogue's 32 stores sits out their acknowledgement; operand latency was never what the
         // prologue waited for.  Hence off.
         prefetched = false;
-        if constexpr (ASMDMA && DBG == 0 && TN == 64) {
+        if constexpr (ASMDMA && DBG == 0 && TN == 64 && BM >= 256) {
             const int nxt = jobs.dynamic ? job_slot[(jobs.iter + 1) & 1] : jobs.cur + jobs.step;
             if ((p.stage_next & 128) && (nt & 1) == 0 && nt >= 2 && nxt < jobs.cnt && tile_in && !p.zgrad && !p.r) {
                 int tm2, tn2, ks2;
@@ -421,7 +477,9 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
                 }
             }
         }
-        if (!(p.stage_next & 16)) gemm_epilogue<FM, FN, TN, (BM == 256 ? 8 : EPF), GemmNoHook, TN == 64>(p, acc, smem + (TN == 64 ? STAGE : 0), wave, lane, m0, wm0, n0, wn0, ks, GemmNoHook(), tile_in ? bias_lds : nullptr,
+        // (the eight swizzled 8 KiB patches fill operand buffer 1 of the 256- / 320-row tiles; the 128-row tile's 48 KiB stages are
+        // smaller than that: its patches start at buffer 0 and run into buffer 1)
+        if (!(p.stage_next & 16)) gemm_epilogue<FM, FN, TN, (BM == 320 ? EPF : 8), GemmNoHook, TN == 64>(p, acc, smem + (TN == 64 && STAGE >= NW * 8192 ? STAGE : 0), wave, lane, m0, wm0, n0, wn0, ks, GemmNoHook(), tile_in ? bias_lds : nullptr,
                                                            (p.trace && tid == 0 && jobs.iter < 8) ? p.trace + ((long)blockIdx.x * 8 + jobs.iter) * 8 : nullptr);
         else { float t = 0.f;
 #pragma unroll
@@ -440,7 +498,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void gemm_wp_kernel(cons
     gemm_jobs_end(p, jobs);
 }
 
-template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true, int DBG = 0, int BM = 256>
+template <bool TA, bool TB, int WM, int WN, bool ASMDMA = true, int DBG = 0, int BM = 256, int NST = 2>
 static int launch_wp(const GemmP& p0, hipStream_t s) {
     GemmP p = p0;
     const int tiles_m = (p.m + BM - 1) / BM;
@@ -449,7 +507,7 @@ static int launch_wp(const GemmP& p0, hipStream_t s) {
     p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
     if (nblk > g_gemm_cus) nblk = g_gemm_cus;
-    hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN, ASMDMA, DBG, BM>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
+    hipLaunchKernelGGL((gemm_wp_kernel<TA, TB, WM, WN, ASMDMA, DBG, BM, NST>), dim3(nblk), dim3(64 * WM * WN), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -72,7 +72,8 @@ typedef struct DwGemm {
     int32_t r_dtype;    /* DW_F32 / DW_BF16 */
     int32_t r_row_mod;  /* 0: R row = m; >0: R row = m %% r_row_mod (positional table broadcast) */
     int32_t round_res;  /* 1: round v to bf16 before adding R (autocast semantics) */
-    int32_t tile;       /* 0 auto, 128 or 256: force the block tile; 16: the skinny-M (m <= 64) weight-streaming kernel */
+    int32_t tile;       /* 0 auto, 128 or 256: force the block tile; 16: the skinny-M (m <= 64) weight-streaming kernel;
+                           129 (probing): like 0 for outputs below two rounds of 256-row tiles, refused for k-major A / split K */
     int32_t split_k;    /* > 1: the K range is cut into that many slices, combined either by atomic_acc or by
                            storing fp32 partials at c + slice * slice_stride (then call dw_reduce_slices) */
     int32_t atomic_acc; /* 1: C (f32, plain epilogue) += result with float atomics (gradient accumulation) */
@@ -325,7 +326,11 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *           the online softmax before the reference moves (default 8; 0 = the exact running maximum, the A/B leg of
  *           tests/test_sharp_parity_gpu.py)
  *   key 24  128-tile launches on the four-wave tile (2 x 2 waves of 64 x 64; 1 plain K loop, 2 register double buffer;
- *           default 0 = eight waves of 64 x 32; bit-identical) */
+ *           default 0 = eight waves of 64 x 32; bit-identical)
+ *   key 25  outputs with fewer than two rounds of 256-row tiles (the decoders' M = 32 x live positions): kernel chosen by the
+ *           rounds of the CUs it needs among 128 x 256 tiles in a three-stage operand ring (csrc/gemm_wp8_m128.hip), 256 x 256
+ *           on 16x16x32 and 320 x 256 (default 1; 0 = the lock-step 128 x 128 kernel; bit-identical)
+ */
 int dw_debug_set(int key, int value);
 
 #ifdef __cplusplus

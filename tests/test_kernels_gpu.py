@@ -217,6 +217,45 @@ def test_gemm_320_row_tiles_are_bit_identical(ops, ref, tb):
         ops.lib.dw_debug_set(0, 2163)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm_small_m_rule_is_bit_identical(ops, ref, tb):
+    """Outputs with fewer than two rounds of 256-row tiles (dw_debug_set key 25, gemm.hip): the 128 x 256 tile in a THREE-stage
+    operand ring (gemm_wp8_m128.hip: counted vmcnt waits, buffers rotating over t mod 3), the 256-row tile on 16x16x32 or the
+    320-row tile, chosen by the rounds of the CUs each needs.  Same fp32 chain over k per element as the lock-step 128 x 128
+    kernel the rule replaces: every bit agrees -- ragged M and N, 1..5 / 20 / 80 K tiles (every prologue / tail path of the
+    ring), one and several rounds of tiles, the step's epilogue flavours, repeated launches."""
+    try:
+        shapes = ((200, 392, 64), (520, 392, 128), (776, 1024, 192), (1100, 520, 256), (1300, 768, 320), (4258, 1280, 1280),
+                  (4480, 3840, 1280), (2240, 1280, 5120), (7136, 1280, 1280), (4352, 5120, 1280))
+        for M, N, K in shapes:
+            a = rnd((M, K), 0.5, seed=81)
+            b = rnd((K, N) if tb else (N, K), 0.1, seed=82)
+            bias = rnd((N,), 0.5, torch.float32, seed=83)
+            r16 = rnd((M, N), 1.0, seed=84)
+            r32 = rnd((M, N), 1.0, torch.float32, seed=85)
+            zin = rnd((M, N), 1.0, seed=86).to(torch.float16)
+            flavours = (dict(), dict(bias=bias), dict(bias=bias, act=1), dict(bias=bias, residual=r16),
+                        dict(bias=bias, residual=r32, out_dtype=torch.float32), dict(zgrad=zin), dict(bias=bias, act=1, want_z="grad"))
+            if K >= 5120: flavours = flavours[:2] + flavours[3:4]
+            ops.lib.dw_debug_set(25, 0)
+            want = []
+            for f in flavours:
+                o = ops.gemm(a, b, trans_b=tb, tile=128, **f)
+                want.append([t.clone() for t in o] if isinstance(o, tuple) else [o.clone()])
+            ops.lib.dw_debug_set(25, 1)
+            for tile in (0, 129):
+                for rep in range(2):
+                    for f, w in zip(flavours, want):
+                        o = ops.gemm(a, b, trans_b=tb, tile=tile, **f)
+                        o = list(o) if isinstance(o, tuple) else [o]
+                        for g_, w_ in zip(o, w):
+                            assert torch.equal(g_, w_), (M, N, K, tb, tile, sorted(f), rep, (g_.float() - w_.float()).abs().max().item())
+            assert relerr(want[0][0].float(), ref.gemm(a, b, trans_b=tb, out_dtype=torch.float32)) < 1e-2
+    finally:
+        ops.lib.dw_debug_set(25, 1)
+
+
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
 def test_gemm_16x16x32_main_loop_is_bit_identical(ops, ref, ta, tb):
     """gemm_wp16.h: the software-pipelined main loop on v_mfma_f32_16x16x32_bf16 (dw_debug_set key 20; the default for the
