@@ -274,6 +274,148 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// forward, software-pipelined across key tiles (non-causal shapes; dw_debug_set key 26).  In attn_fwd_kernel a wave runs
+// QK(t) -> softmax(t) -> PV(t) strictly in sequence: the softmax's ~100 vector instructions wait for the QK MFMAs to drain and the
+// PV MFMAs for the softmax, and only the other waves of the SIMD fill the holes.  Here the scores of tile t+1 are computed one
+// iteration ahead (two score register sets, ping-pong by name): inside an iteration the QK MFMAs of tile t+1 and the softmax of
+// tile t are independent instruction streams of the SAME wave -- the matrix pipe works on one while the vector unit works on the
+// other.  Costs: 32 more registers (three waves per SIMD instead of four) and a THIRD K / V stage in LDS (tile t+1 must be
+// resident while tile t is still read by the PV product): 48 KiB per workgroup, three workgroups per CU.
+// Same arithmetic per element and the same order of every sum as attn_fwd_kernel: bit-identical output.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW = 4>
+__global__ __launch_bounds__(64 * NW, 3) void attn_fwd_pipe_kernel(const AttnP p) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * 16384];  // [stage][K tile 8K | V tile 8K]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5, ln = lane & 31;
+    int tile, h, b;
+    attn_workgroup((p.Lq + 32 * NW - 1) / (32 * NW), p.H, p.plain_order, tile, h, b);
+    const int qb0 = tile * (32 * NW);
+    const int q = qb0 + wave * 32 + ln;
+    const bool q_ok = q < p.Lq;
+    const int qc = q_ok ? q : p.Lq - 1;
+    const bf16* Q = p.q + (long)b * p.q_rows * p.ldq + h * 64;
+    const bf16* K = p.k + (long)b * p.kv_rows * p.ldk + h * 64;
+    const bf16* V = p.v + (long)b * p.kv_rows * p.ldv + h * 64;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = ldg8(Q, qc, p.ldq, kk * 16 + hi * 8);
+    const int nkt = (p.Lk + 63) >> 6;
+    const float c = p.scale * 1.4426950408889634f;
+    float m_run = NEG_BIG, l_run = 0.f;
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+
+    auto stage = [&](int kt, int st) __attribute__((always_inline)) {
+        stage_tile64<NW>(K, p.ldk, kt * 64, p.Lk, smem + st * 16384, wave, lane);
+        stage_tile64<NW>(V, p.ldv, kt * 64, p.Lk, smem + st * 16384 + 8192, wave, lane);
+    };
+    // S^T of key tile kt (stage st), masked on the tail tile
+    auto scores = [&](int kt, int st, f32x16 (&s)[2]) __attribute__((always_inline)) {
+        const char* tK = smem + st * 16384;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(tK, kb, kk, lane), qf[kk], s[kb], 0, 0, 0);
+        }
+        if ((kt + 1) * 64 > p.Lk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    s[kb][r] = key < p.Lk ? s[kb][r] : NEG_BIG;
+                }
+        }
+    };
+    // softmax of one tile's scores (in place: s becomes P) + the PV product out of stage st
+    auto softmax_pv = [&](int st, f32x16 (&s)[2]) __attribute__((always_inline)) {
+        const char* tV = smem + st * 16384 + 8192;
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = xhalf_max(mx);
+        const bool move = __any((mx - m_run) * c > p.defer);
+        const float m_new = move ? fmaxf(m_run, mx) : m_run;
+        const float mc = m_new * c;
+        f32x2 rs2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+        const f32x2 c2 = {c, c}, mc2 = {mc, mc};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 t = {s[kb][r], s[kb][r + 1]};
+                t = t * c2 - mc2;
+                const f32x2 pv = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                s[kb][r] = pv[0];
+                s[kb][r + 1] = pv[1];
+                rs2[(r >> 1) & 1] += pv;
+            }
+        rs2[0] += rs2[1];
+        float rs = rs2[0][0] + rs2[0][1];
+        rs = xhalf_sum(rs);
+        if (move) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
+        l_run += rs;
+        m_run = m_new;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(s[kb], s2);
+                const int rb = kb * 32 + s2 * 16 + hi * 4;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tV, db, rb, rb + 8, lane), pf, o[db], 0, 0, 0);
+            }
+    };
+
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+    wait_vm0_seen();
+    __syncthreads();
+    f32x16 sa[2], sb[2];
+    scores(0, 0, sa);
+    // iteration kt: tile kt's scores are in `cur`; tile kt in stage st0, tile kt+1 (requested an iteration ago) in st1
+    auto iter = [&](int kt, int st0, int st1, int st2, f32x16 (&cur)[2], f32x16 (&nxt)[2]) __attribute__((always_inline)) {
+        if (kt > 0) {                       // (iteration 0: tiles 0 and 1 were waited for in front of the loop)
+            wait_vm0_seen();                // tile kt+1 has landed ...
+            __syncthreads();                // ... for every wave, and every wave is done with tile kt-1 (stage st2)
+        }
+        if (kt + 2 < nkt) stage(kt + 2, st2);
+        if (kt + 1 < nkt) scores(kt + 1, st1, nxt);
+        softmax_pv(st0, cur);
+    };
+    int st0 = 0, st1 = 1, st2 = 2;
+    for (int kt = 0; kt < nkt; kt += 2) {
+        iter(kt, st0, st1, st2, sa, sb);
+        if (kt + 1 < nkt) iter(kt + 1, st1, st2, st0, sb, sa);
+        const int t0 = st0; st0 = st2; st2 = st1; st1 = t0;      // two tiles on: (st0, st1, st2) -> (st2, st0, st1)
+    }
+    const float inv = 1.0f / l_run;
+    bf16* O = p.o + (long)b * p.q_rows * p.ldo + h * 64;
+    if (DW_ATTN_ROWSTORE && (p.ldo & 7) == 0 && ((uintptr_t)p.o & 15) == 0) {
+        __syncthreads();
+        store_rows(O, p.ldo, qb0 + wave * 32, p.Lq, smem + wave * 4608, lane, o[0], o[1], inv);
+    } else {
+        store_t(O, p.ldo, q, q_ok, 0, hi, o[0], inv);
+        store_t(O, p.ldo, q, q_ok, 1, hi, o[1], inv);
+    }
+    if (p.lse && q_ok && hi == 0) p.lse[((long)b * p.H + h) * p.Lq + q] = m_run * p.scale + __logf(l_run);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // decode: ONE query per (batch, head) against Lk cached keys/values (cross-attention over the 1500 encoder positions
 // and self-attention over the tokens so far, TF:modeling_whisper.py:312-335).  HBM-bound: every K and V byte is read
 // exactly once (15.4 MB of cross K/V per sequence and decoder layer pair), nothing is staged or re-read.
@@ -725,6 +867,7 @@ int g_attn_bwd_stage = 5;  // (dw_debug_set key 3; 5 measured best: 1.65 vs 1.75
 int g_attn_bwd_waves = 4;  // dw_debug_set key 17: 4 / 12 waves per workgroup of the non-causal backward kernels (12: 384 stationary
                            // rows per workgroup, a third of the tile staging -- measured neutral at the encoder shape, slower at 448 x 1500)
 int g_attn_fwd_waves = 4;  // dw_debug_set key 16: 4 / 8 waves (x 32 queries) per workgroup of the non-causal forward kernel (8: half
+int g_attn_fwd_pipe = 0;      // dw_debug_set key 26: non-causal forward on attn_fwd_pipe_kernel (scores of tile t+1 under the softmax of tile t)
                            // the K/V staging per query -- measured neutral: the kernel is not bound by the staging traffic)
 int g_attn_plain_order = 0; // dw_debug_set key 18
 int g_attn_defer = DW_ATTN_DEFER;  // dw_debug_set key 23: the forward's deferred-maximum threshold (0 = exact running maximum; the
@@ -793,6 +936,7 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     // are fetched and written to LDS once per 256 queries (1500 -> 1536 and 448 -> 512 either way)
     const int g8 = (Lq + 255) / 256;
     if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, p);
+    else if (g_attn_fwd_pipe && Lk > 64) hipLaunchKernelGGL(attn_fwd_pipe_kernel<4>, grid, block, 0, s, p);
     else if (g_attn_fwd_waves == 8 && g8 * 2 == g4 && (long)g8 * H * B >= 512)
         hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), dim3(g8 * H * B), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, p);

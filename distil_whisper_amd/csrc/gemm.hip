@@ -50,6 +50,7 @@ extern int g_attn_bwd_stage;  // attention.hip
 extern int g_attn_decode;
 extern int g_attn_ablate;
 extern int g_attn_fwd_waves;
+extern int g_attn_fwd_pipe;
 extern int g_attn_plain_order;
 extern int g_attn_defer;
 extern int g_attn_bwd_waves;
@@ -131,6 +132,7 @@ extern "C" int dw_debug_set(int key, int value) {
     if (key == 21) { g_ln_variant = value; return DW_OK; }
     if (key == 22) { g_gemm_row_tail = value; return DW_OK; }
     if (key == 25) { g_gemm_small_m = value; return DW_OK; }
+    if (key == 26) { g_attn_fwd_pipe = value; return DW_OK; }
     if (key == 18) { g_attn_plain_order = value; return DW_OK; }
     if (key == 24) { if (value < 0 || value > 2) return DW_EINVAL; g_gemm_t128_w4 = value; return DW_OK; }
     if (key == 23) { if (value < 0 || value > 64) return DW_EINVAL; g_attn_defer = value; return DW_OK; }
@@ -267,7 +269,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
     if (tile == 129 && (g->trans_a || p.split_k != 1 || p.atomic)) return DW_EINVAL;   // (tile 129: force the software-pipelined 128 x 256 tile)
     bool one_round_320 = false;
     bool small_m_256 = false;       // a 256-row kernel chosen by the small-M rule below: runs on the 16x16x32 loop
-    if (tile != 128 && tile != 256) {
+    if (tile != 128 && tile != 256 && !(tile == 129 && g_gemm_small_m == 2)) {     // (key 25 = 2: tile 129 forces the 128-row kernel at any size -- probing)
         const long tn = (g->n + 255) / 256;
         const long t256 = (long)((g->m + 255) / 256) * tn;
         tile = t256 >= 512 ? 256 : 128;

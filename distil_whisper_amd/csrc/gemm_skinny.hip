@@ -27,7 +27,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int SK_MAXS = 10;   // 32-deep k steps a wave keeps in registers (10 x 16 B of W + as much of A per lane)
 constexpr int SK_MAXW = 16;   // waves per workgroup
-int g_skinny_wide = 1;        // dw_debug_set key 8: wide (64 columns per workgroup) variant for the LM head
+int g_skinny_wide = 5;        // dw_debug_set key 8: bit 0 wide (64 columns per workgroup) variant for the LM head; bit 1: LayerNorm variants keep ONE column block per workgroup; bits 2-3: columns per workgroup of the projections back to d_model (4: 8 columns, the default; 0: 4; 12: 16)
 
 // 8 consecutive elements of the LayerNorm input (f32 or bf16) as floats
 template <bool XBF>
@@ -45,29 +45,47 @@ __device__ __forceinline__ void ld_x8(const void* x, long off, float (&v)[8]) {
 
 // LN: 0 = A is a ready bf16 operand; 1 / 2 = A = bf16(LayerNorm(ln_x)), ln_x in f32 / bf16 (k <= 1280: <= 4 waves, so
 // the kernel may use up to 512 registers per lane and keep the row slices resident)
-template <int MB, int LN>
+// NB (LayerNorm variants only): 16-column weight blocks per workgroup.  A LayerNorm-on-load workgroup keeps ~300 registers per
+// lane (row slices, gamma, beta, weight fragments): ONE workgroup per CU, so fc1's 320 blocks of 16 columns were two rounds of the
+// 256 CUs (18.2 us against 10.5 for the 240 blocks of the QKV projection, profiles/r6_decode_step_sequence.md) and every
+// workgroup repeated the row statistics of all 16 rows for 40 KB of weights.  With two blocks per workgroup the launch is 160 /
+// 120 workgroups -- one round -- and the LayerNorm work per weight byte halves.
+// VR (plain variant only): weight rows (output columns) a workgroup owns, 16 / 8 / 4.  A projection back to d_model has N / 16 = 80
+// workgroups at D = 1280 -- 80 of the 256 CUs pull the weights, and a CU sustains ~25 GB/s of misses (fc2's 13 MB: 12 us against a
+// 5.5 us launch floor).  With 8 or 4 valid rows per workgroup (the other lanes of the 16-row MFMA operand stay zero: the matrix
+// pipe is idle here anyway) the same bytes are pulled by 160 / 320 workgroups.
+template <int MB, int LN, int NB = 1, int VR = 16>
 __global__ __launch_bounds__(LN ? 256 : 64 * SK_MAXW) void gemm_skinny_kernel(const GemmP p, int nw, int steps_total) {
-    extern __shared__ float red[];  // [nw][MB][64][4]
+    extern __shared__ float red[];  // [nw][NB][MB][64][4]
+    static_assert(NB == 1 || LN != 0, "several column blocks per workgroup: the LayerNorm variants");
+    static_assert(VR == 16 || (LN == 0 && NB == 1 && (VR == 8 || VR == 4)), "partial column blocks: the plain variant");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * (VR == 16 ? 16 * NB : VR);
     const int r16 = lane & 15, g = lane >> 4;
     // this wave's k steps: [s0, s0 + ns)
     const int base = steps_total / nw, rem = steps_total - base * nw;
     const int s0 = wave * base + (wave < rem ? wave : rem);
     const int ns = base + (wave < rem ? 1 : 0);
 
-    int wrow = n0 + r16;
-    wrow = wrow < p.n ? wrow : p.n - 1;
-    const bf16* wp = p.b + (long)wrow * p.ldb + (long)s0 * 32 + g * 8;
-    bf16x8 wf[SK_MAXS];
+    bf16x8 wf[NB][SK_MAXS];
 #pragma unroll
-    for (int s = 0; s < SK_MAXS; ++s)
-        if (s < ns) wf[s] = ld_stream<1>((const bf16x8*)(wp + s * 32));
+    for (int nb = 0; nb < NB; ++nb) {
+        int wrow = n0 + nb * 16 + r16;
+        wrow = wrow < p.n ? wrow : p.n - 1;
+        const bf16* wp = p.b + (long)wrow * p.ldb + (long)s0 * 32 + g * 8;
+#pragma unroll
+        for (int s = 0; s < SK_MAXS; ++s) {
+            if constexpr (VR < 16) wf[nb][s] = bf16x8{};
+            if (s < ns && (VR == 16 || r16 < VR)) wf[nb][s] = ld_stream<1>((const bf16x8*)(wp + s * 32));
+        }
+    }
 
-    f32x4_t acc[MB];
+    f32x4_t acc[NB][MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     if constexpr (LN != 0) {
         constexpr bool XBF = LN == 2;
         // this lane's slices of rows mb*16 + r16: k = (s0 + s)*32 + g*8 + 0..7
@@ -143,7 +161,8 @@ __global__ __launch_bounds__(LN ? 256 : 64 * SK_MAXW) void gemm_skinny_kernel(co
                     bf16x8 af;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) af[e] = f2bf((xs[mb][s][e] - mu[mb]) * rs[mb] * gm[s][e] + bt[s][e]);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af, acc[mb], 0, 0, 0);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], af, acc[nb][mb], 0, 0, 0);
                 }
         }
     } else {
@@ -158,23 +177,26 @@ __global__ __launch_bounds__(LN ? 256 : 64 * SK_MAXW) void gemm_skinny_kernel(co
             if (s < ns) af[s] = *(const bf16x8*)(ap + s * 32);
 #pragma unroll
         for (int s = 0; s < SK_MAXS; ++s)
-            if (s < ns) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[s], acc[mb], 0, 0, 0);
+            if (s < ns) acc[0][mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][s], af[s], acc[0][mb], 0, 0, 0);
     });
     }
     // acc[mb][r] = partial C[m = mb*16 + (lane & 15)][n = n0 + 4*(lane >> 4) + r]
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) *(f32x4_t*)(red + ((wave * MB + mb) * 64 + lane) * 4) = acc[mb];
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) *(f32x4_t*)(red + (((wave * NB + nb) * MB + mb) * 64 + lane) * 4) = acc[nb][mb];
     __syncthreads();
-    for (int idx = threadIdx.x; idx < MB * 64; idx += blockDim.x) {
-        const int mb = idx >> 6, l = idx & 63;
+    for (int idx = threadIdx.x; idx < NB * MB * 64; idx += blockDim.x) {
+        const int nb = idx / (MB * 64), mb = (idx >> 6) % MB, l = idx & 63;
         f32x4_t v4 = {0.f, 0.f, 0.f, 0.f};
         for (int w = 0; w < nw; ++w) {
-            const f32x4_t t = *(const f32x4_t*)(red + ((w * MB + mb) * 64 + l) * 4);
+            const f32x4_t t = *(const f32x4_t*)(red + (((w * NB + nb) * MB + mb) * 64 + l) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v4[e] += t[e];
         }
         const int m = mb * 16 + (l & 15);
-        const int n = n0 + 4 * (l >> 4);
+        const int n = n0 + nb * 16 + 4 * (l >> 4);
+        if (VR < 16 && 4 * (l >> 4) >= VR) continue;
         if (m >= p.m || n >= p.n) continue;      // (n is a multiple of 4 and p.n of 16: all four columns are valid)
         float v[4] = {v4[0], v4[1], v4[2], v4[3]};
         if (p.bias) {
@@ -308,7 +330,7 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s) {
     if (nw > SK_MAXW) nw = SK_MAXW;
     if ((steps + nw - 1) / nw > SK_MAXS) return DW_EINVAL;
     const int mb = (p.m + 15) / 16;
-    if (g_skinny_wide && !p.bias && !p.act && !p.r && !p.ln_x && !p.kv_out && nw <= 4 && p.n >= 16384 && mb <= 2) {
+    if ((g_skinny_wide & 1) && !p.bias && !p.act && !p.r && !p.ln_x && !p.kv_out && nw <= 4 && p.n >= 16384 && mb <= 2) {
         constexpr int NB = 4;
         dim3 grid((p.n + 16 * NB - 1) / (16 * NB)), block(64 * nw);
         const size_t lds = (size_t)nw * NB * mb * 64 * 4 * sizeof(float);
@@ -321,10 +343,29 @@ int dw_gemm_skinny_launch(const GemmP& p, hipStream_t s) {
     const size_t lds = (size_t)nw * (mb == 3 ? 4 : mb) * 64 * 4 * sizeof(float);
     if (p.ln_x) {
         const bool xbf = p.ln_x_dtype == DW_BF16;
+        // two column blocks per workgroup when that is what brings the launch into one round of the CUs (or halves a round that
+        // fits already, one row block only: the LayerNorm prologue is the same work per workgroup); dw_debug_set key 8 bit 1 = off
+        // (measured at batch 16, D = 1280: fc1's 320 blocks 18.2 -> 12.5 us; the QKV projection's 240 blocks fit one round already
+        // and LOSE 1.5 us as 120 workgroups -- fewer CUs pulling the weights)
+        if (mb == 1 && (g_skinny_wide & 2) == 0 && p.n % 32 == 0 && p.n / 16 > 256) {
+            dim3 grid2(p.n / 32);
+            if (!xbf) hipLaunchKernelGGL((gemm_skinny_kernel<1, 1, 2>), grid2, block, 2 * lds, s, p, nw, steps);
+            else hipLaunchKernelGGL((gemm_skinny_kernel<1, 2, 2>), grid2, block, 2 * lds, s, p, nw, steps);
+            DW_CHECK_LAUNCH();
+            return DW_OK;
+        }
         if (mb == 1 && !xbf) hipLaunchKernelGGL((gemm_skinny_kernel<1, 1>), grid, block, lds, s, p, nw, steps);
         else if (mb == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, 2>), grid, block, lds, s, p, nw, steps);
         else if (!xbf) hipLaunchKernelGGL((gemm_skinny_kernel<2, 1>), grid, block, lds, s, p, nw, steps);
         else hipLaunchKernelGGL((gemm_skinny_kernel<2, 2>), grid, block, lds, s, p, nw, steps);
+    } else if (mb == 1 && p.n / 16 <= 128 && (g_skinny_wide & 12) != 12) {
+        // few column blocks (a projection back to d_model): 8 columns per workgroup so that 160 instead of 80 CUs pull the weights.
+        // Measured at batch 16, D = 1280 (eager token step, tools/decode_profile.py): 16 columns 0.2195 ms, 8 columns 0.2161, 4 columns
+        // 0.2319 -- every workgroup fetches the activation slice of all 16 rows, so more workgroups multiply the L2 traffic
+        // (fc2: 160 KB per workgroup) and four columns lose what the spread wins.
+        // (dw_debug_set key 8 bits 2-3: 0 -> 4 columns, 4 -> 8 columns, 12 -> 16 columns as before)
+        if (g_skinny_wide & 4) hipLaunchKernelGGL((gemm_skinny_kernel<1, 0, 1, 8>), dim3(p.n / 8), block, lds, s, p, nw, steps);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<1, 0, 1, 4>), dim3(p.n / 4), block, lds, s, p, nw, steps);
     } else if (mb == 1) hipLaunchKernelGGL((gemm_skinny_kernel<1, 0>), grid, block, lds, s, p, nw, steps);
     else if (mb == 2) hipLaunchKernelGGL((gemm_skinny_kernel<2, 0>), grid, block, lds, s, p, nw, steps);
     else hipLaunchKernelGGL((gemm_skinny_kernel<4, 0>), grid, block, lds, s, p, nw, steps);

@@ -17,6 +17,7 @@ model = WhisperForConditionalGeneration(sdims, ops=ops, state_dict=s_sd)
 fe = WhisperFeatureExtractor(feature_size=128, ops=ops)
 B, NEW = int(os.environ.get("B", 16)), int(os.environ.get("NEW", 64))
 ops.lib.dw_debug_set(7, int(os.environ.get("FUSE_OFF", 4)))
+ops.lib.dw_debug_set(8, int(os.environ.get("DW_KEY8", 5)))
 tr = LongFormTranscriber(model, fe, batch_size=B, max_new_tokens=NEW, use_graphs=bool(int(os.environ.get("GRAPHS", 1))))
 feats = torch.randn(B, 128, 3000, device=dev) * 0.5
 enc, _ = model.engine.encode(feats, save=False)
