@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdwamd.so")
-SOURCES = ["gemm.hip", "gemm_tile256.hip", "gemm_tile128.hip", "gemm_tile128w4.hip", "gemm_phased.hip", "gemm_wp8_nn.hip", "gemm_wp8_nn_ref.hip", "gemm_wp8_dbg.hip", "gemm_wp8_m320.hip", "gemm_wp8_m128.hip", "gemm_wp8_nt.hip", "gemm_wp8_tt.hip", "gemm_wp16_nn.hip", "gemm_wp16_nt.hip", "gemm_wp16_tt.hip", "gemm_wp16_w4.hip", "gemm_skinny.hip", "attention.hip", "norm.hip", "loss.hip", "logmel.hip", "elementwise.hip", "optim.hip", "decode.hip"]
+SOURCES = ["gemm.hip", "gemm_tile256.hip", "gemm_tile128.hip", "gemm_tile128w4.hip", "gemm_phased.hip", "gemm_wp8_nn.hip", "gemm_wp8_nn_ref.hip", "gemm_wp8_dbg.hip", "gemm_wp8_m320.hip", "gemm_wp8_m128.hip", "gemm_wp8_nt.hip", "gemm_wp8_tt.hip", "gemm_wp16_nn.hip", "gemm_wp16_nt.hip", "gemm_wp16_small.hip", "gemm_wp16_tt.hip", "gemm_wp16_w4.hip", "gemm_skinny.hip", "attention.hip", "norm.hip", "loss.hip", "logmel.hip", "elementwise.hip", "optim.hip", "decode.hip"]
 # -munsafe-fp-atomics: float atomicAdd becomes the hardware global_atomic_add_f32 instead of a CAS loop
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-munsafe-fp-atomics"]
 

@@ -283,8 +283,8 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
 // resident while tile t is still read by the PV product): 48 KiB per workgroup, three workgroups per CU.
 // Same arithmetic per element and the same order of every sum as attn_fwd_kernel: bit-identical output.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NW = 4>
-__global__ __launch_bounds__(64 * NW, 3) void attn_fwd_pipe_kernel(const AttnP p) {
+template <int NW = 4, int OCC = 3>
+__global__ __launch_bounds__(64 * NW, OCC) void attn_fwd_pipe_kernel(const AttnP p) {
     __shared__ __attribute__((aligned(1024))) char smem[3 * 16384];  // [stage][K tile 8K | V tile 8K]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -936,7 +936,8 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     // are fetched and written to LDS once per 256 queries (1500 -> 1536 and 448 -> 512 either way)
     const int g8 = (Lq + 255) / 256;
     if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, 0, s, p);
-    else if (g_attn_fwd_pipe && Lk > 64) hipLaunchKernelGGL(attn_fwd_pipe_kernel<4>, grid, block, 0, s, p);
+    else if (g_attn_fwd_pipe == 2 && Lk > 64) hipLaunchKernelGGL((attn_fwd_pipe_kernel<4, 2>), grid, block, 0, s, p);
+    else if (g_attn_fwd_pipe && Lk > 64) hipLaunchKernelGGL((attn_fwd_pipe_kernel<4, 3>), grid, block, 0, s, p);
     else if (g_attn_fwd_waves == 8 && g8 * 2 == g4 && (long)g8 * H * B >= 512)
         hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), dim3(g8 * H * B), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, p);

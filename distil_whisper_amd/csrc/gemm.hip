@@ -43,6 +43,8 @@ int dw_gemm_wp16_nn_launch(const GemmP& p, hipStream_t s);                  // g
 int dw_gemm_wp16_nn320_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp16_nt_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp16_nt320_launch(const GemmP& p, hipStream_t s);
+int dw_gemm_wp16_nn_small_launch(const GemmP& p, hipStream_t s);             // gemm_wp16_small.hip (the small-M rule's 256-row launches)
+int dw_gemm_wp16_nt_small_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp16_tt_launch(const GemmP& p, hipStream_t s);
 int dw_gemm_wp16_nn_dbg_launch(const GemmP& p, int dbg, hipStream_t s);
 
@@ -341,7 +343,7 @@ extern "C" int dw_gemm_bf16(const DwGemm* g, void* stream) {
                               !g->r && !g->z_out && !g->zgrad_in && g->c_dtype != DW_F32 &&    // (the flavours of the accumulator-side walk)
                               !one_round_320 && !(v & 4096) && !g_gemm_dbg;   // (a forced / single-round 320-row tile and the ablation path keep their kernel)
         auto launch256 = [&](const GemmP& q) -> int {
-            if (small_m_256 && wp_ok && !g_gemm_dbg) return g->trans_b ? dw_gemm_wp16_nt_launch(q, s) : dw_gemm_wp16_nn_launch(q, s);
+            if (small_m_256 && wp_ok && !g_gemm_dbg) return g->trans_b ? dw_gemm_wp16_nt_small_launch(q, s) : dw_gemm_wp16_nn_small_launch(q, s);
             if (nn16_256) {
                 // Row tail (round 5; dw_debug_set key 22, default on): M = 48 000 is 187.5 row tiles -- 2 820 tiles = 11.02 rounds of the
                 // CUs, and with the per-XCD job ranges four XCDs run a TWELFTH round for four tiles (8 % of the launch).  The last,

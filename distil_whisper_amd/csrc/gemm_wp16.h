@@ -54,7 +54,9 @@ __device__ __forceinline__ bf16x8 frag_kmajor16(const char* tile, int x, int ks,
 
 #define PINQ(f) asm volatile("" : "+v"(f))
 
-template <bool TA, bool TB, int BM = 256, int DBG = 0, int WN = 4>
+// TAG: no effect on the code -- a second symbol for the launches the small-M rule of gemm.hip sends here (outputs below two rounds
+// of 256-row tiles), so that per-kernel profiles (rocprofv3, tools/pmc_traffic.py) can tell them from the step's wide launches.
+template <bool TA, bool TB, int BM = 256, int DBG = 0, int WN = 4, int TAG = 0>
 __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(const GemmP p) {
     // WN = 4: eight waves (two per SIMD), 128 x 64 (160 x 64) per wave.  WN = 2: FOUR waves, one per SIMD, 128 x 128 per wave --
     // 32 fragment reads per 128 MFMAs instead of 24 per 64: the LDS port (128 B per clock: 192 KiB of fragment reads + 64 KiB of
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(WN * 128, WN == 4 ? 2 : 1) void gemm_wp16_kernel(co
     gemm_jobs_end(p, jobs);
 }
 
-template <bool TA, bool TB, int BM = 256, int DBG = 0, int WN = 4>
+template <bool TA, bool TB, int BM = 256, int DBG = 0, int WN = 4, int TAG = 0>
 static int launch_wp16(const GemmP& p0, hipStream_t s) {
     GemmP p = p0;
     const int tiles_m = (p.m + BM - 1) / BM;
@@ -336,7 +338,7 @@ static int launch_wp16(const GemmP& p0, hipStream_t s) {
     p.strip = gemm_strip_width(p.k, p.tiles_n, p.strip);
     int nblk = p.nwg * p.split_k;
     if (nblk > g_gemm_cus) nblk = g_gemm_cus;
-    hipLaunchKernelGGL((gemm_wp16_kernel<TA, TB, BM, DBG, WN>), dim3(nblk), dim3(WN * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm_wp16_kernel<TA, TB, BM, DBG, WN, TAG>), dim3(nblk), dim3(WN * 128), 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -312,7 +312,8 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *           and 2 apply to the NON-causal dK/dV kernel only: the causal launch always runs two waves per SIMD; default 5);   key 4  single-query attention kernel (bit 0 on [default], bit 1 all-loads-up-front variant)
  *   key 5   log-mel DFT on the matrix cores (default 1);   key 7  decode-step fusions off (bit 0 LayerNorm-on-load,
  *           bit 1 K/V append, bit 2 self-attention with its q / k / v projection inside, bit 3 cross-attention with its q
- *           projection inside; default 4);   key 8  wide LM-head GEMV (default 1)
+ *           projection inside; default 4);   key 8  token-step GEMVs, bit mask (default 5): bit 0 wide LM-head kernel; bit 1 LayerNorm-on-load kernels keep one
+ *           column block per workgroup; bits 2-3 columns per workgroup of the projections back to d_model (4: 8, 0: 4, 12: 16)
  *   key 19  row-major 256-row GEMMs run main-loop ablation `value` (1 no fragment reads, 2 no operand DMA, 3 both, 4 DMA that
  *           always hits L2; WRONG results by construction; tools/gemm_dma_diag.py);   key 20  bit mask: software-pipelined GEMM
  *           kernels on v_mfma_f32_16x16x32_bf16 (1 row-major, 2 k-major B, 4 both k-major, 32 row-major with K <= 2560 and
@@ -329,7 +330,11 @@ int dw_selftest_tr16(int32_t* out, void* stream);
  *           default 0 = eight waves of 64 x 32; bit-identical)
  *   key 25  outputs with fewer than two rounds of 256-row tiles (the decoders' M = 32 x live positions): kernel chosen by the
  *           rounds of the CUs it needs among 128 x 256 tiles in a three-stage operand ring (csrc/gemm_wp8_m128.hip), 256 x 256
- *           on 16x16x32 and 320 x 256 (default 1; 0 = the lock-step 128 x 128 kernel; bit-identical)
+ *           on 16x16x32 and 320 x 256 (default 1; 0 = the lock-step 128 x 128 kernel; 2 = as 1, and DwGemm.tile 129 forces the
+ *           128-row kernel at any size; bit-identical)
+ *   key 26  non-causal attention forward on the software-pipelined kernel (scores of key tile t+1 under the softmax of tile
+ *           t, three K / V stages; 1: three waves per SIMD, 2: two).  Default 0: measured 8 % / 15 % SLOWER than the four-waves-
+ *           per-SIMD kernel at the encoder shape (tools/attn_pipe_ab.py), bit-identical -- kept as the A/B of that design
  */
 int dw_debug_set(int key, int value);
 

@@ -76,8 +76,9 @@ SCRATCH_BUDGET = [
     # (round 6: the 128 x 256 tile in a three-stage ring for outputs below two rounds of 256-row tiles; 164 registers)
     ("gemm_wp8_m128", r"gemm_wp_kernel<false, (true|false), 2, 4, true, 0, 128, 3>", 0, 0),
     # (one lane index parked at the top of the epilogue, reloaded in the bf16-output walk only -- the weight-gradient launches store fp32)
-    ("gemm_wp16_tt", r"gemm_wp16_kernel<true, true, 256, 0, 4>", 8, 2),
-    ("gemm_wp16_nn", r"gemm_wp16_kernel<false, false, 256, 0, 4>", 0, 0),
+    ("gemm_wp16_tt", r"gemm_wp16_kernel<true, true, 256, 0, 4, 0>", 8, 2),
+    ("gemm_wp16_nn", r"gemm_wp16_kernel<false, false, 256, 0, 4, 0>", 0, 0),
+    ("gemm_wp16_small", r"gemm_wp16_kernel<false, (true|false), 256, 0, 4, 1>", 8, 2),   # (the k-major-B form parks one lane index, like the weight-gradient kernel)
 ]
 
 

@@ -44,8 +44,14 @@ def test_main_loop_kernels_map_to_the_keys_ops_hip_reports():
         for tb in (False, True):
             key = f"gemm_t256_{'T' if ta else 'N'}{'T' if tb else 'N'}"
             a, b = str(ta).lower(), str(tb).lower()
-            assert pt.classify(f"void gemm_wp16_kernel<{a}, {b}, 256, 0, 4>(GemmP)") == key
-            assert pt.classify(f"void gemm_wp_kernel<{a}, {b}, 2, 4, true, 0, 320>(GemmP)") == key
+            assert pt.classify(f"void gemm_wp16_kernel<{a}, {b}, 256, 0, 4, 0>(GemmP)") == key
+            assert pt.classify(f"void gemm_wp_kernel<{a}, {b}, 2, 4, true, 0, 320, 2>(GemmP)") == key
+    # the small-M rule's kernels (dw_debug_set key 25) report under the keys ops_hip.py gives launches below two rounds of 256-row tiles
+    for tb in (False, True):
+        key = f"gemm_t128_N{'T' if tb else 'N'}"
+        b = str(tb).lower()
+        assert pt.classify(f"void gemm_wp_kernel<false, {b}, 2, 4, true, 0, 128, 3>(GemmP)") == key
+        assert pt.classify(f"void gemm_wp16_kernel<false, {b}, 256, 0, 4, 1>(GemmP)") == key
 
 
 def test_bench_refuses_traffic_with_a_wrong_launch_count(tmp_path, monkeypatch):

@@ -9,9 +9,9 @@ for B, Lq, Lk in ((32, 1500, 1500), (32, 223, 1500), (7, 333, 777)):
     q = torch.randn(B * Lq, H * 64, device="cuda").bfloat16()
     k, v = [torch.randn(B * Lk, H * 64, device="cuda").bfloat16() for _ in range(2)]
     outs = {}
-    res = {0: [], 1: []}
+    res = {0: [], 1: [], 2: []}
     for r in range(5):
-        for key in (0, 1):
+        for key in (0, 1, 2):
             ops.lib.dw_debug_set(26, key)
             for _ in range(2): o, lse = ops.attn_fwd(q, k, v, B, H, Lq, Lk, False, 0.125)
             torch.cuda.synchronize()
@@ -21,7 +21,7 @@ for B, Lq, Lk in ((32, 1500, 1500), (32, 223, 1500), (7, 333, 777)):
             e.record(); torch.cuda.synchronize()
             res[key].append(s.elapsed_time(e) / 10 * 1e3)
             outs[key] = (o.clone(), lse.clone())
-    same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    same = all(torch.equal(outs[0][0], outs[k_][0]) and torch.equal(outs[0][1], outs[k_][1]) for k_ in (1, 2))
     fl = 4.0 * B * H * Lq * Lk * 64
     med = {k_: sorted(v_)[len(v_) // 2] for k_, v_ in res.items()}
     print(f"B={B} Lq={Lq} Lk={Lk} identical={same} max|do|={(outs[0][0].float() - outs[1][0].float()).abs().max().item():.3g} " +

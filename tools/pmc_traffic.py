@@ -21,6 +21,10 @@ CLASS_OF = [  # kernel symbol -> the per-class key bench.py / ops_hip.py use
     (r"gemm_kernel<256, 256, \d+, \d+, false, false", "gemm_t256_NN"), (r"gemm_kernel<256, 256, \d+, \d+, false, true", "gemm_t256_NT"),
     (r"gemm_kernel<256, 256, \d+, \d+, true, false", "gemm_t256_TN"), (r"gemm_kernel<256, 256, \d+, \d+, true, true", "gemm_t256_TT"),
     (r"gemm_kernel<128, 128, \d+, \d+, false, false", "gemm_t128_NN"), (r"gemm_kernel<128, 128, \d+, \d+, false, true", "gemm_t128_NT"),
+    # round 6: the small-M rule's kernels (outputs below two rounds of 256-row tiles; ops_hip.py keys those launches gemm_t128_*):
+    # the 128 x 256 tile in a three-stage ring and the 256-row 16x16x32 kernels under their second symbol (TAG = 1)
+    (r"gemm_wp_kernel<false, false, 2, 4, true, 0, 128, 3>", "gemm_t128_NN"), (r"gemm_wp_kernel<false, true, 2, 4, true, 0, 128, 3>", "gemm_t128_NT"),
+    (r"gemm_wp16_kernel<false, false, 256, 0, 4, 1>", "gemm_t128_NN"), (r"gemm_wp16_kernel<false, true, 256, 0, 4, 1>", "gemm_t128_NT"),
     (r"gemm_wp_kernel<false, false", "gemm_t256_NN"), (r"gemm_wp_kernel<false, true", "gemm_t256_NT"),
     (r"gemm_wp_kernel<true, true", "gemm_t256_TT"), (r"gemm_wp_kernel<true, false", "gemm_t256_TN"),
     # the 16x16x32 main loops (gemm_wp16.h): same class keys as the 32x32x16 kernels they replace per shape -- round 4 added the

@@ -17,10 +17,17 @@ del t_sd, s_sd
 B, T = int(os.environ.get("B", 32)), 447
 audio = 0.1 * torch.randn(B, 480000, device=dev)
 ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = tdims.decoder_start_token_id
-dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone(); labels[:, 200:] = -100
+dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone()
+# DW_LENS=1: bench.py's batch (label lengths U{32..224}, the step over the live decoder rows only)
+if os.environ.get("DW_LENS"):
+    lens = torch.randint(32, 225, (B,), generator=torch.Generator().manual_seed(1234)).tolist()
+    labels[torch.arange(T, device=dev)[None, :] >= torch.tensor(lens, device=dev)[:, None]] = -100
+else:
+    lens = None
+    labels[:, 200:] = -100
 def step():
-    return tr.train_step(tr.features(audio), dec_in, labels)
-ops.lib.dw_debug_set(0, int(os.environ.get('DW_VARIANT', 3)))  # 3 = the library default layouts
+    return tr.train_step(tr.features(audio), dec_in, labels, valid_len=lens)
+ops.lib.dw_debug_set(0, int(os.environ.get('DW_VARIANT', 2163)))  # 2163 = the library default (dw_debug_set key 0)
 for _ in range(2): step()
 torch.cuda.synchronize()
 ops.profile_detail = True
