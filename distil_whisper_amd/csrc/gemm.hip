@@ -112,7 +112,7 @@ static int* gemm_sched_slot(hipStream_t s) {
     slots[s] = ptr;
     return ptr;
 }
-int g_gemm_strip_budget = 8;   // x 512 KiB of L2 for the resident strip of B tiles
+int g_gemm_strip_budget = 4;   // x 512 KiB of L2 for the resident strip of B tiles (round 6: 8 -> 4, i.e. strips of 3 instead of 6 column tiles at K = 1280: -0.7 % per step on large-v3 and small.en in same-process A/Bs, tools/ab_keys.py; 3 and 5-6 lose)
 extern "C" int dw_debug_set(int key, int value) {
     if (key == 0) { g_gemm_variant = value; return DW_OK; }
     if (key == 1) { g_gemm_strip = value; return DW_OK; }

@@ -10,15 +10,16 @@ from distil_whisper_amd.distill import DistillationTrainer
 from distil_whisper_amd import student_init as si
 dev = "cuda:0"
 ops = HipOps(dev)
-tdims = si.PRESETS["large-v3"]
+MODEL = os.environ.get("MODEL", "large-v3")            # large-v3 | small.en | tiny.en
+tdims = si.PRESETS[MODEL]
 t_sd = si.random_state_dict(tdims, 0, dev)
-s_sd, sdims = si.student_from_teacher(t_sd, tdims, 32, 2)
-filt = torch.tensor(si.mel_filter_bank(128), dtype=torch.float32, device=dev).contiguous()
+s_sd, sdims = si.student_from_teacher(t_sd, tdims, *si.STUDENT_LAYERS[MODEL])
+filt = torch.tensor(si.mel_filter_bank(tdims.n_mels), dtype=torch.float32, device=dev).contiguous()
 tr = DistillationTrainer(ops, s_sd, sdims, t_sd, tdims, mel_filters=filt)
 del t_sd, s_sd
 B, T = 32, 447
 audio = 0.1 * torch.randn(B, 480000, device=dev)
-ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = 50258
+ids = torch.randint(0, 50257, (B, T + 1), device=dev); ids[:, 0] = tdims.decoder_start_token_id
 dec_in = ids[:, :-1].contiguous(); labels = ids[:, 1:].clone()
 lens = torch.randint(32, 225, (B,), generator=torch.Generator().manual_seed(1234)).tolist()
 labels[torch.arange(T, device=dev)[None, :] >= torch.tensor(lens, device=dev)[:, None]] = -100
@@ -33,7 +34,7 @@ base = os.path.join(os.path.dirname(_oh.LIB_PATH), "libdwamd_base.so")
 for i, path in [(1, base)] + [(j, base.replace("_base.so", f"_base{j}.so")) for j in (2, 3, 4, 5)]:
     if os.path.exists(path): libs[i] = _oh.load_library(path)
 allkeys = sorted({k for c in configs for k in c if k != "lib"})
-DEF = {0: 2163, 1: 0, 3: 5, 6: 8, 9: 256, 10: 1, 11: 1, 12: 0, 20: 36, 22: 1, 23: 8, 24: 0, 25: 1, 26: 0, 27: 0, 28: 0}
+DEF = {0: 2163, 1: 0, 3: 5, 6: 4, 9: 256, 10: 1, 11: 1, 12: 0, 20: 36, 22: 1, 23: 8, 24: 0, 25: 1, 26: 0, 27: 0, 28: 0}
 step(); torch.cuda.synchronize()
 res = [[] for _ in configs]
 NS = int(os.environ.get("DW_NS", "3"))
