@@ -36,5 +36,10 @@ MODEL=small.en timeout 300 python tools/step_breakdown.py > $O/small_en_step_bre
 timeout 600 python bench.py --mode recipe --no-cpu-baseline > $O/bench_recipe.json 2> $O/bench_recipe.err
 timeout 300 python bench.py --model tiny.en --batch 2 --no-cpu-baseline --no-reference-loop > $O/bench_tiny_en_b2.json 2> $O/bench_tiny.err
 timeout 300 python tools/bench_longform.py > $O/longform_bench.json 2> $O/longform.err
-timeout 300 python tools/gemm_t128_w4_probe.py > $O/gemm_t128_w4_probe.txt 2>&1
+timeout 300 python tools/gemm_m128_probe.py > $O/gemm_small_m_probe.txt 2>&1
+timeout 300 python tools/bench_pseudo_label.py > $O/pseudo_label_bench.json 2> $O/pseudo_label.err
+DW_LENS=1 timeout 300 python tools/step_breakdown.py > $O/step_breakdown.md 2> $O/step_breakdown.err
+timeout 300 bash tools/decode_profile_step.sh > $O/decode_step_sequence.txt 2>&1
+timeout 200 python tools/attn_pipe_ab.py > $O/attn_pipe_ab.txt 2>&1
+DW_STREAMS=1 DW_ROUNDS=4 DW_AB="[{}, {25: 0}, {6: 8}, {25: 0, 6: 8}]" timeout 400 python tools/ab_keys.py > $O/ab_round6_kernel_changes.txt 2>&1
 tail -c 400 $O/bench_full.json; echo; tail -2 $O/pmc_traffic.log; head -4 $O/gemm_pmc_table.md | cut -c1-250
