@@ -6,7 +6,29 @@
 #include "../../include/dwamd.h"
 
 #define LN_MAXV 8  // up to 8 float4 per lane -> cols <= 2048
+#ifndef DW_NT_LN_IN
+#define DW_NT_LN_IN 1      // 1 (default): the forward kernels' row loads are non-temporal; 2: + the backward kernels' x and dy loads; 0: off.
+                           // Same-process A/B of variant builds on the full step (tools/ab_keys.py `lib`): 344.8 -> 343.9 and 343.1 -> 342.5 ms with 1
+                           // (the rows are read once here; kept out of the caches they leave more room for the GEMM operands); 2 and the same
+                           // hint in AdamW (-DDW_NT_ADAMW) add nothing measurable.
+#endif
 
+template <bool XBF>
+__device__ __forceinline__ f32x4 ld4b(const void* x, long off) {       // backward kernels: x and dy are read once
+    if constexpr (DW_NT_LN_IN >= 2) {
+        if (XBF) {
+            const bf16x4 t = __builtin_nontemporal_load((const bf16x4*)((const bf16*)x + off));
+            f32x4 r; r[0] = bf2f(t[0]); r[1] = bf2f(t[1]); r[2] = bf2f(t[2]); r[3] = bf2f(t[3]);
+            return r;
+        } else return __builtin_nontemporal_load((const f32x4*)((const float*)x + off));
+    } else {
+        if (XBF) {
+            const bf16x4 t = *(const bf16x4*)((const bf16*)x + off);
+            f32x4 r; r[0] = bf2f(t[0]); r[1] = bf2f(t[1]); r[2] = bf2f(t[2]); r[3] = bf2f(t[3]);
+            return r;
+        } else return *(const f32x4*)((const float*)x + off);
+    }
+}
 template <bool XBF>
 __device__ __forceinline__ f32x4 ld4(const void* x, long off) {
     if (XBF) {
@@ -22,6 +44,13 @@ __device__ __forceinline__ f32x4 ld4(const void* x, long off) {
 #ifndef DW_NT_LN
 #define DW_NT_LN 0
 #endif
+// Input loads of the forward kernels.  -DDW_NT_LN_IN=1 marks the row loads non-temporal (the fp32 residual stream / the teacher's bf16
+// stream is read ONCE by this kernel; the student's is read again only in the backward, hundreds of MB of other traffic later).
+template <class T>
+__device__ __forceinline__ T ln_load_in(const T* src) {
+    if constexpr (DW_NT_LN_IN != 0) return __builtin_nontemporal_load(src);
+    else return *src;
+}
 template <int LEVEL, class T>
 __device__ __forceinline__ void ln_store(T* dst, const T& v) {
     if constexpr (LEVEL <= DW_NT_LN) __builtin_nontemporal_store(v, dst);
@@ -88,7 +117,7 @@ __global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, con
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = lane + 64 * j;
-        if (idx < nvec) v[j] = *(const f32x4*)(x + (long)row * ldx + idx * 4);
+        if (idx < nvec) v[j] = ln_load_in((const f32x4*)(x + (long)row * ldx + idx * 4));
     }
     for (; row < rows; row += stride) {
         const int nrow = row + stride;
@@ -96,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_fwd_persist_kernel(const float* x, con
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int idx = lane + 64 * j;
-                if (idx < nvec) nx[j] = *(const f32x4*)(x + (long)nrow * ldx + idx * 4);
+                if (idx < nvec) nx[j] = ln_load_in((const f32x4*)(x + (long)nrow * ldx + idx * 4));
             }
         }
         float s = 0.f;
@@ -148,7 +177,7 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16* x, const
     for (int j = 0; j < NV8; ++j) {
         const int idx = lane + 64 * j;
         if (idx < nvec) {
-            const bf16x8 t = *(const bf16x8*)(x + (long)row * ldx + idx * 8);
+            const bf16x8 t = ln_load_in((const bf16x8*)(x + (long)row * ldx + idx * 8));
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[j][e] = bf2f(t[e]); s += v[j][e]; }
         }
@@ -210,8 +239,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16* dy, const v
         for (int j = 0; j < NV; ++j) {
             const int idx = lane + 64 * j;
             if (idx < nvec) {
-                const f32x4 xv = ld4<XBF>(x, (long)row * ldx + idx * 4);
-                const f32x4 dv = ld4<true>(dy, (long)row * lddy + idx * 4);
+                const f32x4 xv = ld4b<XBF>(x, (long)row * ldx + idx * 4);
+                const f32x4 dv = ld4b<true>(dy, (long)row * lddy + idx * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     xh[j][e] = (xv[e] - mu) * rs;
@@ -312,7 +341,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int idx = lane + 64 * j;
-            if (idx < nvec) { xv[j] = ld4<XBF>(x, (long)row * ldx + idx * 4); dv[j] = ld4<true>(dy, (long)row * lddy + idx * 4); }
+            if (idx < nvec) { xv[j] = ld4b<XBF>(x, (long)row * ldx + idx * 4); dv[j] = ld4b<true>(dy, (long)row * lddy + idx * 4); }
         }
     }
     for (; row < rows; row += stride) {
@@ -332,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_pf_kernel(const bf16* dy, cons
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int idx = lane + 64 * j;
-                if (idx < nvec) { nxv[j] = ld4<XBF>(x, (long)nrow * ldx + idx * 4); ndv[j] = ld4<true>(dy, (long)nrow * lddy + idx * 4); }
+                if (idx < nvec) { nxv[j] = ld4b<XBF>(x, (long)nrow * ldx + idx * 4); ndv[j] = ld4b<true>(dy, (long)nrow * lddy + idx * 4); }
             }
         }
         f32x4 xh[NV], g[NV];
