@@ -181,7 +181,11 @@ __global__ __launch_bounds__(256) void reduce_slices_ld_kernel(const float* part
     f32x4 acc = accumulate ? *(const f32x4*)o : f32x4{0.f, 0.f, 0.f, 0.f};
     const float* src = part + (long)r * ld_part + c;
     for (int s = 0; s < slices; ++s) {
+#ifdef DW_NT_REDUCE      // (experiment: the slabs are read once)
+        const f32x4 v = __builtin_nontemporal_load((const f32x4*)(src + s * slice_stride));
+#else
         const f32x4 v = *(const f32x4*)(src + s * slice_stride);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += v[e];
     }

@@ -482,7 +482,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, Acc& acc, char* sm
                 constexpr int slot = gi % PFD;
                 constexpr long rg = (gi / NIT) * 32 + (gi % NIT) * RPI;              // first row of the row group in the wave tile
 #ifndef DW_EPI_NT_SIDE
-#define DW_EPI_NT_SIDE 0       // (1: gelu'(z), 2: the residual, 3: both side inputs are read with the non-temporal hint -- experiments)
+#define DW_EPI_NT_SIDE 1       // 1 (default since round 6): gelu'(z) -- 491 MB per dX-of-fc2 launch, read once -- is loaded with the non-temporal hint:
+                               // 338.7 -> 337.2 ms per step against a variant build in one process (tools/ab_keys.py `lib`); 2: the residual, 3: both (3 = 1 within noise)
 #endif
                 if (want_z) {
                     if constexpr ((DW_EPI_NT_SIDE & 1) != 0) zq[slot] = __builtin_nontemporal_load((const bf16x4*)(zg_u + rg * p.ldzg * 2 + l_zg));
