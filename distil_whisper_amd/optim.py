@@ -58,6 +58,8 @@ def _unwrap(model):
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    merge_segments = True      # False: one norm / update launch per (group, contiguous run of its tensors) -- the A/B of tools/ref_loop_profile.py
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, *, model, max_grad_norm=None):
         """`params`: parameters or parameter-group dicts of ONE `distil_whisper_amd.WhisperForConditionalGeneration`
         (`model`, possibly DDP-wrapped), as `torch.optim.AdamW` takes them.  `max_grad_norm`: clip inside `step()` without a
@@ -89,6 +91,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._sumsq = self.ops.zeros((1,), torch.float32)
         self._segments = None
         self._seg_key = None
+        self._norm_segments, self._step_plan, self._step_key = None, None, None
         self._gathered = False
         self._max_norm = float(max_grad_norm) if max_grad_norm else 0.0
         self._clip_once = None
@@ -120,6 +123,36 @@ class FusedAdamW(torch.optim.Optimizer):
                     segs.append([a, b])
             plan.append(segs)
         self._segments, self._seg_key = plan, key
+        # The gradient norm is ONE quantity over every parameter that has a gradient: the union of the groups' segments, merged
+        # (the reference's two groups -- decay / no decay -- interleave tensor by tensor: 321 segments at distil-large-v3, whose
+        # union is the single trainable range; summed per segment that was 321 x two launches per step, 3 ms of launch floors).
+        self._norm_segments = self._merged([s for segs in plan for s in segs]) if self.merge_segments else [s for segs in plan for s in segs]
+        self._step_plan, self._step_key = None, None
+
+    @staticmethod
+    def _merged(segs):
+        out = []
+        for a, b in sorted((a, b) for a, b in segs):
+            if out and out[-1][1] >= a:
+                out[-1][1] = max(out[-1][1], b)
+            else:
+                out.append([a, b])
+        return out
+
+    def _classes(self):
+        """Groups whose update is the same function of (p, g, m, v) -- equal lr, betas, eps, weight decay and step count -- are
+        stepped together over their MERGED segments (the reference's default weight_decay = 0 makes its two groups one class:
+        one launch over the trainable range instead of one per tensor).  Each group keeps its own device-resident state."""
+        key = tuple((g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"], g.get("_steps", 0)) for g in self.param_groups)
+        if self._step_plan is not None and key == self._step_key:
+            return self._step_plan
+        by = {}
+        for gi, k in enumerate(key):
+            if self._segments[gi]:
+                by.setdefault(k if self.merge_segments else (gi,), []).append(gi)
+        plan = [(gis, self._merged([s for gi in gis for s in self._segments[gi]])) for gis in by.values()]
+        self._step_plan, self._step_key = plan, key
+        return plan
 
     def _gather(self):
         """p.grad (separate tensors: autograd clones, DDP bucket views, accumulated micro-batches) -> the flat buffer the
@@ -132,14 +165,18 @@ class FusedAdamW(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is not None:
                     a, _, name = self._ranges[id(p)]
-                    dst.append(self.st.G[a:a + p.numel()].view(p.shape))
+                    d = self.st.G[a:a + p.numel()].view(p.shape)
+                    # (the drop-in's backward hands out views of the flat buffer as gradients: already in place -- a self-copy of
+                    # 3 GB would cost a read and a write of every gradient, 1.3 ms per step at distil-large-v3)
+                    if p.grad.data_ptr() == d.data_ptr() and p.grad.dtype == d.dtype and p.grad.is_contiguous():
+                        continue
+                    dst.append(d)
                     src.append(p.grad)
         if dst:
             torch._foreach_copy_(dst, src)
         self._sumsq.zero_()
-        for segs in self._segments:
-            for a, b in segs:
-                self.ops.sumsq(self.st.G[a:b], self._sumsq)
+        for a, b in self._norm_segments:
+            self.ops.sumsq(self.st.G[a:b], self._sumsq)
         self.last_grad_norm = torch.sqrt(self._sumsq[0])
         self._gathered = True
 
@@ -164,6 +201,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._gather()
         max_norm = self._clip_once if self._clip_once is not None else self._max_norm
         st, ops = self.st, self.ops
+        plan = self._classes()                               # (before the step counts move: they are part of the class key)
         for group, segs in zip(self.param_groups, self._segments):
             if not segs:
                 continue
@@ -171,6 +209,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 group["_adam"][0:1].fill_(group["lr"])
                 group["_lr_dev"] = group["lr"]
             ops.adam_tick(group["_adam"], None)
+            group["_steps"] = group.get("_steps", 0) + 1
+        for gis, segs in plan:
+            group = self.param_groups[gis[0]]                # (every group of the class holds the same scalars)
             for a, b in segs:
                 ops.adamw_dev(st.P[a:b], st.G[a:b], st.M[a:b], st.V[a:b], st.S[a:b], self._sumsq, max_norm, 1.0, group["_adam"],
                               group["eps"], group["weight_decay"])
@@ -186,7 +227,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().zero_grad(set_to_none=set_to_none)
 
     # -- checkpointing (accelerator.save_state / load_state) -------------------------------------------------------------
-    _PRIVATE_KEYS = ("params", "_adam", "_lr_dev")
+    _PRIVATE_KEYS = ("params", "_adam", "_lr_dev", "_steps")
 
     def state_dict(self):
         """Flat form: the moments of the whole trainable range in two tensors + the parameter groups (every public key,
@@ -212,6 +253,8 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = g["betas"]
             g["_adam"] = self.ops.adam_state(g["lr"], b1, b2, step)
             g["_lr_dev"] = g["lr"]
+            g["_steps"] = int(step)
+        self._step_plan, self._step_key = None, None
 
     def load_state_dict(self, state_dict):
         """Accepts this class's flat form and the torch.optim.AdamW layout (`state` keyed by parameter index with
