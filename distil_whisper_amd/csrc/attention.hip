@@ -20,6 +20,9 @@
 #ifndef DW_ATTN_DEFER
 #define DW_ATTN_DEFER 8
 #endif
+#ifndef DW_ATTN_IDLE_SKIP
+#define DW_ATTN_IDLE_SKIP 1   // a wave whose 32 stationary rows lie wholly behind the end of the sequence skips its tiles' arithmetic
+#endif
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct AttnP {
@@ -180,6 +183,8 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
         }
         const char* tK = smem + buf * 16384;
         const char* tV = tK + 8192;
+        if (DW_ATTN_IDLE_SKIP && qb0 + wave * 32 >= p.Lq) continue;   // none of this wave's 32 queries exists (the last wave of the
+                                                                      // 1500-query tail workgroup): it stages and meets the barriers only
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -645,6 +650,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_bwd_dq_kernel(const AttnP p) 
         const int wq0 = qb0 + wave * 32;
         const bool need_mask = MODE == 1 || (MODE == 2 && (((kt + 1) * 64 > p.Lk) || (CAUSAL && kt * 64 + 63 > wq0)));
         if (CAUSAL && kt * 64 > wq0 + 31) continue;
+        if (DW_ATTN_IDLE_SKIP && wq0 >= p.Lq) continue;               // (see attn_fwd_kernel)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
@@ -780,6 +786,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dkv_kernel(const AttnP 
         // mask needed on the query tail, on a partially valid key block, or on the causal diagonal
         const bool need_mask = MODE == 1 || (MODE == 2 && (((qt + 1) * 64 > p.Lq) || (wk0 + 31 >= p.Lk) || (CAUSAL && wk0 + 31 > qt * 64)));
         if (CAUSAL && wk0 > qt * 64 + 63) continue;  // all 64 queries of this tile precede every key of this wave
+        if (DW_ATTN_IDLE_SKIP && wk0 >= p.Lk) continue;               // none of this wave's 32 keys exists
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             // accumulators start from -lse/scale and -delta of their query rows (register r <-> query
