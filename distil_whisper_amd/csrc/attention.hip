@@ -33,6 +33,9 @@ struct AttnP {
     long q_rows, kv_rows;  // rows between consecutive batches in memory (= Lq / Lk unless reading a padded KV cache)
     float* dq_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dq (q_proj.bias gradient), or null
     float* dv_colsum;      // f32 [B][H*64] += per-batch column sums of the stored dv (v_proj.bias gradient), or null
+    const int* q_start; const int* q_len;     // ragged batches (attn_fwd_kernel VL): packed-row offset and length of every sequence
+    const int* kv_start; const int* kv_len;   // ... of its keys / values (null: rectangular K / V, batch min(b, kv_B - 1))
+    int kv_B;
     int plain_order;       // 1 = workgroups take (tile, head, batch) in launch order (A/B switch of attn_workgroup)
     float defer;           // deferred-maximum threshold of the forward softmax in log2 units (g_attn_defer; 0 = the exact rule)
     int coff;              // causal mask: key <= query + coff (0 = top-left aligned, Lk - Lq = bottom-right aligned)
@@ -138,7 +141,7 @@ __device__ __forceinline__ void attn_workgroup(int ntile, int H, bool plain, int
 // ABL (builds with -DDW_ABLATE only, tools/attn_ablate.py): timing experiments that leave out one resource user each and
 // compute garbage -- 1 no exp, 2 / 4 K / V fragments from registers instead of LDS, 8 no operand staging inside the loop,
 // 16 no barrier, 32 / 64 without the QK / PV MFMAs.
-template <bool CAUSAL, int NW = 4, int ABL = 0>
+template <bool CAUSAL, int NW = 4, int ABL = 0, bool VL = false>
 __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const AttnP p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * 16384];  // [buf][K tile 8K | V tile 8K]
     const int lane = threadIdx.x & 63;
@@ -147,20 +150,33 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
     int tile, h, b;
     attn_workgroup((p.Lq + 32 * NW - 1) / (32 * NW), p.H, p.plain_order, tile, h, b);
     const int qb0 = tile * (32 * NW);
+    // VL (ragged batches, forward-only passes over packed rows): sequence b owns query rows [q_start[b], q_start[b] + q_len[b]) of
+    // the packed buffers, and -- self-attention -- the same rows as keys / values (kv_start == q_start); cross-attention keeps the
+    // rectangular K / V of batch min(b, kv_B - 1) (entries behind kv_B: filler rows of a quantised row count, any finite result).
+    // p.Lq is the longest sequence (the grid's tile count); workgroups behind their sequence's last query leave at once.
+    long q_row0 = (long)b * p.q_rows, kv_row0 = (long)b * p.kv_rows;
+    int Lq = p.Lq, Lk = p.Lk;
+    if constexpr (VL) {
+        q_row0 = p.q_start[b];
+        Lq = p.q_len[b];
+        if (p.kv_start) { kv_row0 = p.kv_start[b]; Lk = p.kv_len[b]; }
+        else kv_row0 = (long)min(b, p.kv_B - 1) * p.kv_rows;
+        if (qb0 >= Lq) return;
+    }
     const int q = qb0 + wave * 32 + ln;          // this lane's query (column of S^T)
-    const bool q_ok = q < p.Lq;
-    const int qc = q_ok ? q : p.Lq - 1;
-    const bf16* Q = p.q + (long)b * p.q_rows * p.ldq + h * 64;
-    const bf16* K = p.k + (long)b * p.kv_rows * p.ldk + h * 64;
-    const bf16* V = p.v + (long)b * p.kv_rows * p.ldv + h * 64;
+    const bool q_ok = q < Lq;
+    const int qc = q_ok ? q : Lq - 1;
+    const bf16* Q = p.q + q_row0 * p.ldq + h * 64;
+    const bf16* K = p.k + kv_row0 * p.ldk + h * 64;
+    const bf16* V = p.v + kv_row0 * p.ldv + h * 64;
 
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = ldg8(Q, qc, p.ldq, kk * 16 + hi * 8);
 
-    int nkt = (p.Lk + 63) >> 6;
+    int nkt = (Lk + 63) >> 6;
     if (CAUSAL) {
-        const int lim = ((min(qb0 + 32 * NW - 1, p.Lq - 1) + p.coff) >> 6) + 1;
+        const int lim = ((min(qb0 + 32 * NW - 1, Lq - 1) + p.coff) >> 6) + 1;
         nkt = min(nkt, lim);
     }
     const float c = p.scale * 1.4426950408889634f;
@@ -169,8 +185,8 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
 
-    stage_tile64<NW>(K, p.ldk, 0, p.Lk, smem, wave, lane);
-    stage_tile64<NW>(V, p.ldv, 0, p.Lk, smem + 8192, wave, lane);
+    stage_tile64<NW>(K, p.ldk, 0, Lk, smem, wave, lane);
+    stage_tile64<NW>(V, p.ldv, 0, Lk, smem + 8192, wave, lane);
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (!(ABL & 16) || kt == 0) {
@@ -178,12 +194,12 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
             __syncthreads();
         }
         if (kt + 1 < nkt && !(ABL & 8)) {
-            stage_tile64<NW>(K, p.ldk, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384, wave, lane);
-            stage_tile64<NW>(V, p.ldv, (kt + 1) * 64, p.Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
+            stage_tile64<NW>(K, p.ldk, (kt + 1) * 64, Lk, smem + (buf ^ 1) * 16384, wave, lane);
+            stage_tile64<NW>(V, p.ldv, (kt + 1) * 64, Lk, smem + (buf ^ 1) * 16384 + 8192, wave, lane);
         }
         const char* tK = smem + buf * 16384;
         const char* tV = tK + 8192;
-        if (DW_ATTN_IDLE_SKIP && qb0 + wave * 32 >= p.Lq) continue;   // none of this wave's 32 queries exists (the last wave of the
+        if (DW_ATTN_IDLE_SKIP && qb0 + wave * 32 >= Lq) continue;   // none of this wave's 32 queries exists (the last wave of the
                                                                       // 1500-query tail workgroup): it stages and meets the barriers only
         f32x16 s[2];
 #pragma unroll
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
         }
         // mask (key tail / causal diagonal) only on the tiles that need it -- a wave-uniform test
         const int wq0 = qb0 + wave * 32 + (CAUSAL ? p.coff : 0);   // last key the wave's first query may see
-        const bool need_mask = ((kt + 1) * 64 > p.Lk) || (CAUSAL && kt * 64 + 63 > wq0);
+        const bool need_mask = ((kt + 1) * 64 > Lk) || (CAUSAL && kt * 64 + 63 > wq0);
         if (CAUSAL && kt * 64 > wq0 + 31) continue;  // every key of this tile is in the future of all 32 queries
         float mx = NEG_BIG;
         if (need_mask) {
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool ok = key < p.Lk && (!CAUSAL || key <= q + p.coff);
+                    const bool ok = key < Lk && (!CAUSAL || key <= q + p.coff);
                     s[kb][r] = ok ? s[kb][r] : NEG_BIG;
                 }
         }
@@ -267,15 +283,15 @@ __global__ __launch_bounds__(64 * NW, CAUSAL ? 2 : 4) void attn_fwd_kernel(const
             }
     }
     const float inv = 1.0f / l_run;
-    bf16* O = p.o + (long)b * p.q_rows * p.ldo + h * 64;
+    bf16* O = p.o + q_row0 * p.ldo + h * 64;
     if (DW_ATTN_ROWSTORE && NW <= 7 && (p.ldo & 7) == 0 && ((uintptr_t)p.o & 15) == 0) {
         __syncthreads();                              // every wave is done with the last K/V tile: the patches overlay the tiles
-        store_rows(O, p.ldo, qb0 + wave * 32, p.Lq, smem + wave * 4608, lane, o[0], o[1], inv);
+        store_rows(O, p.ldo, qb0 + wave * 32, Lq, smem + wave * 4608, lane, o[0], o[1], inv);
     } else {
         store_t(O, p.ldo, q, q_ok, 0, hi, o[0], inv);
         store_t(O, p.ldo, q, q_ok, 1, hi, o[1], inv);
     }
-    if (p.lse && q_ok && hi == 0) p.lse[((long)b * p.H + h) * p.Lq + q] = m_run * p.scale + __logf(l_run);
+    if (!VL && p.lse && q_ok && hi == 0) p.lse[((long)b * p.H + h) * Lq + q] = m_run * p.scale + __logf(l_run);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -948,6 +964,40 @@ extern "C" int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     else if (g_attn_fwd_waves == 8 && g8 * 2 == g4 && (long)g8 * H * B >= 512)
         hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), dim3(g8 * H * B), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, 0, s, p);
+    DW_CHECK_LAUNCH();
+    return DW_OK;
+}
+
+// Forward over RAGGED batches (packed rows; forward-only passes: no lse).  n_seq sequences; sequence i has q_len[i] <= max_q queries
+// at packed rows q_start[i]...; self-attention (kv_start = q_start, kv_len = q_len: keys / values are rows of the same packed
+// buffers, causal or not) or cross-attention (kv_start = kv_len = null: K / V are [kv_batches][kv_batch_rows] rectangles of Lk
+// valid rows, sequence i reads batch min(i, kv_batches - 1)).  Replaces the scatter -> rectangular attention -> gather the packed
+// teacher decoder went through (SURVEY 8 a4 / a5 on the live rows of a batch: TF:modeling_whisper.py:284-356).
+extern "C" int dw_attn_fwd_varlen(const void* q, const void* k, const void* v, void* o, int n_seq, int H, int max_q, int Lk,
+                                  int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* q_start, const int32_t* q_len,
+                                  const int32_t* kv_start, const int32_t* kv_len, int kv_batches, int64_t kv_batch_rows, int causal,
+                                  float scale, void* stream) {
+    DW_CLEAR_ERR();
+    if (!q || !k || !v || !o || !q_start || !q_len || n_seq <= 0 || H <= 0 || max_q <= 0) return DW_EINVAL;
+    if ((kv_start == nullptr) != (kv_len == nullptr)) return DW_EINVAL;
+    if (!kv_start && (Lk <= 0 || kv_batches <= 0 || kv_batch_rows < Lk || causal)) return DW_EINVAL;
+    if (causal != 0 && causal != 1) return DW_EINVAL;
+    if (check_ld(ldq) || check_ld(ldk) || check_ld(ldv) || (ldo & 7)) return DW_EINVAL;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 15)) return DW_EINVAL;
+    const int64_t lk_max = kv_start ? max_q : Lk;
+    if (lk_max * ldk >= (1LL << 31) || lk_max * ldv >= (1LL << 31)) return DW_EINVAL;  // 32-bit tile offsets
+    AttnP p = {};
+    p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = nullptr;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.B = n_seq; p.H = H; p.Lq = max_q; p.Lk = kv_start ? max_q : Lk; p.scale = scale;
+    p.q_rows = 0; p.kv_rows = kv_batch_rows; p.coff = 0;
+    p.q_start = q_start; p.q_len = q_len; p.kv_start = kv_start; p.kv_len = kv_len; p.kv_B = kv_batches;
+    p.plain_order = g_attn_plain_order;
+    p.defer = (float)g_attn_defer;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(((max_q + 127) / 128) * H * n_seq), block(256);
+    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, 4, 0, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, 4, 0, true>), grid, block, 0, s, p);
     DW_CHECK_LAUNCH();
     return DW_OK;
 }

@@ -232,6 +232,8 @@ def trim_dead_positions(decoder_input_ids, labels, valid_len):
 
 
 class DistillationTrainer:
+    overwrite_wgrad = True    # the split-K combine of the layers' weight gradients stores into the cleared buffer instead of adding to it
+
     def __init__(self, ops, student_sd, student_dims, teacher_sd, teacher_dims, *, temperature=2.0, kl_weight=1.0,
                  lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, freeze_encoder=False,
                  share_encoder=False, freeze_embed_positions=False, process_group=None, mel_filters=None,
@@ -349,12 +351,16 @@ class DistillationTrainer:
             S.zero_small_grads()
         st = self.student_store
         dp = self.reducer is not None and self.reducer.active and sync_grads
-        denc = S.backward_decoder(dctx, logits_s, want_denc=not self.freeze_encoder)
-        del logits_s, dctx
-        if dp:
-            self.reducer.ready(st.train_start if self.freeze_encoder else st.dec_start, st.train_end)
-        if not self.freeze_encoder:
-            S.backward_encoder(ectx, denc, on_ready=self.reducer.ready if dp else None)
+        S.wgrad_overwrite = bool(zero_grad) and self.overwrite_wgrad   # (the buffer was just cleared: the layers' weight gradients are stored, not added)
+        try:
+            denc = S.backward_decoder(dctx, logits_s, want_denc=not self.freeze_encoder)
+            del logits_s, dctx
+            if dp:
+                self.reducer.ready(st.train_start if self.freeze_encoder else st.dec_start, st.train_end)
+            if not self.freeze_encoder:
+                S.backward_encoder(ectx, denc, on_ready=self.reducer.ready if dp else None)
+        finally:
+            S.wgrad_overwrite = False
         S.join_wgrad_stream()
         return losses
 
@@ -484,7 +490,10 @@ class DistillationTrainer:
             ins = self._graph_inputs = {"key": in_key, "stream": torch.cuda.Stream(device=dev), "pool": None,
                                         "x": torch.empty_like(inputs), "ids": torch.empty_like(decoder_input_ids),
                                         "labels": torch.empty_like(labels),
-                                        "live_idx": torch.zeros(B * T, dtype=torch.int32, device=dev)}
+                                        "live_idx": torch.zeros(B * T, dtype=torch.int32, device=dev),
+                                        # ragged-batch table of the packed rows (LiveRows.seq_table): B sequences + filler entries
+                                        "seq_start": torch.zeros(B + max(1, qr) + 1, dtype=torch.int32, device=dev),
+                                        "seq_len": torch.zeros(B + max(1, qr) + 1, dtype=torch.int32, device=dev)}
         g = self._graph
         if g is None or g["key"] != key:
             g = self._graphs.get(key)
@@ -500,7 +509,11 @@ class DistillationTrainer:
         live = None
         if lens is not None:             # the row list of this batch goes into the plan's static index buffer
             ins["live_idx"][:Rc].copy_(LiveRows.host_index(lens, Te, fill_to=Rc))
-            live = LiveRows(ins["live_idx"][:Rc], Rc, B, Te)
+            E = B + -(-max(1, qr) // Te)           # table entries of this plan (fixed: the launch's sequence count is captured)
+            st, ln = LiveRows.seq_table(lens, Te, fill_to=Rc, entries=E)
+            ins["seq_start"][:E].copy_(st)
+            ins["seq_len"][:E].copy_(ln)
+            live = LiveRows(ins["live_idx"][:Rc], Rc, B, Te, ins["seq_start"][:E], ins["seq_len"][:E], Te)
 
         def body():
             feats = self.features(ins["x"]) if ins["x"].dim() == 2 else ins["x"]

@@ -218,8 +218,29 @@ class LiveRows:
     LayerNorm, MLP, LM head, loss) runs over the n packed rows; attention gets the (batch, position) layout back through
     one scatter / gather pair (ops.scatter_rows / gather_rows)."""
 
-    def __init__(self, idx, n, B, T):
+    def __init__(self, idx, n, B, T, seq_start=None, seq_len=None, max_q=0, attn_flops=(0.0, 0.0)):
         self.idx, self.n, self.B, self.T = idx, int(n), int(B), int(T)
+        # ragged-batch table of the packed rows (int32 on the device, LiveRows.seq_table): with it attention reads the packed rows
+        # in place (ops.attn_fwd_varlen) instead of going through the (batch, position) rectangle
+        self.seq_start, self.seq_len, self.max_q = seq_start, seq_len, int(max_q)
+        self.attn_flops = attn_flops          # (sum of len^2, sum of len) over the sequences: flop counts of the per-launch profile
+
+    @staticmethod
+    def seq_table(lens, T, fill_to=None, entries=None):
+        """(starts, lengths) of the packed rows host_index(lens, T, fill_to) lists: one entry per sequence, then the filler rows cut
+        into pseudo-sequences of at most T rows (their attention results are never used, they only have to be finite), then
+        zero-length entries up to `entries` (a captured plan's table has a fixed size: B + ceil(row quantum / T))."""
+        lens = [max(1, min(int(T), int(x))) for x in lens]
+        n_live = sum(lens)
+        fill = max(0, int(fill_to) - n_live) if fill_to is not None else 0
+        lens = lens + [min(T, fill - o) for o in range(0, fill, T)]
+        if entries is not None:
+            if len(lens) > entries:
+                raise ValueError("LiveRows.seq_table: more filler sequences than the table holds")
+            lens = lens + [0] * (entries - len(lens))
+        ln = torch.tensor(lens, dtype=torch.int32)
+        st = torch.cumsum(ln, 0, dtype=torch.int32) - ln
+        return st, ln
 
     @staticmethod
     def host_index(lens, T, fill_to=None):
@@ -239,7 +260,10 @@ class LiveRows:
     @classmethod
     def build(cls, lens, T, device):
         h = cls.host_index(lens, T)
-        return cls(h.to(device), h.numel(), len(lens), T)
+        st, ln = cls.seq_table(lens, T)
+        lf = ln.double()
+        return cls(h.to(device), h.numel(), len(lens), T, st.to(device), ln.to(device), int(ln.max()),
+                   attn_flops=(float((lf * lf).sum()), float(lf.sum())))
 
 
 class WhisperEngine:
@@ -366,6 +390,9 @@ class WhisperEngine:
         else:
             self._wgrad_issue(dy, x, gout, gbias, R, bias_cols)
 
+    varlen_attention = True   # packed (live-row) forward passes: attention over ragged batches in place (False: scatter -> rectangle -> gather)
+    wgrad_overwrite = False   # set by the trainer around a backward that follows zero_small_grads(): every weight matrix handed to
+                              # _wgrad gets exactly one contribution per backward, so the split-K combine may store instead of add
     wgrad_lag = 2     # layers of weight-gradient work the side stream may be behind before the main stream waits for it
 
     def _wgrad_fence(self):
@@ -385,7 +412,8 @@ class WhisperEngine:
 
     def _wgrad_issue(self, dy, x, gout, gbias, R, bias_cols):
         if gout is not None:  # the gradient buffer was zeroed (or holds earlier micro-batches): always accumulate
-            self.ops.gemm(dy, x, trans_a=True, trans_b=True, out_dtype=torch.float32, out=gout, atomic_acc=True)
+            self.ops.gemm(dy, x, trans_a=True, trans_b=True, out_dtype=torch.float32, out=gout, atomic_acc=True,
+                          overwrite=self.wgrad_overwrite)
         if gbias is not None:
             if bias_cols is None:
                 self.ops.colsum(dy[:R], gbias, accumulate=True)
@@ -456,6 +484,17 @@ class WhisperEngine:
             if live is None:
                 _, lse = ops.attn_fwd(q_src[:R, :D], k, v, B, H, L, Lkv, is_causal, 0.125, out=o[:R])
                 return o, lse
+            if live.seq_start is not None and self.varlen_attention:
+                # ragged batches: the kernel walks the packed rows of every sequence in place (same arithmetic per query row as over
+                # the rectangle: bit-identical live rows; no scatter / gather launches, no dead query rows)
+                if k is None:
+                    ops.attn_fwd_varlen(q_src[:R, :D], q_src[:R, D:2 * D], q_src[:R, 2 * D:], H, live.max_q, live.seq_start,
+                                        live.seq_len, is_causal, 0.125, o[:R], self_attention=True,
+                                        flops=256.0 * H * live.attn_flops[0])
+                else:
+                    ops.attn_fwd_varlen(q_src[:R, :D], k, v, H, live.max_q, live.seq_start, live.seq_len, is_causal, 0.125, o[:R],
+                                        Lk=Lkv, kv_batches=B, self_attention=False, flops=256.0 * H * Lkv * live.attn_flops[1])
+                return o, None
             # Dead rows must hold FINITE values: a live query's masked keys (later positions inside its 64-key tile) enter
             # the P.V product with probability exactly 0, and 0 x NaN from stale memory would poison the live row.  The
             # scatter target is a buffer of this engine that starts zeroed and only ever receives projected rows.

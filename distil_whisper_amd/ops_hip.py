@@ -65,6 +65,8 @@ _SIGS = {
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_int64] * 4 + [C.c_void_p], C.c_int),
     "dw_attn_fwd": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_fwd_ex": ([C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_int64] * 6 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
+    "dw_attn_fwd_varlen": ([C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_int64] * 4 + [C.c_void_p] * 4 + [C.c_int, C.c_int64, C.c_int, C.c_float,
+                                                                                                           C.c_void_p], C.c_int),
     "dw_attn_bwd": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float, C.c_void_p], C.c_int),
     "dw_attn_bwd_ex": ([C.c_void_p] * 10 + [C.c_int] * 4 + [C.c_int64] * 8 + [C.c_int, C.c_float] + [C.c_void_p] * 3, C.c_int),
     "dw_distill_loss": ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_float,
@@ -216,11 +218,14 @@ class HipOps:
 
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
              r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
-             kv_append=None, colsum=None, z_row_pad=0, out_row_pad=0):
+             kv_append=None, colsum=None, z_row_pad=0, out_row_pad=0, overwrite=False):
         """C = op(a) @ op(b) with the fused epilogue of dw_gemm_bf16.  a: [M,K] (or [K,M] if trans_a);
         b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1.
         atomic_acc: out (fp32) += result via float atomics, with the K range split over several workgroups when the
         output has too few tiles to fill the 256 CUs (weight-gradient GEMMs: small M x N, K = all tokens).
+        overwrite (with atomic_acc, split-K launches only): the combination of the partial slabs STORES `out` instead of adding to
+        it -- the caller knows `out` holds zeros (first micro-batch after the gradient buffer was cleared), so reading it back is
+        4 bytes per weight per step for nothing.
         Decode-step fusions (M <= 32 / 64, skinny kernel): ln=(gamma, beta[, eps]) makes the operand
         bf16(LayerNorm(a)) with `a` the f32 / bf16 residual stream; kv_append=(cache, split, rows_per_batch,
         batch_pitch, row0) stores output columns >= split into the K/V cache rows of their positions."""
@@ -320,7 +325,7 @@ class HipOps:
         self._chk(self.lib.dw_gemm_bf16(C.byref(g), self._stream()), f"gemm m={M} n={N} k={K} ta={trans_a} tb={trans_b}")
         if ws is not None:
             self._chk(self.lib.dw_reduce_slices_ld(ws.data_ptr(), g.slice_stride, g.ldc, g.split_k, out.data_ptr(), out.stride(0),
-                                                   M, N, 1, self._stream()), "reduce_slices")
+                                                   M, N, 0 if overwrite else 1, self._stream()), "reduce_slices")
         key = f"gemm_t{tile_key}_{'T' if trans_a else 'N'}{'T' if trans_b else 'N'}"
         if self.profile_detail:
             key += (f" m{M} n{N} k{K} c{'f32' if out.dtype == torch.float32 else 'bf16'}"
@@ -369,6 +374,22 @@ class HipOps:
                                                _p(dgamma), _p(dbeta), _p(out_lowp), _p(colsum), rows, cols,
                                                dy.stride(0), x.stride(0), dres.stride(0), ldl, self._stream()), "layernorm_bwd")
         return dres
+
+    def attn_fwd_varlen(self, q, k, v, H, max_q, q_start, q_len, causal, scale, out, Lk=0, kv_batches=0, self_attention=True,
+                        flops=0.0):
+        """Ragged batches over packed rows (dw_attn_fwd_varlen).  q_start / q_len: int32 device tensors, one entry per sequence.
+        self_attention: k / v are rows of the same packed buffers; otherwise k / v are [kv_batches * Lk] rectangular rows."""
+        for t in (q, k, v, out):
+            assert t.dtype == torch.bfloat16 and t.stride(1) == 1
+        assert q_start.dtype == torch.int32 and q_len.dtype == torch.int32 and q_start.numel() == q_len.numel()
+        n = q_start.numel()
+        e0 = self._t0()
+        self._chk(self.lib.dw_attn_fwd_varlen(_p(q), _p(k), _p(v), _p(out), n, H, int(max_q), int(Lk), q.stride(0), k.stride(0),
+                                              v.stride(0), out.stride(0), _p(q_start), _p(q_len),
+                                              _p(q_start) if self_attention else None, _p(q_len) if self_attention else None,
+                                              int(kv_batches), int(Lk), int(causal), float(scale), self._stream()), "attn_fwd_varlen")
+        self._t1(e0, "attn_fwd", flops)
+        return out
 
     def attn_fwd(self, q, k, v, B, H, Lq, Lk, causal, scale, out=None, kv_batch_rows=None):
         """kv_batch_rows: rows between consecutive batches of k/v in memory (a padded KV cache), default Lk."""

@@ -141,6 +141,17 @@ int dw_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 int dw_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t q_batch_rows, int64_t kv_batch_rows,
                    int causal, float scale, void* stream);
+/* Forward over RAGGED batches of packed rows (forward-only passes: the frozen teacher's decoder over the live positions of a
+ * batch, run_distillation.py:1472-1480 with the dead decoder positions left out; no lse).  n_seq sequences; sequence i has
+ * q_len[i] (1 <= q_len[i] <= max_q) queries at rows q_start[i], q_start[i] + 1, ... of q / o (int32 arrays on the device).
+ * Self-attention: kv_start = q_start and kv_len = q_len -- keys / values are rows of the same packed buffers (causal 0 / 1).
+ * Cross-attention: kv_start = kv_len = NULL -- k / v are [kv_batches][kv_batch_rows] rectangles with Lk valid rows each and
+ * sequence i reads batch min(i, kv_batches - 1) (n_seq may exceed kv_batches by filler sequences whose results are unused).
+ * Same arithmetic per query as dw_attn_fwd over the rectangular layout (bit-identical rows). */
+int dw_attn_fwd_varlen(const void* q, const void* k, const void* v, void* o, int n_seq, int H, int max_q, int Lk, int64_t ldq,
+                       int64_t ldk, int64_t ldv, int64_t ldo, const int32_t* q_start, const int32_t* q_len,
+                       const int32_t* kv_start, const int32_t* kv_len, int kv_batches, int64_t kv_batch_rows, int causal,
+                       float scale, void* stream);
 /* delta: caller-owned f32 scratch of 2*B*H*Lq elements (the dQ kernel stores -rowsum(dO*O) and -lse/scale of its queries
  * there; the dK/dV kernel, launched behind it, starts its accumulators from them).  dq/dk/dv bf16 with row strides
  * lddq/lddk/lddv. */

@@ -62,8 +62,10 @@ class RefOps:
     # nn.Linear under bf16 autocast: bf16 operands, fp32 accumulation (TF:modeling_whisper.py:279-282 etc.)
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
              r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
-             kv_append=None, colsum=None, z_row_pad=0, out_row_pad=0):
-        # (z_row_pad / out_row_pad: memory layout of the HIP path's buffers, nothing to restate here)
+             kv_append=None, colsum=None, z_row_pad=0, out_row_pad=0, overwrite=False):
+        # (z_row_pad / out_row_pad: memory layout of the HIP path's buffers, nothing to restate here; overwrite: the HIP path's
+        # split-K combine stores instead of adding when the caller knows `out` holds zeros -- the restatement always adds, so a
+        # wrong `overwrite` from the engine shows up as a gradient mismatch in the tests that inject this class)
         out_dtype = self.lowp if out_dtype is None else out_dtype
         if ln is not None:                     # operand = bf16(LayerNorm(a)) (decode-step fusion of the HIP kernel)
             a = self.layernorm_fwd(a, ln[0], ln[1], ln[2] if len(ln) > 2 else 1e-5, save_stats=False)[0]
@@ -162,6 +164,22 @@ class RefOps:
             out.copy_(o)
             o = out
         return o, lse
+
+    def attn_fwd_varlen(self, q, k, v, H, max_q, q_start, q_len, causal, scale, out, Lk=0, kv_batches=0, self_attention=True,
+                        flops=0.0):
+        # ragged batches over packed rows (include/dwamd.h dw_attn_fwd_varlen): sequence i = rows q_start[i] ... + q_len[i]
+        for i, (s0, n) in enumerate(zip(q_start.tolist(), q_len.tolist())):
+            if n == 0:
+                continue
+            qi = q[s0:s0 + n]
+            if self_attention:
+                ki, vi, lk = k[s0:s0 + n], v[s0:s0 + n], n
+            else:
+                b = min(i, kv_batches - 1)
+                ki, vi, lk = k[b * Lk:(b + 1) * Lk], v[b * Lk:(b + 1) * Lk], Lk
+            o, _ = self.attn_fwd(qi, ki, vi, 1, H, n, lk, causal, scale)
+            out[s0:s0 + n].copy_(o)
+        return out
 
     def attn_bwd(self, q, k, v, o, do, lse, B, H, Lq, Lk, causal, scale, dq=None, dk=None, dv=None, dq_colsum=None,
                  dv_colsum=None):

@@ -557,6 +557,40 @@ def test_attention_bottom_right_causal_against_padded_kv_cache(ops, ref, B, H, L
     assert relerr(o.view(B, Lq, D)[:, -1], o1) < 5e-3      # (a couple of bf16 ulps: tile kernel vs streaming kernel)
 
 
+@pytest.mark.parametrize("H,T,lens,Lk", [(2, 40, [7, 40, 1, 33], 70), (1, 224, [130, 224, 64, 65, 1], 1500), (3, 96, [96, 5], 200)])
+def test_attention_varlen_equals_rectangular_rows(ops, ref, H, T, lens, Lk):
+    """dw_attn_fwd_varlen over packed rows (the frozen teacher's decoder over the live positions of a batch): every live row is
+    BIT-IDENTICAL to the row dw_attn_fwd computes over the (batch, position) rectangle -- causal self-attention whose keys /
+    values are rows of the same packed buffers, and cross-attention against rectangular K / V; filler pseudo-sequences and
+    zero-length table entries (a captured plan's fixed table) leave finite rows and touch nothing else."""
+    from distil_whisper_amd.engine import LiveRows
+    B, D = len(lens), H * 64
+    rect = rnd((B * T, 3 * D), 1.0, seed=70)
+    fill_to = sum(lens) + 9 if sum(lens) + 9 <= B * T else None
+    idx = LiveRows.host_index(lens, T, fill_to=fill_to).cuda()
+    st, ln = LiveRows.seq_table(lens, T, fill_to=fill_to, entries=B + 3 if fill_to else None)
+    st, ln = st.cuda(), ln.cuda()
+    R = idx.numel()
+    packed = rect.index_select(0, idx.long()).contiguous()
+    # causal self-attention
+    want, _ = ops.attn_fwd(rect[:, :D], rect[:, D:2 * D], rect[:, 2 * D:], B, H, T, T, True, 0.125)
+    got = torch.full((R + 4, D), float("nan"), device="cuda").bfloat16()
+    ops.attn_fwd_varlen(packed[:, :D], packed[:, D:2 * D], packed[:, 2 * D:], H, T, st, ln, True, 0.125, got[:R], self_attention=True)
+    n_live = sum(lens)
+    assert torch.equal(got[:n_live], want.index_select(0, idx[:n_live].long()))
+    assert torch.isfinite(got[:R].float()).all() and torch.isnan(got[R:].float()).all()     # filler rows finite, nothing behind written
+    r = ref.attn_fwd_varlen(packed[:, :D], packed[:, D:2 * D], packed[:, 2 * D:], H, T, st, ln, True, 0.125,
+                            torch.zeros_like(got[:R]), self_attention=True)
+    assert relerr(got[:n_live], r[:n_live]) < 1e-2
+    # cross-attention against rectangular keys / values
+    kv = rnd((B * Lk, 2 * D), 1.0, seed=71)
+    want, _ = ops.attn_fwd(rect[:, :D], kv[:, :D], kv[:, D:], B, H, T, Lk, False, 0.125)
+    got = torch.full((R + 4, D), float("nan"), device="cuda").bfloat16()
+    ops.attn_fwd_varlen(packed[:, :D], kv[:, :D], kv[:, D:], H, T, st, ln, False, 0.125, got[:R], Lk=Lk, kv_batches=B, self_attention=False)
+    assert torch.equal(got[:n_live], want.index_select(0, idx[:n_live].long()))
+    assert torch.isfinite(got[:R].float()).all() and torch.isnan(got[R:].float()).all()
+
+
 def test_attention_spiked_row(ops, ref):
     """Force the online-softmax rescale: one key per tile dominates a query's row."""
     B, H, L = 1, 1, 320

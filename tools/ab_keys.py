@@ -1,7 +1,8 @@
 """In-process A/B of dw_debug_set keys on the full distillation step (bench.py's batch: label lengths U{32..224}, packed live
 rows), interleaved rounds.  DW_AB = python list of configs, each a dict {key: value, ..., "lib": index}; keys not named keep
 the library default.  `lib` > 0 runs the config on distil_whisper_amd/libdwamd_base[N].so (another build on the same box).
-DW_STREAMS=1: teacher / weight-gradient side streams (bench.py's eager_side_streams)."""
+DW_STREAMS=1: teacher / weight-gradient side streams (bench.py's eager_side_streams).  String keys are Python-level switches:
+"varlen" (WhisperEngine.varlen_attention), "overwrite" (DistillationTrainer.overwrite_wgrad); default 1."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distil_whisper_amd.ops_hip import HipOps
@@ -33,7 +34,8 @@ libs = {0: ops.lib}
 base = os.path.join(os.path.dirname(_oh.LIB_PATH), "libdwamd_base.so")
 for i, path in [(1, base)] + [(j, base.replace("_base.so", f"_base{j}.so")) for j in (2, 3, 4, 5)]:
     if os.path.exists(path): libs[i] = _oh.load_library(path)
-allkeys = sorted({k for c in configs for k in c if k != "lib"})
+allkeys = sorted({k for c in configs for k in c if isinstance(k, int)})
+from distil_whisper_amd.engine import WhisperEngine
 DEF = {0: 2163, 1: 0, 3: 5, 6: 4, 9: 256, 10: 1, 11: 1, 12: 0, 20: 36, 22: 1, 23: 8, 24: 0, 25: 1, 26: 0, 27: 0, 28: 0}
 step(); torch.cuda.synchronize()
 res = [[] for _ in configs]
@@ -42,6 +44,8 @@ for r in range(int(os.environ.get("DW_ROUNDS", "4"))):
     for ci, c in enumerate(configs):
         ops.lib = libs[c.get("lib", 0)]
         for k in allkeys: ops.lib.dw_debug_set(k, c.get(k, DEF.get(k, 0)))
+        WhisperEngine.varlen_attention = bool(c.get("varlen", 1))
+        tr.overwrite_wgrad = bool(c.get("overwrite", 1))
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(NS): step()
