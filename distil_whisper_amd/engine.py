@@ -868,8 +868,9 @@ class WhisperEngine:
         tr_emb = st.is_trainable(emb)
         if tr_emb:
             # tied head: dE = dlogits^T . hf  (rows beyond V of the padded dlogits are not stored: m = V)
+            # (first writer of dE in a backward: after zero_small_grads() it may store; the embedding backward adds to it later)
             ops.gemm(dlogits[:, :d.vocab], ctx["hf"], trans_a=True, trans_b=True, out_dtype=torch.float32,
-                     out=st.g[emb], atomic_acc=True)
+                     out=st.g[emb], atomic_acc=True, overwrite=self.wgrad_overwrite)
         # dhf = dlogits . E : contraction over the padded vocabulary (pad columns of dlogits are zero; the rows of
         # the shadow buffer behind E are finite parameters / zero slack)
         eo = st.entries[emb][0]

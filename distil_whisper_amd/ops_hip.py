@@ -223,9 +223,9 @@ class HipOps:
         b: [N,K] (nn.Linear weight layout) or [K,N] if trans_b.  Inner strides must be 1.
         atomic_acc: out (fp32) += result via float atomics, with the K range split over several workgroups when the
         output has too few tiles to fill the 256 CUs (weight-gradient GEMMs: small M x N, K = all tokens).
-        overwrite (with atomic_acc, split-K launches only): the combination of the partial slabs STORES `out` instead of adding to
-        it -- the caller knows `out` holds zeros (first micro-batch after the gradient buffer was cleared), so reading it back is
-        4 bytes per weight per step for nothing.
+        overwrite (with atomic_acc): the caller knows `out` holds zeros (first micro-batch after the gradient buffer was cleared) --
+        the combination of the partial slabs STORES `out` instead of adding to it, and a single-slice launch stores its tiles
+        instead of issuing one float atomic per element (the tied LM head's dE: 66 M atomics per step).
         Decode-step fusions (M <= 32 / 64, skinny kernel): ln=(gamma, beta[, eps]) makes the operand
         bf16(LayerNorm(a)) with `a` the f32 / bf16 residual stream; kv_append=(cache, split, rows_per_batch,
         batch_pitch, row0) stores output columns >= split into the K/V cache rows of their positions."""
@@ -283,6 +283,8 @@ class HipOps:
                 ws = self.empty((sk, M, ldw), torch.float32)
                 g.c, g.ldc = ws.data_ptr(), ldw
                 g.split_k, g.slice_stride = sk, M * ldw
+            elif overwrite:
+                g.atomic_acc, g.split_k = 0, 1         # one slice into a buffer that holds zeros: plain fp32 stores, no float atomics
             else:
                 g.atomic_acc, g.split_k = 1, 1
         if ln is not None:
