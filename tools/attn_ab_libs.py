@@ -11,6 +11,12 @@ _base = ops_hip.load_library(_bp) if os.path.exists(_bp) else _new
 # tag -> (library, {dw_debug_set key: value}): 16 / 17 = waves per workgroup of the forward / backward kernels, 18 = 1: plain
 # workgroup order instead of the XCD-aware one
 libs = {"base": (_base, {16: 4, 17: 4, 18: 0}), "new": (_new, {16: 4, 17: 4, 18: 0})}
+if os.environ.get("DW_ATTN_ALL_LIBS"):   # every libdwamd_base[N].so next to the library (compiler-flag variants, tools/build_variant_lib.sh); "base" = the current build
+    libs = {"base": (_new, {16: 4, 17: 4, 18: 0})}
+    for j in ("", "2", "3", "4", "5"):
+        pj = _bp.replace("_base.so", f"_base{j}.so")
+        if os.path.exists(pj):
+            libs[f"lib{j or 1}"] = (ops_hip.load_library(pj), {16: 4, 17: 4, 18: 0})
 if os.environ.get("DW_ATTN_STAGE"):      # dw_debug_set key 3 (bit 0: dq, bit 1: dkv 32-bit staging flag, bit 2: dkv at three waves per SIMD)
     libs = {f"stage {v}": (_new, {16: 4, 17: 4, 18: 0, 3: v}) for v in (5, 1, 7, 3)}
     libs["base"] = libs.pop("stage 5")
