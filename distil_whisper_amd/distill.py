@@ -348,7 +348,7 @@ class DistillationTrainer:
         del logits_t
         self._gate = losses[3:4] if (zero_grad or self._gate is None) else self._gate + losses[3:4]
         if zero_grad:
-            S.zero_small_grads()
+            S.zero_small_grads(skip_weights=self.overwrite_wgrad)
         st = self.student_store
         dp = self.reducer is not None and self.reducer.active and sync_grads
         S.wgrad_overwrite = bool(zero_grad) and self.overwrite_wgrad   # (the buffer was just cleared: the layers' weight gradients are stored, not added)

@@ -140,6 +140,23 @@ class ParamStore:
             self.s[name] = self.S[o:o + n].view(shape)
             if self.G is not None and o >= self.train_start:
                 self.g[name] = self.G[o:o + n].view(shape)
+        # Ranges of G that are ACCUMULATED into (atomics / += : biases, LayerNorm parameters, embeddings, the convolution
+        # weights' unpack) as opposed to the layers' weight matrices, which their weight-gradient GEMMs can store outright
+        # (engine.wgrad_overwrite): merged into contiguous views, cleared by one multi-tensor fill instead of a 3 GB one.
+        self.small_grad_views = []
+        if self.G is not None:
+            rng = []
+            for name, (o, shape, kind) in self.entries.items():
+                if o < self.train_start or kind == "w":
+                    continue
+                n = 1
+                for d in shape:
+                    n *= d
+                if rng and rng[-1][1] == o:
+                    rng[-1][1] = o + _rup(n, 64)
+                else:
+                    rng.append([o, o + _rup(n, 64)])
+            self.small_grad_views = [self.G[a:b] for a, b in rng]
         self.kpad1 = _rup(3 * dims.n_mels, 64)
         self.conv1_packed = ops.zeros((D, self.kpad1), ops.lowp)
         self.conv2_packed = ops.zeros((D, 3 * D), ops.lowp)
@@ -962,9 +979,15 @@ class WhisperEngine:
             on_ready(st.train_start, hi)
         self._enc_ready_hi = None
 
-    def zero_small_grads(self):
+    def zero_small_grads(self, skip_weights=False):
         """Bias / LayerNorm / embedding gradients are accumulated with atomics: zero the gradient buffer's trainable
-        range before a (non-accumulating) backward.  Weight-matrix gradients are overwritten by their GEMMs."""
+        range before a (non-accumulating) backward.  skip_weights: the caller runs the backward with wgrad_overwrite, so
+        the layers' weight matrices (97 % of the range) are stored by their GEMMs and only the accumulated ranges are
+        cleared (ParamStore.small_grad_views, one multi-tensor fill)."""
         st = self.st
-        if st.G is not None:
+        if st.G is None:
+            return
+        if skip_weights and st.small_grad_views:
+            torch._foreach_zero_(st.small_grad_views)
+        else:
             st.G[st.train_start:st.train_end].zero_()

@@ -462,10 +462,17 @@ class _EngineFn(torch.autograd.Function):
                     buf[: B * T, :V].copy_(g_logits.reshape(B * T, V))
                 else:
                     buf[: ctx.sel.n, :V].copy_(ctx.sel.select(g_logits.reshape(B * T, V)))
-        eng.zero_small_grads()
-        denc = eng.backward_decoder(ctx.dctx, buf, want_denc=ctx.ectx is not None)
-        if ctx.ectx is not None:
-            eng.backward_encoder(ctx.ectx, denc)
+        # (the flat buffer is this backward's scratch: cleared here, so the layers' weight gradients are stored, not added)
+        # (not when this backward stops at `encoder_outputs` while the encoder is trainable: its weight gradients must read zero)
+        every_weight_written = ctx.ectx is not None or not st.is_trainable("model.encoder.layers.0.fc1.weight")
+        eng.zero_small_grads(skip_weights=every_weight_written)
+        eng.wgrad_overwrite = True
+        try:
+            denc = eng.backward_decoder(ctx.dctx, buf, want_denc=ctx.ectx is not None)
+            if ctx.ectx is not None:
+                eng.backward_encoder(ctx.ectx, denc)
+        finally:
+            eng.wgrad_overwrite = False
         # copies of the flat gradient buffer's ranges: the buffer is zeroed and rewritten by the next backward, so a
         # returned view would change under torch.autograd.grad results, tensor hooks or DDP bucket views that keep it.
         # (AccumulateGrad takes ownership of a fresh non-view gradient without copying it again: still one copy.)

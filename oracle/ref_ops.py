@@ -63,9 +63,9 @@ class RefOps:
     def gemm(self, a, b, *, trans_a=False, trans_b=False, bias=None, act=0, want_z=False, zgrad=None, residual=None,
              r_row_mod=0, round_res=True, out_dtype=None, out=None, tile=0, atomic_acc=False, split_k=0, ln=None,
              kv_append=None, colsum=None, z_row_pad=0, out_row_pad=0, overwrite=False):
-        # (z_row_pad / out_row_pad: memory layout of the HIP path's buffers, nothing to restate here; overwrite: the HIP path's
-        # split-K combine stores instead of adding when the caller knows `out` holds zeros -- the restatement always adds, so a
-        # wrong `overwrite` from the engine shows up as a gradient mismatch in the tests that inject this class)
+        # (z_row_pad / out_row_pad: memory layout of the HIP path's buffers, nothing to restate here; overwrite: with atomic_acc,
+        # `out` is STORED instead of added to -- the engine only clears the accumulated ranges of the gradient buffer before such
+        # a backward, so stale values of the previous step sit in `out`)
         out_dtype = self.lowp if out_dtype is None else out_dtype
         if ln is not None:                     # operand = bf16(LayerNorm(a)) (decode-step fusion of the HIP kernel)
             a = self.layernorm_fwd(a, ln[0], ln[1], ln[2] if len(ln) > 2 else 1e-5, save_stats=False)[0]
@@ -103,7 +103,7 @@ class RefOps:
             rows = (m // rpb) * pitch + row0 + (m % rpb)
             cache.view(-1, v.shape[1] - split)[rows] = v[:, split:].to(cache.dtype)
         if out is not None:
-            if atomic_acc:
+            if atomic_acc and not overwrite:
                 out += v
             else:
                 out.copy_(v)
