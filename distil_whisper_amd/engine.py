@@ -363,6 +363,18 @@ class WhisperEngine:
                                       colsum=colsum_to if emit else None)
         return dres, nxt
 
+    def _train_scatter_buf(self, slot, rows, cols):
+        """(batch, position)-layout buffers of the PACKED TRAINING pass (pack_train_layers): one per (layer, operand) slot -- the
+        backward reads them -- zero-initialised once and only ever written with projected / computed rows, so rows that are dead
+        in this step hold finite values of an earlier one (all the attention kernels need of them: their dO is exactly zero)."""
+        if not hasattr(self, "_tsb"):
+            self._tsb = {}
+        key = (slot, cols)
+        buf = self._tsb.get(key)
+        if buf is None or buf.shape[0] < rows:
+            buf = self._tsb[key] = self.ops.zeros((_rup(rows, 64), cols), self.lowp)
+        return buf
+
     def _scatter_buf(self, rows, cols):
         """(batch, position)-layout target of the packed pass's scatter: zero-initialised once, afterwards it only ever
         receives projected rows, so its dead rows stay finite.  Buffers are never freed or replaced while the engine lives
@@ -407,6 +419,8 @@ class WhisperEngine:
         else:
             self._wgrad_issue(dy, x, gout, gbias, R, bias_cols)
 
+    pack_train_layers = True  # training passes with per-sequence label lengths: the decoder layers' row-local work (GEMMs, LayerNorm, their
+                              # backward) over the packed live rows, attention through the rectangle (False: the layers keep the rectangle)
     varlen_attention = True   # packed (live-row) forward passes: attention over ragged batches in place (False: scatter -> rectangle -> gather)
     wgrad_overwrite = False   # set by the trainer around a backward that follows zero_small_grads(): every weight matrix handed to
                               # _wgrad gets exactly one contribution per backward, so the split-K combine may store instead of add
@@ -492,14 +506,27 @@ class WhisperEngine:
         R = Rp if live is None else live.n          # valid rows of x
         Rg = R if Rg is None else Rg
         assert Rg == R or not save
-        assert live is None or not save
         lc = {} if save else None
+        rect = {}                              # (packed training pass: the rectangular q / k / v / o of this layer's attentions)
 
         def attend(q_src, k, v, Lkv, is_causal, cols):
             """q_src [>= R, cols] with the queries in its first D columns -> o [Rg, D]"""
             o = self.act(Rg, D, zero_pad=save, pad=self.row_pad)
             if live is None:
                 _, lse = ops.attn_fwd(q_src[:R, :D], k, v, B, H, L, Lkv, is_causal, 0.125, out=o[:R])
+                return o, lse
+            if save:
+                # Packed TRAINING pass (pack_train_layers): the row-local work of the layer runs over the live rows, attention --
+                # whose backward kernels want the (batch, position) rectangle -- between a scatter and a gather, on buffers this
+                # layer keeps for its backward.  Dead rows of the rectangle: finite values (see _train_scatter_buf).
+                tag = "x" if k is not None else "s"
+                qp = self._train_scatter_buf((p, tag, "q"), Rp, cols)
+                ops.scatter_rows(q_src[:R], live.idx, qp)
+                op = self._train_scatter_buf((p, tag, "o"), Rp, D)
+                kk, vv = (qp[:Rp, D:2 * D], qp[:Rp, 2 * D:]) if k is None else (k, v)
+                _, lse = ops.attn_fwd(qp[:Rp, :D], kk, vv, B, H, L, Lkv, is_causal, 0.125, out=op[:Rp])
+                ops.gather_rows(op, live.idx, o)
+                rect[tag] = (qp, op)
                 return o, lse
             if live.seq_start is not None and self.varlen_attention:
                 # ragged batches: the kernel walks the packed rows of every sequence in place (same arithmetic per query row as over
@@ -535,6 +562,8 @@ class WhisperEngine:
         x1 = ops.gemm(o[:Rg], av["wo"], bias=av["bo"], residual=x, round_res=True, out_dtype=self.stream, out_row_pad=xp)
         if save:
             lc.update(x0=x, mu0=mu, rs0=rs, h0=h, qkv=qkv, o0=o, lse0=lse)
+            if live is not None:
+                lc.update(qkv_r=rect["s"][0], o0_r=rect["s"][1])
         x = x1
         # --- cross attention (decoder only)
         if enc_out is not None:
@@ -549,6 +578,8 @@ class WhisperEngine:
             x1 = ops.gemm(o[:Rg], cv["wo"], bias=cv["bo"], residual=x, round_res=True, out_dtype=self.stream, out_row_pad=xp)
             if save:
                 lc.update(x1=x, mu1=mu, rs1=rs, h1=h, q1=q, kv1=kv, o1=o, lse1=lse)
+                if live is not None:
+                    lc.update(q1_r=rect["x"][0], o1_r=rect["x"][1])
             x = x1
         # --- feed forward
         h, mu, rs = self._ln(f"{p}.final_layer_norm", x, R, save, Rg, pad=self.row_pad)
@@ -569,15 +600,17 @@ class WhisperEngine:
         enc_out low-precision [>= B*Lk, D].  Returns (logits low-precision [rows, ldv] with V valid columns, ctx); rows =
         B*T in (batch, position) order, or -- with `live` (LiveRows) -- its n live rows in packed order:
           * forward-only pass (the frozen teacher): the whole decoder runs over the packed rows (_layer_fwd);
-          * training pass: the layers keep the (batch, position) layout (their backward does), the LM head and with it
-            dE = dlogits^T . hf and dhf = dlogits . E run over the live rows only."""
+          * training pass: the LM head and with it dE = dlogits^T . hf and dhf = dlogits . E run over the live rows only; with
+            pack_train_layers (default) so does every row-local operation of the layers, forward and backward -- attention alone
+            goes through the (batch, position) rectangle its backward kernels want (_layer_fwd / _layer_bwd); otherwise the layers
+            keep the rectangle."""
         ops, st, d = self.ops, self.st, self.dims
         B, T = ids.shape
         R, Lk = B * T, d.max_src
         assert live is None or (live.B == B and live.T == T)
         ctx = {"B": B, "T": T, "R": R, "ids": ids, "layers": [], "enc_out": enc_out} if save else None
-        packed = live is not None and not save
-        if packed and getattr(self, "_sb", None):
+        packed = live is not None and (not save or self.pack_train_layers)
+        if packed and not save and getattr(self, "_sb", None):
             # The dead rows of the scatter targets must be finite (see _layer_fwd.attend).  They only ever receive
             # projected rows, but one overflowing row of one bad batch would stay in a dead slot for the rest of the run
             # and reach later batches through 0 x NaN: one fill per buffer and pass (two fills of a 32-layer pass).
@@ -585,6 +618,7 @@ class WhisperEngine:
                 for b_ in bufs:
                     b_.zero_()
         Rv = live.n if packed else R                 # rows the layers run over
+        self._last_decode_rows = Rv                  # (tests)
         Rg = self._gemm_rows(Rv, save)
         if self.stream == torch.float32:
             x = ops.embed_fwd(ids, st.p["model.decoder.embed_tokens.weight"],
@@ -610,7 +644,7 @@ class WhisperEngine:
             Rl = _rup(Rh, 320)
             Rl = Rl if Rl - Rh <= Rh * self.pad_gemm_rows_slack else Rh
         hf, mu, rs = self._ln("model.decoder.layer_norm", x, Rv, save, max(Rl, Rv))
-        if live is not None and save:                # (batch, position) rows of the final LayerNorm -> live rows
+        if live is not None and save and not packed: # (batch, position) rows of the final LayerNorm -> live rows
             hfp, hf = hf, self.act(Rl, d.d_model)
             ops.gather_rows(hfp, live.idx, hf)
             del hfp
@@ -624,7 +658,7 @@ class WhisperEngine:
         e_pad = st.S[eo:eo + self.ldv * d.d_model].view(self.ldv, d.d_model)
         ops.gemm(hf[:Rh], e_pad, out=logits[:Rh])
         if save:
-            ctx.update(x_final=x, mu=mu, rs=rs, hf=hf, lm_rows=Rl, live=live)
+            ctx.update(x_final=x, mu=mu, rs=rs, hf=hf, lm_rows=Rl, live=live, packed=packed, Rv=Rv)
         return logits, ctx
 
     # ---- incremental decoding with a KV cache (TF:modeling_whisper.py:312-335, EncoderDecoderCache) -----------------
@@ -813,15 +847,23 @@ class WhisperEngine:
     def _bias_grad(self, name):
         return self.st.g[name] if self.st.is_trainable(name) else None
 
-    def _layer_bwd(self, p, lc, dres, dy, B, L, Lk, causal, denc, emit_last, colsum_last):
+    def _layer_bwd(self, p, lc, dres, dy, B, L, Lk, causal, denc, emit_last, colsum_last, live=None):
         """Backward of _layer_fwd.  dres: fp32 [R, D] gradient w.r.t. the layer output (updated in place to the
         gradient w.r.t. the layer input); dy: its low-precision copy, whose column sums were already added to this
         layer's fc2.bias gradient by the kernel that produced it.  denc: fp32 [Re, D] accumulator for the encoder
         output gradient.  Returns (dres, dy_for_the_layer_below)."""
         ops, st, d = self.ops, self.st, self.dims
-        D, H, R = d.d_model, d.heads, B * L
+        D, H, Rp = d.d_model, d.heads, B * L
+        R = Rp if live is None else live.n      # live (packed training pass, _layer_fwd): row-local work over the live rows, attention
+                                                # over the layer's rectangular buffers between a scatter and a gather
         tr = st.is_trainable(f"{p}.fc1.weight")
         cross = "x1" in lc
+
+        def to_rect(t, cols):
+            """packed rows -> a ZEROED (batch, position) rectangle (a row that is dead in this step must contribute nothing)"""
+            r = ops.zeros((_rup(Rp, 64), cols), t.dtype)
+            ops.scatter_rows(t[:R], live.idx, r)
+            return r
         # --- feed forward
         dz = self.act(R, d.ffn, pad=self.ffn_row_pad)
         # (fc1.bias gradient = column sums of dz: accumulated by this GEMM's epilogue, no separate pass over dz)
@@ -844,9 +886,18 @@ class WhisperEngine:
             dq = self.act(R, D, pad=self.row_pad)
             dkv = self.act(Re, 2 * D, pad=self.row_pad)
             fb = tr and self.fuse_attn_bias_grad      # q / v bias gradients from the attention-backward kernels
-            ops.attn_bwd(lc["q1"][:R], lc["kv1"][:Re, :D], lc["kv1"][:Re, D:], lc["o1"][:R], do, lc["lse1"], B, H, L,
-                         Lk, False, 0.125, dq=dq[:R], dk=dkv[:Re, :D], dv=dkv[:Re, D:],
-                         dq_colsum=cv["g_bqkv"][:D] if fb else None, dv_colsum=cv["g_bqkv"][2 * D:] if fb else None)
+            if live is None:
+                ops.attn_bwd(lc["q1"][:R], lc["kv1"][:Re, :D], lc["kv1"][:Re, D:], lc["o1"][:R], do, lc["lse1"], B, H, L,
+                             Lk, False, 0.125, dq=dq[:R], dk=dkv[:Re, :D], dv=dkv[:Re, D:],
+                             dq_colsum=cv["g_bqkv"][:D] if fb else None, dv_colsum=cv["g_bqkv"][2 * D:] if fb else None)
+            else:
+                do_r = to_rect(do, D)
+                dq_r = self.act(Rp, D, zero_pad=False)
+                ops.attn_bwd(lc["q1_r"][:Rp], lc["kv1"][:Re, :D], lc["kv1"][:Re, D:], lc["o1_r"][:Rp], do_r[:Rp], lc["lse1"], B, H, L,
+                             Lk, False, 0.125, dq=dq_r[:Rp], dk=dkv[:Re, :D], dv=dkv[:Re, D:],
+                             dq_colsum=cv["g_bqkv"][:D] if fb else None, dv_colsum=cv["g_bqkv"][2 * D:] if fb else None)
+                ops.gather_rows(dq_r, live.idx, dq)
+                del do_r, dq_r
             if tr:
                 self._wgrad(dy, lc["o1"], cv["g_wo"], None, R)
                 self._wgrad(dq, lc["h1"], cv["g_wqkv"][:D], None if fb else cv["g_bqkv"][:D], R)
@@ -864,9 +915,19 @@ class WhisperEngine:
         dqkv = self.act(R, 3 * D, pad=self.row_pad)
         qkv = lc["qkv"]
         fb = tr and self.fuse_attn_bias_grad
-        ops.attn_bwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], lc["o0"][:R], do, lc["lse0"], B, H, L, L, causal,
-                     0.125, dq=dqkv[:R, :D], dk=dqkv[:R, D:2 * D], dv=dqkv[:R, 2 * D:],
-                     dq_colsum=av["g_bqkv"][:D] if fb else None, dv_colsum=av["g_bqkv"][2 * D:] if fb else None)
+        if live is None:
+            ops.attn_bwd(qkv[:R, :D], qkv[:R, D:2 * D], qkv[:R, 2 * D:], lc["o0"][:R], do, lc["lse0"], B, H, L, L, causal,
+                         0.125, dq=dqkv[:R, :D], dk=dqkv[:R, D:2 * D], dv=dqkv[:R, 2 * D:],
+                         dq_colsum=av["g_bqkv"][:D] if fb else None, dv_colsum=av["g_bqkv"][2 * D:] if fb else None)
+        else:
+            qr = lc["qkv_r"]
+            do_r = to_rect(do, D)
+            dqkv_r = self.act(Rp, 3 * D, zero_pad=False)
+            ops.attn_bwd(qr[:Rp, :D], qr[:Rp, D:2 * D], qr[:Rp, 2 * D:], lc["o0_r"][:Rp], do_r[:Rp], lc["lse0"], B, H, L, L, causal,
+                         0.125, dq=dqkv_r[:Rp, :D], dk=dqkv_r[:Rp, D:2 * D], dv=dqkv_r[:Rp, 2 * D:],
+                         dq_colsum=av["g_bqkv"][:D] if fb else None, dv_colsum=av["g_bqkv"][2 * D:] if fb else None)
+            ops.gather_rows(dqkv_r, live.idx, dqkv)
+            del do_r, dqkv_r
         if tr:
             self._wgrad(dy, lc["o0"], av["g_wo"], None, R)
             self._wgrad(dqkv, lc["h0"], av["g_wqkv"], None if fb else av["g_bqkv"], R, bias_cols=[(0, D), (2 * D, 3 * D)])
@@ -896,25 +957,32 @@ class WhisperEngine:
         assert dlogits.shape[0] >= Rl
         dh = ops.gemm(dlogits[:Rl], e_pad, trans_b=True)      # rows R..Rl of dlogits are zero (decode, pad_lm_rows)
         live = ctx.get("live")
-        if live is not None:                                  # packed LM-head rows -> (batch, position); dead rows: zero
+        packed = bool(ctx.get("packed")) and live is not None
+        Rv = ctx["Rv"] if packed else R                       # rows the layers' backward runs over
+        if live is not None and not packed:                   # packed LM-head rows -> (batch, position); dead rows: zero
             dhp = self.act(R, D)
             dhp[:R].zero_()
             ops.scatter_rows(dh, live.idx, dhp)
             dh = dhp
         nl = d.dec_layers
-        dres, dy = self._ln_bwd("model.decoder.layer_norm", dh, ctx["x_final"], ctx["mu"], ctx["rs"], None, R,
+        dres, dy = self._ln_bwd("model.decoder.layer_norm", dh, ctx["x_final"], ctx["mu"], ctx["rs"], None, Rv,
                                 emit=True, colsum_to=self._bias_grad(f"model.decoder.layers.{nl - 1}.fc2.bias"))
         denc = ops.zeros((B * Lk, D), torch.float32) if want_denc else None
         for i in reversed(range(nl)):
             lc = ctx["layers"][i]
             lc["enc_out"] = ctx["enc_out"]
             below = self._bias_grad(f"model.decoder.layers.{i - 1}.fc2.bias") if i > 0 else None
-            dres, dy = self._layer_bwd(f"model.decoder.layers.{i}", lc, dres, dy, B, T, Lk, True, denc, i > 0, below)
+            dres, dy = self._layer_bwd(f"model.decoder.layers.{i}", lc, dres, dy, B, T, Lk, True, denc, i > 0, below,
+                                       live=live if packed else None)
             ctx["layers"][i] = None
             self._wgrad_fence()
         if tr_emb or st.is_trainable("model.decoder.embed_positions.weight"):
             dtok = st.g[emb] if tr_emb else self._scratch_tok()
             dpos = st.g.get("model.decoder.embed_positions.weight")
+            if packed:                                        # live rows -> (batch, position); dead rows: zero
+                dres_r = ops.zeros((R, D), dres.dtype)
+                ops.scatter_rows(dres[:Rv], live.idx, dres_r)
+                dres = dres_r
             ops.embed_bwd(dres, ctx["ids"], dtok, dpos)
         return denc
 

@@ -389,3 +389,40 @@ def test_live_rows_filled_with_dead_rows_and_integer_spellings():
     l2, g2 = run(Te, LiveRows(h, 40, 2, Te))
     assert l2[3].item() == l0[3].item()
     assert torch.allclose(l0, l2, rtol=1e-6, atol=0) and relerr(g2, g0) < 1e-6
+
+
+def test_packed_training_decoder_layers_equal_rectangular_layers():
+    """engine.pack_train_layers: with per-sequence label lengths the student's decoder layers run their row-local work (GEMMs,
+    LayerNorm, the backward of both) over the packed live rows and only attention over the (batch, position) rectangle; losses and
+    every gradient equal the rectangular layers' (fp32 restatement: summation order only), also with filler rows in the list and
+    over two steps (stale dead rows of the per-layer rectangles from the first step are harmless in the second)."""
+    from distil_whisper_amd.engine import LiveRows, WhisperEngine
+    cfg_t, cfg_s, t_sd, s_sd, batch = setup(T=37)
+    labels = batch["labels"].clone()
+    labels[0, 19:] = -100
+    labels[1, 11:] = -100
+    labels2 = batch["labels"].clone()
+    labels2[0, 7:] = -100
+    labels2[1, 23:] = -100
+    ops = RefOps("cpu", lowp=torch.float32)
+    Te = 24
+
+    def run(pack):
+        WhisperEngine.pack_train_layers = pack
+        try:
+            tr = DistillationTrainer(ops, s_sd, cfg_s, t_sd, cfg_t)
+            out = []
+            for lab, lens, fill in ((labels, [19, 11], 40), (labels2, [7, 23], None)):
+                h = LiveRows.host_index(lens, Te, fill_to=fill)
+                losses = tr.forward_backward(batch["input_features"], batch["decoder_input_ids"], lab, valid_len=Te,
+                                             _live=LiveRows(h, h.numel(), 2, Te))
+                out.append((losses.clone(), tr.student_store.G.clone()))
+            rows = tr.student._last_decode_rows
+            return out, rows
+        finally:
+            WhisperEngine.pack_train_layers = True
+    a, rows_a = run(True)
+    b, rows_b = run(False)
+    assert rows_a == 30 and rows_b == 2 * Te          # (second step: 7 + 23 live rows against the 48-row rectangle)
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert torch.allclose(la, lb, rtol=1e-6, atol=0) and relerr(ga, gb) < 1e-6

@@ -2,7 +2,7 @@
 rows), interleaved rounds.  DW_AB = python list of configs, each a dict {key: value, ..., "lib": index}; keys not named keep
 the library default.  `lib` > 0 runs the config on distil_whisper_amd/libdwamd_base[N].so (another build on the same box).
 DW_STREAMS=1: teacher / weight-gradient side streams (bench.py's eager_side_streams).  String keys are Python-level switches:
-"varlen" (WhisperEngine.varlen_attention), "overwrite" (DistillationTrainer.overwrite_wgrad); default 1."""
+"varlen" (WhisperEngine.varlen_attention), "pack" (WhisperEngine.pack_train_layers), "overwrite" (DistillationTrainer.overwrite_wgrad); default 1."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distil_whisper_amd.ops_hip import HipOps
@@ -45,6 +45,7 @@ for r in range(int(os.environ.get("DW_ROUNDS", "4"))):
         ops.lib = libs[c.get("lib", 0)]
         for k in allkeys: ops.lib.dw_debug_set(k, c.get(k, DEF.get(k, 0)))
         WhisperEngine.varlen_attention = bool(c.get("varlen", 1))
+        WhisperEngine.pack_train_layers = bool(c.get("pack", 1))
         tr.overwrite_wgrad = bool(c.get("overwrite", 1))
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
