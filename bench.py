@@ -31,11 +31,12 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 
 
-def step_flops(d, mode, T=447, rows=None):
+def step_flops(d, mode, T=447, rows=None, sq=None):
     """Algorithmic FLOPs per 30 s sample (2 x MAC, causal attention counted full, no recompute): SURVEY.md section 8(d).
     T = decoder positions the step computes (447, or the live ones when the dead tail of the batch is left out);
-    rows = average packed rows per sample of the passes that run over live rows only (frozen teacher decoder: its
-    row-local work; both LM heads), T when nothing is packed."""
+    rows = average packed rows per sample of the passes that run over live rows only (the frozen teacher's decoder, the
+    row-local work of the student's decoder layers, both LM heads), T when nothing is packed; sq = mean squared sequence
+    length (ragged-batch self-attention of the packed teacher decoder: sum of len^2 instead of T^2 per sample)."""
     S = 1500
     D, V, M = d.d_model, d.vocab, d.n_mels
     rows = T if rows is None else rows
@@ -43,8 +44,10 @@ def step_flops(d, mode, T=447, rows=None):
     def enc(le):
         return 6 * M * D * 3000 + 6 * D * D * 1500 + le * (24 * S * D * D + 4 * S * S * D)
 
-    def dec(ld, packed=False):
+    def dec(ld, packed=False, ragged_attention=False):
         r = rows if packed else T
+        if ragged_attention and sq is not None:     # attention over the live rows only (dw_attn_fwd_varlen)
+            return ld * (28 * r * D * D + 4 * S * D * D + 4 * sq * D + 4 * rows * S * D)
         return ld * (28 * r * D * D + 4 * S * D * D + 4 * T * T * D + 4 * T * S * D)
 
     head = 2 * rows * D * V
@@ -193,6 +196,7 @@ def main():
     valid_len = None if args.dense else (max(lens_host) if args.no_pack else lens_host)
     Te = T if valid_len is None else max(lens_host)
     rows_avg = sum(lens_host) / B if isinstance(valid_len, list) and sum(lens_host) < tr.pack_live_rows_below * B * Te else Te
+    sq_avg = sum(x * x for x in lens_host) / B if rows_avg != Te else None     # (packed passes: mean squared live length)
 
     use_graph = args.graph == "on" or (args.graph == "auto" and world == 1)
     if use_graph and world > 1:
@@ -343,12 +347,16 @@ def main():
     value = world * B * 30.0 * args.steps / dt
     loss_val = float(losses[2].item())
 
-    def sample_flops(Tc, rows=None):
-        enc, dec, head = step_flops(tdims, args.mode, Tc, rows)
+    # what runs over the packed live rows: the frozen teacher's decoder incl. its attention (ragged batches), the row-local
+    # work of the student's decoder layers (engine.pack_train_layers; their attention keeps the rectangle), both LM heads
+    ragged, spack = bool(tr.teacher.varlen_attention), bool(tr.student.pack_train_layers)      # (read now: `tr` is released before the JSON line)
+
+    def sample_flops(Tc, rows=None, sq=None):
+        enc, dec, head = step_flops(tdims, args.mode, Tc, rows, sq)
         if recipe:
-            return enc(tdims.enc_layers) + (dec(tdims.dec_layers, True) + head) + 3 * (dec(ld) + head)
-        return (enc(tdims.enc_layers) + dec(tdims.dec_layers, True) + head) + 3 * (enc(le) + dec(ld) + head)
-    fl = sample_flops(Te, rows_avg)     # the flops the step EXECUTES (the fraction of peak is priced on these)
+            return enc(tdims.enc_layers) + (dec(tdims.dec_layers, True, ragged) + head) + 3 * (dec(ld, spack) + head)
+        return (enc(tdims.enc_layers) + dec(tdims.dec_layers, True, ragged) + head) + 3 * (enc(le) + dec(ld, spack) + head)
+    fl = sample_flops(Te, rows_avg, sq_avg)     # the flops the step EXECUTES (the fraction of peak is priced on these)
     step_tflops = value / 30.0 * fl / 1e12 / world
 
     ab = None
