@@ -369,10 +369,12 @@ class WhisperEngine:
         in this step hold finite values of an earlier one (all the attention kernels need of them: their dO is exactly zero)."""
         if not hasattr(self, "_tsb"):
             self._tsb = {}
-        key = (slot, cols)
-        buf = self._tsb.get(key)
-        if buf is None or buf.shape[0] < rows:
-            buf = self._tsb[key] = self.ops.zeros((_rup(rows, 64), cols), self.lowp)
+        # (never freed or replaced: a captured step has the addresses baked in -- a larger plan ADDS a buffer, like _scatter_buf)
+        fits = [b for b in self._tsb.get((slot, cols), []) if b.shape[0] >= rows]
+        if fits:
+            return min(fits, key=lambda b: b.shape[0])
+        buf = self.ops.zeros((_rup(rows, 64), cols), self.lowp)
+        self._tsb.setdefault((slot, cols), []).append(buf)
         return buf
 
     def _scatter_buf(self, rows, cols):
