@@ -426,3 +426,23 @@ def test_packed_training_decoder_layers_equal_rectangular_layers():
     assert rows_a == 30 and rows_b == 2 * Te          # (second step: 7 + 23 live rows against the 48-row rectangle)
     for (la, ga), (lb, gb) in zip(a, b):
         assert torch.allclose(la, lb, rtol=1e-6, atol=0) and relerr(ga, gb) < 1e-6
+
+
+def test_live_rows_sequence_table():
+    """LiveRows.seq_table: (start, length) of every sequence's packed rows -- what dw_attn_fwd_varlen walks -- consistent with
+    host_index; filler rows are cut into pseudo-sequences of at most T rows and a captured plan's table is padded with empty
+    entries to its fixed size."""
+    from distil_whisper_amd.engine import LiveRows
+    lens, T = [5, 0, 8, 1], 8                      # (lengths are clamped to [1, T])
+    st, ln = LiveRows.seq_table(lens, T)
+    assert ln.tolist() == [5, 1, 8, 1] and st.tolist() == [0, 5, 6, 14] and st.dtype == torch.int32
+    idx = LiveRows.host_index(lens, T)
+    for b, (s0, n) in enumerate(zip(st.tolist(), ln.tolist())):
+        assert idx[s0:s0 + n].tolist() == [b * T + t for t in range(n)]
+    st, ln = LiveRows.seq_table(lens, T, fill_to=15 + 11, entries=8)
+    assert ln.tolist() == [5, 1, 8, 1, 8, 3, 0, 0] and st.tolist() == [0, 5, 6, 14, 15, 23, 26, 26]
+    assert int(ln.sum()) == LiveRows.host_index(lens, T, fill_to=26).numel()
+    with pytest.raises(ValueError):
+        LiveRows.seq_table(lens, T, fill_to=26, entries=5)
+    live = LiveRows.build(lens, T, "cpu")
+    assert live.max_q == 8 and live.seq_len.tolist() == [5, 1, 8, 1] and live.attn_flops == (91.0, 15.0)
