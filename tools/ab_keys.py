@@ -46,6 +46,7 @@ for r in range(int(os.environ.get("DW_ROUNDS", "4"))):
         for k in allkeys: ops.lib.dw_debug_set(k, c.get(k, DEF.get(k, 0)))
         WhisperEngine.varlen_attention = bool(c.get("varlen", 1))
         WhisperEngine.pack_train_layers = bool(c.get("pack", 1))
+        WhisperEngine.fuse_attn_bias_grad = bool(c.get("attn_bias", 0))     # q / v bias gradients from the attention-backward kernels
         tr.overwrite_wgrad = bool(c.get("overwrite", 1))
         step(); torch.cuda.synchronize()
         t0 = time.perf_counter()
